@@ -1,0 +1,206 @@
+#!/usr/bin/env python
+"""Benchmark of the PackPPI-MSC sampling path on MI355X (contract: see the task brief / DESIGN.md §Measurement).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one full ``sampling()`` pass (100 reverse-diffusion network evaluations, no proximal) over the
+rank's batch.  Workload at every N: ``data/T1124_lig.pdb`` (738 true residues, fixture
+tests/golden/g4_T1124.npz) per GPU -- BASELINE.json configs[1]; ranks hold independent complexes (weak scaling,
+no data-path collective); the only collective is the all-gather of per-complex metric rows.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_DIFFUSION_STEPS = 100
+# algorithmic FLOPs (2/MAC, dense projections only) of ONE launch of the dominant kernel (edge update), per edge:
+# edge message MLP 456->128->128->128 + FFN 128->512->128   (SURVEY.md §8d itemisation)
+EDGE_UPDATE_FLOP_PER_EDGE = 2 * (456 * 128 + 128 * 128 + 128 * 128) + 2 * (128 * 512 + 512 * 128)
+NODE_MSG_FLOP_PER_EDGE = 2 * (456 * 128 + 128 * 128 + 128 * 128)
+FP32_MFMA_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+
+
+def load_t1124():
+    from packppi_amd.batch import Batch
+    z = np.load(os.path.join(ROOT, "tests", "golden", "g4_T1124.npz"))
+    b = Batch()
+    for k in z.files:
+        if k.startswith("batch."):
+            key = k[6:]
+            b[key] = int(z[k]) if key in ("num_proteins", "max_size") else torch.from_numpy(z[k])
+    return b, torch.from_numpy(z["init_chi_seed1124"]), torch.from_numpy(z["chi_ode_100"])
+
+
+def synth_workload(kind, rank):
+    from packppi_amd import synth
+    from packppi_amd.batch import collate
+    from packppi_amd.featurize import protein_to_batch, protein_to_data
+    if kind == "s1500":
+        return protein_to_batch(synth.make_complex(1500, 1500))
+    lens = synth.c5_lengths(256)
+    mine = list(range(rank * 32, rank * 32 + 32))
+    return collate([protein_to_data(synth.make_complex(lens[i], 10000 + i)) for i in mine])
+
+
+def cpu_baseline(batch, init, weights, n_sample_steps):
+    """Oracle (CPU port of the reference algorithm, recomputing the graph every step like the reference) on a
+    bounded sample of the same workload; extrapolated linearly to 100 diffusion steps."""
+    from oracle import ref_cpu as O
+    # the GPU box gives one GPU a 16-core CPU share; torch's default (all 128 hardware threads) oversubscribes
+    # these small ops and is ~6x slower
+    cores = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(cores)
+    sched = torch.linspace(1, 0, N_DIFFUSION_STEPS + 1)[: n_sample_steps + 1]
+    with torch.no_grad():
+        O.sampling(weights, batch, init, sched[:2], hoist=False)          # warm-up
+        t0 = time.perf_counter()
+        O.sampling(weights, batch, init, sched, hoist=False)
+        dt = time.perf_counter() - t0
+    res = batch.true_residues()
+    per100 = dt / n_sample_steps * N_DIFFUSION_STEPS
+    return {"value": res / per100, "unit": "residues/s", "cores": cores, "kind": "port",
+            "sample": f"{n_sample_steps} of {N_DIFFUSION_STEPS} diffusion steps of the same complex under "
+                      f"torch.no_grad, graph recomputed per step as the reference does; {dt:.1f} s measured, "
+                      f"scaled x{N_DIFFUSION_STEPS / n_sample_steps:g}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="t1124", choices=["t1124", "s1500", "c5"])
+    ap.add_argument("--proximal", action="store_true", help="add the 50-step proximal optimisation (configs[2])")
+    ap.add_argument("--cpu-steps", type=int, default=20, help="diffusion steps of the CPU-baseline sample (0 = skip)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))   # RCCL over xGMI
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from packppi_amd.module import TDiffusionModule
+    from packppi_amd.weights import make_random_state_dict
+    weights = make_random_state_dict(20251003)
+    ref_chi = None
+    if args.workload == "t1124":
+        batch, init, ref_chi = load_t1124()
+        name = "data/T1124_lig.pdb (L=739, 738 true residues), 1 complex per GPU"
+    else:
+        batch = synth_workload(args.workload, rank)
+        init = None
+        name = {"s1500": "synthetic 1500-residue 2-chain complex (default_rng(1500)), 1 per GPU",
+                "c5": "32 synthetic complexes L~U{270..330} per GPU (default_rng(256))"}[args.workload]
+    residues = batch.true_residues()
+    model = TDiffusionModule(weights, device=dev)
+    model.schedule = torch.linspace(1, 0, N_DIFFUSION_STEPS + 1)
+    gb = batch.to(dev)
+    if init is None:
+        torch.manual_seed(1000 + rank)
+        init_d, _ = model.add_sc_noise(gb, torch.ones(batch.residue_type.numel(), device=dev))
+        init = init_d.cpu()
+    else:
+        init_d = init.to(dev)
+    ctx = model._context(gb)
+
+    def one_pass():
+        chi = ctx.sample(init_d, model.schedule)
+        if args.proximal:
+            from packppi_amd.functional import proximal_optimizer
+            chis, losses = proximal_optimizer(gb, chi, 12.0, 0.5, 1.0, 50)
+            chi = chis[-1] if losses[-1] < losses[0] else chi
+        return chi
+
+    for _ in range(args.warmup):
+        chi = one_pass()
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        chi = one_pass()
+    fence()
+    elapsed = time.perf_counter() - t0
+    total_res = residues
+    if dist is not None:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        rr = torch.tensor([residues], device=dev, dtype=torch.float64)
+        dist.all_reduce(rr, op=dist.ReduceOp.SUM)
+        total_res = int(rr.item())
+
+    # per-complex metric row (the one real collective of the path: RCCL all-gather of metric rows)
+    m = model.analyze_samples(gb, chi)
+    row = torch.stack([torch.as_tensor(float(v), device=dev) for v in m.values()]).float()
+    rows = [row]
+    if dist is not None:
+        rows = [torch.empty_like(row) for _ in range(world)]
+        dist.all_gather(rows, row)
+    max_dchi = None
+    if ref_chi is not None and not args.proximal:
+        d = (chi.cpu().double() - ref_chi.double()).abs()
+        d = torch.minimum(d, (2 * np.pi - d).abs())[batch.SC_D_mask.bool()]
+        max_dchi = float(d.max())
+
+    # dominant-kernel roofline, measured live with HIP events on the launch stream
+    t_edge = ctx.time_kernel(1, 20) * 1e-3
+    t_node = ctx.time_kernel(0, 20) * 1e-3
+    n_edges = residues * ctx.K
+    achieved = EDGE_UPDATE_FLOP_PER_EDGE * n_edges / t_edge / 1e12
+
+    if rank == 0:
+        out = {
+            "metric": "sampled residues/sec at 100 diffusion steps",
+            "value": total_res * args.steps / elapsed,
+            "unit": "residues/s",
+            "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic (seeded random weights; T1124 backbone fixture, seeded initial noise)"
+            if args.workload == "t1124" else "synthetic",
+            "config": {"workload": name, "diffusion_steps": N_DIFFUSION_STEPS, "proximal": bool(args.proximal),
+                       "residues_per_gpu": residues, "mode": "ode"},
+            "roofline": {"bound": "mfma", "kernel": "k_edge_update", "achieved": achieved,
+                         "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
+                         "traffic": None, "kernel_ms": t_edge * 1e3,
+                         "algorithmic_flop_per_launch": EDGE_UPDATE_FLOP_PER_EDGE * n_edges,
+                         "node_message_kernel_ms": t_node * 1e3,
+                         "node_message_tflops": NODE_MSG_FLOP_PER_EDGE * n_edges / t_node / 1e12},
+            "parity": {"max_abs_dchi_vs_reference_rad": max_dchi, "atom_rmsd": float(m["atom_rmsd"])},
+            "metrics_rows_gathered": len(rows),
+        }
+        if args.cpu_steps > 0 and args.gpus == 1:
+            out["cpu_baseline"] = cpu_baseline(batch, init, weights, args.cpu_steps)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,132 @@
+/*
+ * packppi_hip.h -- C ABI of the MI355X (gfx950) side-chain sampling path.
+ *
+ * The reference (Jackz915/PackPPI) is pure Python/PyTorch and has no FFI; the entry points
+ * below are what a binding for its hot path binds.  Each one names the
+ * reference call it replaces (paths relative to the upstream repo root).
+ *
+ * Conventions
+ *   - every `const float*` / `int64_t*` argument that is not marked HOST is a caller-owned,
+ *     contiguous DEVICE pointer (e.g. torch.Tensor.data_ptr() of a ROCm tensor);
+ *   - all floating data is fp32, indices are int64 (as in the reference batch object);
+ *   - `stream` is a hipStream_t passed as void*; work is enqueued asynchronously on it and the
+ *     library never synchronises the device, except where stated;
+ *   - no exceptions cross the ABI: calls return pp_status, pp_last_error() gives the message
+ *     of the calling thread's most recent failure;
+ *   - a pp_ctx is not thread-safe; different ctxs may be driven from different threads.
+ */
+#ifndef PACKPPI_HIP_H
+#define PACKPPI_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum pp_status {
+    PP_OK = 0,
+    PP_ERR_INVALID = 1,     /* bad argument / shape */
+    PP_ERR_HIP = 2,         /* a HIP runtime call failed */
+    PP_ERR_UNSUPPORTED = 3, /* valid request this build does not implement */
+    PP_ERR_NO_DEVICE = 4    /* no gfx950 device visible */
+} pp_status;
+
+typedef struct pp_plan pp_plan; /* weights + chemistry tables resident on one GPU */
+typedef struct pp_ctx pp_ctx;   /* one batch of complexes: cached graph, frames, workspaces */
+
+#define PP_N_WEIGHTS 1439172u /* fp32 parameters of the score network (112 tensors) */
+#define PP_HIDDEN 128
+#define PP_TOP_K 32
+#define PP_MODE_ODE 0
+#define PP_MODE_SDE 1
+
+/* Residue-chemistry tables (HOST pointers; values of src/utils/residue_constants.py:595-677). */
+typedef struct pp_tables {
+    const float *default_frames;   /* [21,8,4,4] restype_rigid_group_default_frame           */
+    const int32_t *atom14_to_group;/* [21,14]    restype_atom14_to_rigid_group               */
+    const float *atom14_mask;      /* [21,14]    restype_atom14_mask                         */
+    const float *lit_positions;    /* [21,14,3]  restype_atom14_rigid_group_positions        */
+    const float *between_radius;   /* [21,14]    vdW radius table of clash.py:263-287        */
+} pp_tables;
+
+/* The reference `batch` object (complex_dataset.py:123-139, complex_datamodule.py:205-224). */
+typedef struct pp_batch {
+    int32_t B, L;
+    const float *X;                /* [B,L,14,3] */
+    const float *atom_mask;        /* [B,L,14]   */
+    const int64_t *residue_type;   /* [B,L]      */
+    const float *residue_mask;     /* [B,L]      */
+    const int64_t *residue_index;  /* [B,L]      */
+    const int64_t *chain_indices;  /* [B,L]      */
+    const float *BB_D;             /* [B,L,3]    */
+    const float *BB_D_sincos;      /* [B,L,3,2]  */
+    const float *SC_D;             /* [B,L,4]    */
+    const float *SC_D_mask;        /* [B,L,4]    */
+    const uint8_t *chi_1pi_periodic_mask; /* [B,L,4] bool */
+    const uint8_t *chi_2pi_periodic_mask; /* [B,L,4] bool */
+} pp_batch;
+
+int pp_version(void);
+const char *pp_last_error(void);
+
+/* Replaces TDiffusionModule.__init__ + load_from_checkpoint (TorsionalDiffusion.py:22-82,
+ * eval_diffusion.py:29-41).  `weights` is a HOST buffer holding the 112 state_dict tensors
+ * concatenated in the order of packppi_amd/weights.py::weight_spec(), nn.Linear [out,in].
+ * weights == NULL gives a geometry-only plan (pp_atom14 / pp_clash / pp_proximal, the
+ * checkpoint-free path of src/proximal_optimize.py); its batches need only X, residue_type,
+ * BB_D and, for the clash calls, atom_mask and residue_index. */
+pp_status pp_plan_create(const float *weights, size_t n_weights, const pp_tables *tables, int device,
+                         pp_plan **plan);
+void pp_plan_destroy(pp_plan *plan);
+
+/* Replaces rc.make_atom14_dists_bounds(tol, vtf) as consumed by find_sc_violations
+ * (clash.py:299-308): `lower`/`upper` are HOST [21,14,14] tables for these parameters. */
+pp_status pp_plan_set_clash_params(pp_plan *plan, float overlap_tolerance, const float *lower,
+                                   const float *upper, void *stream);
+
+/* Replaces the timestep-invariant part of ProteinEncoder.forward (encoder.py:198-246):
+ * kNN graph, 468-d edge features, edge embedding + LayerNorm, backbone frames.  The batch
+ * pointers must stay valid for the lifetime of the ctx. */
+pp_status pp_complex_prepare(pp_plan *plan, const pp_batch *batch, void *stream, pp_ctx **ctx);
+void pp_ctx_destroy(pp_ctx *ctx);
+
+/* Inspection (tests): copy out E_idx [B,L,K] and the embedded edges h_E0 [B,L,K,128]; K = min(32,L). */
+pp_status pp_ctx_get_graph(pp_ctx *ctx, int64_t *E_idx, float *hE0, void *stream);
+
+/* Replaces TDiffusionModule.network(batch, SC_D_noised, t) (TorsionalDiffusion.py:90-109) for a
+ * timestep shared by all residues.  score [B,L,4]; hV [B,L,128] may be NULL. */
+pp_status pp_score(pp_ctx *ctx, const float *chi, float t, float *score, float *hV, void *stream);
+
+/* Replaces the loop of TDiffusionModule.sampling (TorsionalDiffusion.py:259-280):
+ * chi [B,L,4] holds the initial noised angles on entry and the sample on exit.
+ * `schedule` is a HOST array of n_schedule times (n_schedule-1 network evaluations).
+ * mode PP_MODE_SDE needs `sde_noise` [n_schedule-1, 2, B*L, 4] (the two N(0,1) draws of
+ * schedule.py:225 per step, 1pi schedule first); NULL is allowed for PP_MODE_ODE. */
+pp_status pp_sample(pp_ctx *ctx, float *chi, const float *schedule, int n_schedule, int mode,
+                    const float *sde_noise, void *stream);
+
+/* Replaces get_atom14_coords(X, S, BB_D, SC_D) (components/__init__.py:76-120). xyz [B,L,14,3]. */
+pp_status pp_atom14(pp_ctx *ctx, const float *chi, float *xyz, void *stream);
+
+/* Replaces compute_residue_clash (clash.py:335-365) with the parameters last given to
+ * pp_plan_set_clash_params.  per_res [B,L]; dchi, if not NULL, receives
+ * d(mean over all B*L residues of per_res)/dchi [B,L,4] (the autograd of optimize.py:62-63). */
+pp_status pp_clash(pp_ctx *ctx, const float *chi, float *per_res, float *dchi, void *stream);
+
+/* Replaces proximal_optimizer(batch, SC_D, vtf, tol, lamda, num_steps) (optimize.py:21-73),
+ * B must be 1.  chi_traj, if not NULL, receives the per-step angles [num_steps,1,L,4];
+ * chi_last [1,L,4] the last of them; losses (DEVICE, [num_steps]) the pre-step loss values. */
+pp_status pp_proximal(pp_ctx *ctx, const float *chi, float lamda, int num_steps, float *chi_traj,
+                      float *chi_last, float *losses, void *stream);
+
+/* Measurement aid, no reference counterpart: average duration (ms) of one launch of a hot kernel
+ * (which: 0 = node-message kernel, 1 = edge-update kernel), timed with HIP events on `stream`
+ * around `iters` launches.  Synchronises the stream. */
+pp_status pp_time_kernel(pp_ctx *ctx, int which, int iters, float *avg_ms, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PACKPPI_HIP_H */

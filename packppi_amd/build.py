@@ -1,0 +1,50 @@
+"""Compile the HIP sources into ``csrc/libpackppi_hip.so`` (gfx950 only, in-tree)."""
+import os
+import shutil
+import subprocess
+import sys
+
+CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+LIB = os.path.join(CSRC, "libpackppi_hip.so")
+SOURCES = ["pp_api.hip", "pp_prepare.hip", "pp_node.hip", "pp_edge.hip", "pp_clash.hip"]
+FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-variable",
+         "-Wno-unused-but-set-variable"]
+
+
+def _hipcc():
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (set HIPCC or install ROCm)")
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
+    deps.append(os.path.join(CSRC, "..", "..", "include", "packppi_hip.h"))
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_library(force=False, verbose=True, extra_flags=()):
+    if not force and not needs_build():
+        return LIB
+    hipcc = _hipcc()
+    objs = []
+    for src in SOURCES:
+        obj = os.path.join(CSRC, src.replace(".hip", ".o"))
+        cmd = [hipcc, *FLAGS, *extra_flags, "-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+        objs.append(obj)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    build_library(force="--force" in sys.argv)

@@ -1,0 +1,383 @@
+// C ABI of libpackppi_hip.so: plan / ctx lifetime and the per-call kernel schedules.
+#include <math.h>
+#include <string.h>
+
+#include <new>
+#include <string>
+#include <vector>
+
+#include "pp_internal.h"
+
+static thread_local std::string g_err;
+void pp_set_error(const std::string &msg) { g_err = msg; }
+
+extern "C" const char *pp_last_error(void) { return g_err.c_str(); }
+extern "C" int pp_version(void) { return 100; }
+
+#define FAIL(code, msg)      \
+    do {                     \
+        pp_set_error(msg);   \
+        return code;         \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
+WeightOff pp_weight_offsets() {
+    WeightOff o;
+    size_t p = 0;
+    auto take = [&](size_t n) { size_t r = p; p += n; return r; };
+    o.node_emb_w = take(128 * 51); o.node_emb_b = take(128);
+    o.norm_nodes_g = take(128); o.norm_nodes_b = take(128);
+    o.edge_emb_w = take(128 * 468); o.edge_emb_b = take(128);
+    o.norm_edges_g = take(128); o.norm_edges_b = take(128);
+    for (int l = 0; l < 3; l++) {
+        LayerOff &L = o.layer[l];
+        L.pts_node_w = take(24 * 128); L.pts_node_b = take(24);
+        L.pts_edge_w = take(24 * 128); L.pts_edge_b = take(24);
+        L.nm_in_w = take(128 * 456); L.nm_in_b = take(128);
+        L.nm_mid_w = take(128 * 128); L.nm_mid_b = take(128);
+        L.nm_out_w = take(128 * 128); L.nm_out_b = take(128);
+        L.em_in_w = take(128 * 456); L.em_in_b = take(128);
+        L.em_mid_w = take(128 * 128); L.em_mid_b = take(128);
+        L.em_out_w = take(128 * 128); L.em_out_b = take(128);
+        for (int k = 0; k < 4; k++) { L.norm_g[k] = take(128); L.norm_b[k] = take(128); }
+        L.nd_in_w = take(512 * 128); L.nd_in_b = take(512);
+        L.nd_out_w = take(128 * 512); L.nd_out_b = take(128);
+        L.ed_in_w = take(512 * 128); L.ed_in_b = take(512);
+        L.ed_out_w = take(128 * 512); L.ed_out_b = take(128);
+    }
+    o.d0_in_w = take(64 * 128); o.d0_in_b = take(64);
+    o.d0_out_w = take(32 * 64); o.d0_out_b = take(32);
+    o.d2_in_w = take(16 * 32); o.d2_in_b = take(16);
+    o.d2_out_w = take(4 * 16); o.d2_out_b = take(4);
+    o.total = p;
+    return o;
+}
+
+// host-side transpose of W[rows][ld] columns [c0, c0+cols) into dst[cols][rows]
+static size_t put_T(std::vector<float> &arena, const float *W, int rows, int ld, int c0, int cols) {
+    size_t at = arena.size();
+    at = (at + 3) & ~size_t(3);
+    arena.resize(at + (size_t)rows * cols);
+    float *d = arena.data() + at;
+    for (int r = 0; r < rows; r++)
+        for (int c = 0; c < cols; c++) d[(size_t)c * rows + r] = W[(size_t)r * ld + c0 + c];
+    return at;
+}
+
+template <typename T>
+static pp_status upload(T **dst, const T *src, size_t n) {
+    PP_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(dst), n * sizeof(T)));
+    PP_HIP_CHECK(hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice));
+    return PP_OK;
+}
+
+extern "C" pp_status pp_plan_create(const float *weights, size_t n_weights, const pp_tables *tables, int device,
+                                    pp_plan **out) {
+    if (!tables || !out) FAIL(PP_ERR_INVALID, "pp_plan_create: null argument");
+    WeightOff off = pp_weight_offsets();
+    const bool has_net = weights != nullptr;
+    if (has_net && (n_weights != off.total || off.total != PP_N_WEIGHTS))
+        FAIL(PP_ERR_INVALID, "pp_plan_create: expected " + std::to_string(off.total) + " weights, got " +
+                                 std::to_string(n_weights));
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) FAIL(PP_ERR_NO_DEVICE, "pp_plan_create: no HIP device visible");
+    if (device < 0 || device >= ndev) FAIL(PP_ERR_INVALID, "pp_plan_create: bad device index");
+    PP_HIP_CHECK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    PP_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        FAIL(PP_ERR_NO_DEVICE, std::string("pp_plan_create: kernels are built for gfx950 only, device is ") + prop.gcnArchName);
+
+    pp_plan *p = new (std::nothrow) pp_plan();
+    if (!p) FAIL(PP_ERR_INVALID, "out of host memory");
+    memset(p, 0, sizeof(*p));
+    p->device = device;
+    p->off = off;
+    p->has_network = has_net;
+    pp_status st;
+    if (has_net) {
+    if ((st = upload(&p->w, weights, off.total)) != PP_OK) return st;
+
+    std::vector<float> arena;
+    arena.reserve(1u << 20);
+    size_t o_node_emb = put_T(arena, weights + off.node_emb_w, 128, 51, 0, 51);
+    size_t o_edge_emb = put_T(arena, weights + off.edge_emb_w, 128, 468, 0, 468);
+    size_t o_l[3][9];
+    for (int l = 0; l < 3; l++) {
+        const LayerOff &L = off.layer[l];
+        o_l[l][0] = put_T(arena, weights + L.pts_node_w, 24, 128, 0, 128);
+        o_l[l][1] = put_T(arena, weights + L.pts_edge_w, 24, 128, 0, 128);
+        o_l[l][2] = put_T(arena, weights + L.nm_in_w, 128, 456, 0, 128);
+        o_l[l][3] = put_T(arena, weights + L.nm_in_w, 128, 456, 256, 128);
+        o_l[l][4] = put_T(arena, weights + L.em_in_w, 128, 456, 0, 128);
+        o_l[l][5] = put_T(arena, weights + L.em_in_w, 128, 456, 256, 128);
+        o_l[l][6] = put_T(arena, weights + L.nm_out_w, 128, 128, 0, 128);
+        o_l[l][7] = put_T(arena, weights + L.nd_in_w, 512, 128, 0, 128);
+        o_l[l][8] = put_T(arena, weights + L.nd_out_w, 128, 512, 0, 512);
+    }
+    size_t o_d0i = put_T(arena, weights + off.d0_in_w, 64, 128, 0, 128);
+    size_t o_d0o = put_T(arena, weights + off.d0_out_w, 32, 64, 0, 64);
+    size_t o_d2i = put_T(arena, weights + off.d2_in_w, 16, 32, 0, 32);
+    size_t o_d2o = put_T(arena, weights + off.d2_out_w, 4, 16, 0, 16);
+    if ((st = upload(&p->wT, arena.data(), arena.size())) != PP_OK) return st;
+    p->node_emb_T = p->wT + o_node_emb;
+    p->edge_emb_T = p->wT + o_edge_emb;
+    for (int l = 0; l < 3; l++) {
+        LayerT &t = p->lt[l];
+        t.pts_node_wT = p->wT + o_l[l][0]; t.pts_edge_wT = p->wT + o_l[l][1];
+        t.nm_A_T = p->wT + o_l[l][2]; t.nm_C_T = p->wT + o_l[l][3];
+        t.em_A_T = p->wT + o_l[l][4]; t.em_C_T = p->wT + o_l[l][5];
+        t.nm_out_T = p->wT + o_l[l][6];
+        t.nd_in_T = p->wT + o_l[l][7]; t.nd_out_T = p->wT + o_l[l][8];
+    }
+    p->d0_in_T = p->wT + o_d0i; p->d0_out_T = p->wT + o_d0o;
+    p->d2_in_T = p->wT + o_d2i; p->d2_out_T = p->wT + o_d2o;
+    }
+
+    if ((st = upload(&p->default_frames, tables->default_frames, 21 * 8 * 16)) != PP_OK) return st;
+    if ((st = upload(&p->atom14_to_group, tables->atom14_to_group, 21 * 14)) != PP_OK) return st;
+    if ((st = upload(&p->atom14_mask, tables->atom14_mask, 21 * 14)) != PP_OK) return st;
+    if ((st = upload(&p->lit_positions, tables->lit_positions, 21 * 14 * 3)) != PP_OK) return st;
+    if ((st = upload(&p->between_radius, tables->between_radius, 21 * 14)) != PP_OK) return st;
+    PP_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&p->bounds_lower), 21 * 14 * 14 * sizeof(float)));
+    PP_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&p->bounds_upper), 21 * 14 * 14 * sizeof(float)));
+    p->clash_params_set = false;
+    *out = p;
+    return PP_OK;
+}
+
+extern "C" void pp_plan_destroy(pp_plan *p) {
+    if (!p) return;
+    hipFree(p->w); hipFree(p->wT); hipFree(p->default_frames); hipFree(p->atom14_to_group);
+    hipFree(p->atom14_mask); hipFree(p->lit_positions); hipFree(p->between_radius);
+    hipFree(p->bounds_lower); hipFree(p->bounds_upper);
+    delete p;
+}
+
+extern "C" pp_status pp_plan_set_clash_params(pp_plan *p, float tol, const float *lower, const float *upper, void *stream) {
+    if (!p || !lower || !upper) FAIL(PP_ERR_INVALID, "pp_plan_set_clash_params: null argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    // the host tables are caller-owned and may be freed on return: blocking copies
+    PP_HIP_CHECK(hipStreamSynchronize(s));
+    PP_HIP_CHECK(hipMemcpy(p->bounds_lower, lower, 21 * 14 * 14 * sizeof(float), hipMemcpyHostToDevice));
+    PP_HIP_CHECK(hipMemcpy(p->bounds_upper, upper, 21 * 14 * 14 * sizeof(float), hipMemcpyHostToDevice));
+    p->clash_tol = tol;
+    p->clash_params_set = true;
+    return PP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+static pp_status dalloc(T **p, size_t n) {
+    PP_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(p), (n ? n : 1) * sizeof(T)));
+    return PP_OK;
+}
+
+extern "C" void pp_ctx_destroy(pp_ctx *c) {
+    if (!c) return;
+    void *ptrs[] = {c->eidx, c->mask_att, c->frames, c->bbpos, c->hE0, c->hE, c->hV, c->S, c->msum, c->ptsN, c->PAn,
+                    c->PCn, c->ptsE, c->PAe, c->PCe, c->score, c->chi_tmp, c->steps, c->xyz, c->axes, c->brad,
+                    c->per_res, c->dchi, c->px, c->pm, c->pv, c->pz, c->pxeff, c->pmask, c->scal};
+    for (void *q : ptrs) if (q) hipFree(q);
+    if (c->steps_host) hipHostFree(c->steps_host);
+    delete c;
+}
+
+extern "C" pp_status pp_complex_prepare(pp_plan *plan, const pp_batch *b, void *stream, pp_ctx **out) {
+    if (!plan || !b || !out) FAIL(PP_ERR_INVALID, "pp_complex_prepare: null argument");
+    if (b->B <= 0 || b->L <= 0) FAIL(PP_ERR_INVALID, "pp_complex_prepare: B and L must be positive");
+    if (b->L > 16384) FAIL(PP_ERR_UNSUPPORTED, "pp_complex_prepare: L > 16384 residues per complex is not supported");
+    if (!b->X || !b->residue_type || !b->BB_D)
+        FAIL(PP_ERR_INVALID, "pp_complex_prepare: batch needs at least X, residue_type and BB_D");
+    const bool net = plan->has_network;
+    if (net && (!b->atom_mask || !b->residue_mask || !b->residue_index || !b->chain_indices || !b->BB_D_sincos ||
+                !b->SC_D_mask || !b->chi_1pi_periodic_mask || !b->chi_2pi_periodic_mask))
+        FAIL(PP_ERR_INVALID, "pp_complex_prepare: batch has a null tensor pointer");
+    PP_HIP_CHECK(hipSetDevice(plan->device));
+    pp_ctx *c = new (std::nothrow) pp_ctx();
+    if (!c) FAIL(PP_ERR_INVALID, "out of host memory");
+    memset(c, 0, sizeof(*c));
+    c->plan = plan;
+    c->b = *b;
+    c->B = b->B; c->L = b->L; c->N = b->B * b->L;
+    c->K = b->L < PP_TOP_K ? b->L : PP_TOP_K;
+    const size_t N = c->N, K = c->K;
+    pp_status st = PP_OK;
+#define ALLOC(field, n) if (st == PP_OK) st = dalloc(&c->field, (n))
+    if (net) {
+    ALLOC(eidx, N * K); ALLOC(mask_att, N * 32); ALLOC(frames, N * 12); ALLOC(bbpos, N * 15);
+    ALLOC(hE0, N * K * 128); ALLOC(hE, N * K * 128); ALLOC(hV, N * 128); ALLOC(S, N * 128); ALLOC(msum, N);
+    ALLOC(ptsN, N * 48); ALLOC(PAn, N * 128); ALLOC(PCn, N * 128);
+    ALLOC(ptsE, N * 48); ALLOC(PAe, N * 128); ALLOC(PCe, N * 128);
+    ALLOC(score, N * 4); ALLOC(chi_tmp, N * 4);
+    }
+    ALLOC(xyz, N * 42); ALLOC(axes, N * 24); ALLOC(brad, N); ALLOC(per_res, N); ALLOC(dchi, N * 4);
+    ALLOC(px, N * 4); ALLOC(pm, N * 4); ALLOC(pv, N * 4); ALLOC(pz, N * 4); ALLOC(pxeff, N * 4); ALLOC(pmask, N);
+    ALLOC(scal, 64);
+    c->max_steps = 1024;
+    if (net) { ALLOC(steps, (size_t)c->max_steps); }
+#undef ALLOC
+    if (net && st == PP_OK && hipHostMalloc(reinterpret_cast<void **>(&c->steps_host), c->max_steps * sizeof(StepParams)) != hipSuccess) {
+        pp_set_error("hipHostMalloc failed");
+        st = PP_ERR_HIP;
+    }
+    if (net && st == PP_OK) st = pp_launch_prepare(c, static_cast<hipStream_t>(stream));
+    if (st != PP_OK) { pp_ctx_destroy(c); return st; }
+    *out = c;
+    return PP_OK;
+}
+
+__global__ void k_widen_idx(const int32_t *__restrict__ src, int64_t *__restrict__ dst, size_t n, int L, int K) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        size_t node = i / K;
+        int b = (int)(node / L);
+        dst[i] = (int64_t)src[i] - (int64_t)b * L;      // back to the per-complex residue numbering of the reference
+    }
+}
+
+extern "C" pp_status pp_ctx_get_graph(pp_ctx *c, int64_t *E_idx, float *hE0, void *stream) {
+    if (!c) FAIL(PP_ERR_INVALID, "pp_ctx_get_graph: null ctx");
+    if (!c->plan->has_network) FAIL(PP_ERR_INVALID, "pp_ctx_get_graph: plan was created without network weights");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    size_t n = (size_t)c->N * c->K;
+    if (E_idx) hipLaunchKernelGGL(k_widen_idx, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, c->eidx, E_idx, n, c->L, c->K);
+    if (hE0) PP_HIP_CHECK(hipMemcpyAsync(hE0, c->hE0, n * 128 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    PP_HIP_CHECK(hipGetLastError());
+    return PP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-step scalars (schedule.py:165-174,198-235; layers.py:257-268), fp32 like the reference's tensors
+static void fill_step(StepParams *sp, float t, float dt) {
+    const double PI_D = 3.14159265358979323846;
+    const double lo = log(0.01 * PI_D), hi = log(PI_D);
+    memset(sp, 0, sizeof(*sp));
+    // sinusoidal embedding of t * 10000
+    const float ts = t * 10000.0f;
+    const float nemb = (float)(-(log(10000.0) / 7.0));
+    for (int i = 0; i < 8; i++) {
+        float freq = expf((float)i * nemb);
+        float arg = ts * freq;
+        sp->temb[i] = (float)sin((double)arg);
+        sp->temb[8 + i] = (float)cos((double)arg);
+    }
+    float sigma = expf((float)lo + (float)(hi - lo) * t);
+    float g = sigma * (float)sqrt(2.0 * log(PI_D / (0.01 * PI_D)));
+    float ratio = sigma / (float)exp(hi);
+    float alpha = 1.0f - ratio * ratio;
+    const float T = 3.0f;
+    sp->w = T / (alpha + (1.0f - alpha) * T);
+    sp->c_ode = (0.5f * (g * g)) * dt;
+    sp->c_drift = (g * g) * dt;
+    sp->c_diff = g * sqrtf(dt);
+}
+
+static pp_status run_network(pp_ctx *c, hipStream_t s, int step, int last_mode, float *chi, int mode, const float *noise,
+                             bool embed_next) {
+    pp_status st;
+    for (int l = 0; l < 3; l++) {
+        if ((st = pp_launch_node_message(c, l, s)) != PP_OK) return st;
+        if (l < 2) {
+            if ((st = pp_launch_node_update(c, l, PP_NU_MID, chi, step, mode, noise, s)) != PP_OK) return st;
+            if ((st = pp_launch_edge_update(c, l, s)) != PP_OK) return st;
+        } else {
+            int enc = step;
+            if (last_mode == PP_NU_STEP && !embed_next) enc = -step - 1;
+            if ((st = pp_launch_node_update(c, l, last_mode, chi, enc, mode, noise, s)) != PP_OK) return st;
+        }
+    }
+    return PP_OK;
+}
+
+extern "C" pp_status pp_score(pp_ctx *c, const float *chi, float t, float *score, float *hV, void *stream) {
+    if (!c || !chi || !score) FAIL(PP_ERR_INVALID, "pp_score: null argument");
+    if (!c->plan->has_network) FAIL(PP_ERR_INVALID, "pp_score: plan was created without network weights");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    PP_HIP_CHECK(hipSetDevice(c->plan->device));
+    // the staging slot may still be in flight from a previous call on this stream
+    PP_HIP_CHECK(hipStreamSynchronize(s));
+    fill_step(&c->steps_host[0], t, 0.f);
+    PP_HIP_CHECK(hipMemcpyAsync(c->steps, c->steps_host, sizeof(StepParams), hipMemcpyHostToDevice, s));
+    pp_status st;
+    if ((st = pp_launch_node_embed(c, chi, 0, s)) != PP_OK) return st;
+    if ((st = run_network(c, s, 0, PP_NU_SCORE, nullptr, PP_MODE_ODE, nullptr, false)) != PP_OK) return st;
+    PP_HIP_CHECK(hipMemcpyAsync(score, c->score, (size_t)c->N * 4 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (hV) PP_HIP_CHECK(hipMemcpyAsync(hV, c->hV, (size_t)c->N * 128 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return PP_OK;
+}
+
+extern "C" pp_status pp_sample(pp_ctx *c, float *chi, const float *schedule, int n_schedule, int mode,
+                               const float *sde_noise, void *stream) {
+    if (!c || !chi || !schedule) FAIL(PP_ERR_INVALID, "pp_sample: null argument");
+    if (!c->plan->has_network) FAIL(PP_ERR_INVALID, "pp_sample: plan was created without network weights");
+    if (n_schedule < 2) FAIL(PP_ERR_INVALID, "pp_sample: schedule needs at least 2 times");
+    if (n_schedule - 1 > c->max_steps) FAIL(PP_ERR_UNSUPPORTED, "pp_sample: more than 1024 steps");
+    if (mode != PP_MODE_ODE && mode != PP_MODE_SDE) FAIL(PP_ERR_INVALID, "pp_sample: unknown mode");
+    if (mode == PP_MODE_SDE && !sde_noise) FAIL(PP_ERR_INVALID, "pp_sample: sde mode needs the per-step noise tensor");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    PP_HIP_CHECK(hipSetDevice(c->plan->device));
+    const int nsteps = n_schedule - 1;
+    PP_HIP_CHECK(hipStreamSynchronize(s));
+    for (int j = 0; j < nsteps; j++) fill_step(&c->steps_host[j], schedule[j], schedule[j] - schedule[j + 1]);
+    PP_HIP_CHECK(hipMemcpyAsync(c->steps, c->steps_host, (size_t)nsteps * sizeof(StepParams), hipMemcpyHostToDevice, s));
+    pp_status st;
+    if ((st = pp_launch_node_embed(c, chi, 0, s)) != PP_OK) return st;
+    for (int j = 0; j < nsteps; j++) {
+        if ((st = run_network(c, s, j, PP_NU_STEP, chi, mode, sde_noise, j + 1 < nsteps)) != PP_OK) return st;
+    }
+    return PP_OK;
+}
+
+extern "C" pp_status pp_atom14(pp_ctx *c, const float *chi, float *xyz, void *stream) {
+    if (!c || !chi || !xyz) FAIL(PP_ERR_INVALID, "pp_atom14: null argument");
+    PP_HIP_CHECK(hipSetDevice(c->plan->device));
+    return pp_launch_atom14(c, chi, xyz, static_cast<hipStream_t>(stream));
+}
+
+extern "C" pp_status pp_clash(pp_ctx *c, const float *chi, float *per_res, float *dchi, void *stream) {
+    if (!c || !chi || !per_res) FAIL(PP_ERR_INVALID, "pp_clash: null argument");
+    if (!c->plan->clash_params_set) FAIL(PP_ERR_INVALID, "pp_clash: call pp_plan_set_clash_params first");
+    if (!c->b.atom_mask || !c->b.residue_index) FAIL(PP_ERR_INVALID, "pp_clash: batch lacks atom_mask / residue_index");
+    PP_HIP_CHECK(hipSetDevice(c->plan->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    pp_status st;
+    if ((st = pp_launch_atom14(c, chi, c->xyz, s)) != PP_OK) return st;
+    return pp_launch_clash(c, c->xyz, per_res, dchi, s);
+}
+
+extern "C" pp_status pp_proximal(pp_ctx *c, const float *chi, float lamda, int num_steps, float *chi_traj,
+                                 float *chi_last, float *losses, void *stream) {
+    if (!c || !chi || !losses) FAIL(PP_ERR_INVALID, "pp_proximal: null argument");
+    if (c->B != 1) FAIL(PP_ERR_INVALID, "pp_proximal: batch.num_proteins must be 1 (optimize.py:27)");
+    if (num_steps < 1) FAIL(PP_ERR_INVALID, "pp_proximal: num_steps must be >= 1");
+    if (!c->plan->clash_params_set) FAIL(PP_ERR_INVALID, "pp_proximal: call pp_plan_set_clash_params first");
+    if (!c->b.atom_mask || !c->b.residue_index) FAIL(PP_ERR_INVALID, "pp_proximal: batch lacks atom_mask / residue_index");
+    PP_HIP_CHECK(hipSetDevice(c->plan->device));
+    return pp_launch_proximal(c, chi, lamda, num_steps, chi_traj, chi_last, losses, static_cast<hipStream_t>(stream));
+}
+
+// Measurement aid (bench.py): average duration of one launch of a hot kernel, timed with HIP events on
+// `stream` around `iters` back-to-back launches.  which: 0 = node message, 1 = edge update (layer 1 weights).
+// The ctx must have been through pp_score / pp_sample so that its state buffers hold real activations.
+extern "C" pp_status pp_time_kernel(pp_ctx *c, int which, int iters, float *avg_ms, void *stream) {
+    if (!c || !avg_ms || iters < 1) FAIL(PP_ERR_INVALID, "pp_time_kernel: bad argument");
+    if (!c->plan->has_network) FAIL(PP_ERR_INVALID, "pp_time_kernel: plan was created without network weights");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    PP_HIP_CHECK(hipSetDevice(c->plan->device));
+    hipEvent_t e0, e1;
+    PP_HIP_CHECK(hipEventCreate(&e0));
+    PP_HIP_CHECK(hipEventCreate(&e1));
+    pp_status st = PP_OK;
+    for (int w = 0; w < 2 && st == PP_OK; w++) st = which == 0 ? pp_launch_node_message(c, 1, s) : pp_launch_edge_update(c, 1, s);
+    PP_HIP_CHECK(hipEventRecord(e0, s));
+    for (int i = 0; i < iters && st == PP_OK; i++) st = which == 0 ? pp_launch_node_message(c, 1, s) : pp_launch_edge_update(c, 1, s);
+    PP_HIP_CHECK(hipEventRecord(e1, s));
+    PP_HIP_CHECK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    PP_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    *avg_ms = ms / (float)iters;
+    return st;
+}

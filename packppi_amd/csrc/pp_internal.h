@@ -1,0 +1,131 @@
+// Internal declarations shared by the HIP translation units of libpackppi_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+#include "../../include/packppi_hip.h"
+
+#define PP_H 128          // hidden width
+#define PP_MSG_IN 456     // message MLP input width
+#define PP_NPTS 8         // invariant points per node
+
+// ---------------------------------------------------------------------------------------------
+// Offsets (in floats) into the concatenated weight buffer, order of weights.py::weight_spec().
+// ---------------------------------------------------------------------------------------------
+struct LayerOff {
+    size_t pts_node_w, pts_node_b, pts_edge_w, pts_edge_b;
+    size_t nm_in_w, nm_in_b, nm_mid_w, nm_mid_b, nm_out_w, nm_out_b;   // node_message_fn
+    size_t em_in_w, em_in_b, em_mid_w, em_mid_b, em_out_w, em_out_b;   // edge_message_fn
+    size_t norm_g[4], norm_b[4];
+    size_t nd_in_w, nd_in_b, nd_out_w, nd_out_b;                       // node_dense
+    size_t ed_in_w, ed_in_b, ed_out_w, ed_out_b;                       // edge_dense
+};
+struct WeightOff {
+    size_t node_emb_w, node_emb_b, norm_nodes_g, norm_nodes_b;
+    size_t edge_emb_w, edge_emb_b, norm_edges_g, norm_edges_b;
+    LayerOff layer[3];
+    size_t d0_in_w, d0_in_b, d0_out_w, d0_out_b, d2_in_w, d2_in_b, d2_out_w, d2_out_b;
+    size_t total;
+};
+WeightOff pp_weight_offsets();
+
+// Transposed ([in][out]) copies used by the node-level (VALU) kernels, per layer.
+struct LayerT {
+    const float *pts_node_wT, *pts_edge_wT;          // [128][24]
+    const float *nm_A_T, *nm_C_T, *em_A_T, *em_C_T;  // W_in[:, 0:128]^T, W_in[:, 256:384]^T  -> [128][128]
+    const float *nm_out_T;                           // [128][128]
+    const float *nd_in_T;                            // [128][512]
+    const float *nd_out_T;                           // [512][128]
+};
+
+struct pp_plan {
+    int device;
+    bool has_network;         // false: geometry-only plan (atom14 / clash / proximal)
+    float *w;                 // device copy of all weights, original layouts
+    WeightOff off;
+    float *wT;                // device arena of transposed copies
+    LayerT lt[3];
+    const float *node_emb_T;  // [51][128]
+    const float *edge_emb_T;  // [468][128]
+    const float *d0_in_T, *d0_out_T, *d2_in_T, *d2_out_T;   // [128][64] [64][32] [32][16] [16][4]
+    // chemistry tables (device)
+    float *default_frames;    // [21][8][16]
+    int32_t *atom14_to_group; // [21][14]
+    float *atom14_mask;       // [21][14]
+    float *lit_positions;     // [21][14][3]
+    float *between_radius;    // [21][14]
+    float *bounds_lower, *bounds_upper;   // [21][14][14]
+    float clash_tol;
+    bool clash_params_set;
+};
+
+// Per-step scalars of the reverse process, computed on the host (schedule.py:198-235).
+struct StepParams {
+    float temb[16];     // sinusoidal embedding of t
+    float c_ode;        // 0.5 * g^2 * dt
+    float w;            // annealed weight
+    float c_drift;      // g^2 * dt        (sde)
+    float c_diff;       // g * sqrt(dt)    (sde)
+    float pad[12];
+};
+
+struct pp_ctx {
+    pp_plan *plan;
+    pp_batch b;               // caller-owned device pointers
+    int B, L, K, N;           // N = B*L nodes
+    // static per complex
+    int32_t *eidx;            // [N][K] global node index of each neighbour
+    float *mask_att;          // [N][32] mask_i*mask_j (0 for slots >= K)
+    float *frames;            // [N][12]  R (row-major 9) | t (3)
+    float *bbpos;             // [N][5][3] N CA C O CB*
+    float *hE0;               // [N][K][128]
+    // per-evaluation state
+    float *hE;                // [N][K][128]
+    float *hV;                // [N][128]
+    float *S;                 // [N][128]  masked mean of the node-message hidden layer
+    float *msum;              // [N]
+    float *ptsN, *PAn, *PCn;  // node-message inputs [N][48] [N][128] [N][128]
+    float *ptsE, *PAe, *PCe;  // edge-message inputs
+    float *score;             // [N][4]
+    float *chi_tmp;           // [N][4]
+    StepParams *steps;        // device [max_steps]
+    StepParams *steps_host;   // pinned host staging
+    int max_steps;
+    // clash / proximal workspaces
+    float *xyz;               // [N][14][3]
+    float *axes;              // [N][4][6]  chi-frame x-axis (3) | origin (3)
+    float *brad;              // [N] bounding radius around CA
+    float *per_res;           // [N]
+    float *dchi;              // [N][4]
+    float *px, *pm, *pv, *pz, *pxeff;   // proximal: param, Adam moments, anchor, effective chi  [N][4]
+    uint8_t *pmask;           // [N]
+    float *scal;              // small scalar scratch
+};
+
+void pp_set_error(const std::string &msg);
+#define PP_HIP_CHECK(expr)                                                                   \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess) {                                                              \
+            pp_set_error(std::string(#expr) + ": " + hipGetErrorString(_e));                 \
+            return PP_ERR_HIP;                                                               \
+        }                                                                                    \
+    } while (0)
+
+// ---- launchers implemented in the kernel translation units ----------------------------------
+pp_status pp_launch_prepare(pp_ctx *c, hipStream_t s);
+pp_status pp_launch_node_embed(pp_ctx *c, const float *chi, int step, hipStream_t s);
+pp_status pp_launch_node_update(pp_ctx *c, int layer, int last_mode, float *chi, int step, int mode,
+                                const float *noise, hipStream_t s);
+pp_status pp_launch_node_message(pp_ctx *c, int layer, hipStream_t s);
+pp_status pp_launch_edge_update(pp_ctx *c, int layer, hipStream_t s);
+pp_status pp_launch_atom14(pp_ctx *c, const float *chi, float *xyz, hipStream_t s);
+pp_status pp_launch_clash(pp_ctx *c, const float *xyz, float *per_res, float *dchi, hipStream_t s);
+pp_status pp_launch_proximal(pp_ctx *c, const float *chi, float lamda, int nsteps, float *traj,
+                             float *chi_last, float *losses, hipStream_t s);
+
+// last_mode values for pp_launch_node_update
+#define PP_NU_MID 0        // layers 0,1: update + edge-message inputs + next layer's node-message inputs
+#define PP_NU_SCORE 1      // layer 2, single evaluation: update + decoder
+#define PP_NU_STEP 2       // layer 2 inside sampling: update + decoder + reverse step + next embed

@@ -1,0 +1,272 @@
+// Timestep-invariant graph construction (once per complex): kNN over CA atoms, residue frames,
+// 468-d edge features -> Linear(468,128) -> LayerNorm.   Reference: encoder.py:105-118 (kNN),
+// :34-47 (relpos), :120-153 (RBF), :164-196 (inter-residue dihedrals), :243-244 (embedding),
+// rigid_utils.py:1127-1179 (frames).
+#include "pp_internal.h"
+
+#define KNN_THREADS 256
+
+// The distance arithmetic that decides neighbour membership must round like the reference's
+// separate mul/add/sqrt ops, so no FMA contraction in this file's geometric helpers.
+#pragma clang fp contract(off)
+
+__device__ __forceinline__ float dist_eps(const float *a, const float *b, float eps) {
+    float dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2];
+    float s = dx * dx;
+    s = s + dy * dy;
+    s = s + dz * dz;
+    return sqrtf(s + eps);
+}
+
+// ---------------------------------------------------------------------------------------------
+// frames, backbone atom table, virtual CB
+// ---------------------------------------------------------------------------------------------
+__global__ void k_frames(const float *__restrict__ X, int N, float *__restrict__ frames,
+                         float *__restrict__ bbpos) {
+    int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float *x = X + (size_t)n * 42;
+    float Nn[3], CA[3], C[3], O[3];
+    for (int k = 0; k < 3; k++) { Nn[k] = x[k]; CA[k] = x[3 + k]; C[k] = x[6 + k]; O[k] = x[9 + k]; }
+    // Gram-Schmidt: e0 along C-CA, e1 from N-CA (from_3_points(N, CA, C, fixed=True))
+    float a[3], b[3];
+    for (int k = 0; k < 3; k++) { a[k] = C[k] - CA[k]; b[k] = Nn[k] - CA[k]; }
+    float na = sqrtf(((a[0] * a[0] + a[1] * a[1]) + a[2] * a[2]) + 1e-8f);
+    for (int k = 0; k < 3; k++) a[k] = a[k] / na;
+    float dot = (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2];
+    for (int k = 0; k < 3; k++) b[k] = b[k] - a[k] * dot;
+    float nb = sqrtf(((b[0] * b[0] + b[1] * b[1]) + b[2] * b[2]) + 1e-8f);
+    for (int k = 0; k < 3; k++) b[k] = b[k] / nb;
+    float c[3] = {a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]};
+    float *f = frames + (size_t)n * 12;
+    for (int r = 0; r < 3; r++) { f[3 * r] = a[r]; f[3 * r + 1] = b[r]; f[3 * r + 2] = c[r]; }
+    for (int k = 0; k < 3; k++) f[9 + k] = CA[k];
+    // virtual CB (encoder.py:137-142)
+    float bb[3], cc[3];
+    for (int k = 0; k < 3; k++) { bb[k] = CA[k] - Nn[k]; cc[k] = C[k] - CA[k]; }
+    float aa[3] = {bb[1] * cc[2] - bb[2] * cc[1], bb[2] * cc[0] - bb[0] * cc[2], bb[0] * cc[1] - bb[1] * cc[0]};
+    float *p = bbpos + (size_t)n * 15;
+    for (int k = 0; k < 3; k++) {
+        p[k] = Nn[k]; p[3 + k] = CA[k]; p[6 + k] = C[k]; p[9 + k] = O[k];
+        p[12 + k] = ((-0.58273431f * aa[k] + 0.56802827f * bb[k]) - 0.54067466f * cc[k]) + CA[k];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// kNN: one block per residue row; K rounds of (value, index)-lexicographic arg-min.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(KNN_THREADS)
+k_knn(const float *__restrict__ X, const float *__restrict__ rmask, int L, int K,
+      int32_t *__restrict__ eidx, float *__restrict__ mask_att) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float *d = reinterpret_cast<float *>(smem_raw);            // [L]
+    __shared__ float red_v[KNN_THREADS / 64];
+    __shared__ int red_i[KNN_THREADS / 64];
+    __shared__ float s_max;
+    __shared__ int s_pick;
+    const int n = blockIdx.x;
+    const int b = n / L, i = n - b * L;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const float mi = rmask[n];
+    const float *ca_i = X + (size_t)n * 42 + 3;
+    float ci[3] = {ca_i[0], ca_i[1], ca_i[2]};
+    float lmax = 0.f;
+    for (int j = tid; j < L; j += KNN_THREADS) {
+        const float *ca_j = X + (size_t)(b * L + j) * 42 + 3;
+        float m2 = mi * rmask[b * L + j];
+        float v = m2 * dist_eps(ca_j, ci, 1e-6f);
+        d[j] = v;
+        lmax = fmaxf(lmax, v);
+    }
+    for (int o = 32; o > 0; o >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, o));
+    if (lane == 0) red_v[wid] = lmax;
+    __syncthreads();
+    if (tid == 0) {
+        float m = red_v[0];
+        for (int w = 1; w < KNN_THREADS / 64; w++) m = fmaxf(m, red_v[w]);
+        s_max = m;
+    }
+    __syncthreads();
+    const float dmax = s_max;
+    for (int j = tid; j < L; j += KNN_THREADS) {
+        float m2 = mi * rmask[b * L + j];
+        d[j] = d[j] + (2.f * (1.f - m2)) * dmax;
+    }
+    __syncthreads();
+    for (int k = 0; k < K; k++) {
+        float bv = INFINITY;
+        int bi = 0x7fffffff;
+        for (int j = tid; j < L; j += KNN_THREADS) {
+            float v = d[j];
+            if (v < bv) { bv = v; bi = j; }      // strided scan keeps the lowest j among equal values
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            float ov = __shfl_xor(bv, o);
+            int oi = __shfl_xor(bi, o);
+            if (ov < bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        if (lane == 0) { red_v[wid] = bv; red_i[wid] = bi; }
+        __syncthreads();
+        if (tid == 0) {
+            float v = red_v[0];
+            int ix = red_i[0];
+            for (int w = 1; w < KNN_THREADS / 64; w++)
+                if (red_v[w] < v || (red_v[w] == v && red_i[w] < ix)) { v = red_v[w]; ix = red_i[w]; }
+            s_pick = ix;
+            d[ix] = INFINITY;
+            eidx[(size_t)n * K + k] = b * L + ix;
+            mask_att[(size_t)n * 32 + k] = mi * rmask[b * L + ix];
+        }
+        __syncthreads();
+    }
+    if (tid < 32 && tid >= K) mask_att[(size_t)n * 32 + tid] = 0.f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// edge features + embedding: one block (128 threads) per residue, its K edges.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void cross3(const float *a, const float *b, float *o) {
+    o[0] = a[1] * b[2] - a[2] * b[1];
+    o[1] = a[2] * b[0] - a[0] * b[2];
+    o[2] = a[0] * b[1] - a[1] * b[0];
+}
+__device__ __forceinline__ void unit_nan0(float *v) {
+    float n = sqrtf((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]);
+    for (int k = 0; k < 3; k++) {
+        float q = v[k] / n;
+        v[k] = (q != q) ? 0.f : q;           // nan_to_num of 0/0; +-inf cannot occur for finite input
+    }
+}
+// sign * arccos(n1 . n2) with NaN -> 0 (encoder.py:164-174)
+__device__ float pair_dihedral(const float *p0, const float *p1, const float *p2, const float *p3) {
+    float u0[3], u1[3], u2[3], n1[3], n2[3], c12[3];
+    for (int k = 0; k < 3; k++) { u0[k] = p2[k] - p1[k]; u1[k] = p0[k] - p1[k]; u2[k] = p3[k] - p2[k]; }
+    cross3(u0, u1, n1); unit_nan0(n1);
+    cross3(u0, u2, n2); unit_nan0(n2);
+    cross3(u1, u2, c12);
+    float sg = (c12[0] * u0[0] + c12[1] * u0[1]) + c12[2] * u0[2];
+    float sgn = (sg > 0.f) ? 1.f : ((sg < 0.f) ? -1.f : 0.f);
+    float dt = (n1[0] * n2[0] + n1[1] * n2[1]) + n1[2] * n2[2];
+    float ang = sgn * acosf(dt);
+    return (ang != ang) ? 0.f : ang;
+}
+
+#define EF_THREADS 128
+#define EF_RBF 400
+#define EF_STRIDE 404      // padded row of the per-edge RBF vector in LDS
+
+__global__ void __launch_bounds__(EF_THREADS)
+k_edge_embed(const float *__restrict__ bbpos, const int32_t *__restrict__ eidx,
+             const int64_t *__restrict__ res_index, const int64_t *__restrict__ chain, int K,
+             const float *__restrict__ WT /*[468][128]*/, const float *__restrict__ bias,
+             const float *__restrict__ ln_g, const float *__restrict__ ln_b, float *__restrict__ hE0) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float *rbf = reinterpret_cast<float *>(smem_raw);           // [32][EF_STRIDE]
+    __shared__ float s_extra[32][4];                            // relpos idx, etype, phi, psi
+    __shared__ float s_pos[33][15];                             // slot 32 = centre residue
+    const int n = blockIdx.x, tid = threadIdx.x;
+    for (int t = tid; t < 15; t += EF_THREADS) s_pos[32][t] = bbpos[(size_t)n * 15 + t];
+    for (int t = tid; t < K * 15; t += EF_THREADS) {
+        int e = t / 15, c = t - e * 15;
+        s_pos[e][c] = bbpos[(size_t)eidx[(size_t)n * K + e] * 15 + c];
+    }
+    __syncthreads();
+    // 25 atom-pair distances -> 16 RBFs each (centre atom a major, neighbour atom b minor)
+    for (int item = tid; item < K * 25; item += EF_THREADS) {
+        int e = item / 25, pr = item - e * 25;
+        int a = pr / 5, bq = pr - a * 5;
+        float dd = dist_eps(&s_pos[32][3 * a], &s_pos[e][3 * bq], 1e-6f);
+        float *o = rbf + e * EF_STRIDE + pr * 16;
+        for (int r = 0; r < 16; r++) {
+            // torch.linspace(0, 20, 16): ascending from the start below the midpoint, descending from
+            // the end above it, fp32 step
+            const float step = 20.0f / 15.0f;
+            float mu = (r < 8) ? step * (float)r : 20.0f - step * (float)(15 - r);
+            float z = (dd - mu) / 1.25f;
+            o[r] = expf(-(z * z));
+        }
+    }
+    if (tid < K) {
+        int e = tid;
+        int j = eidx[(size_t)n * K + e];
+        long off = (long)(res_index[n] - res_index[j]) + 32;
+        off = off < 0 ? 0 : (off > 64 ? 64 : off);
+        s_extra[e][0] = (float)off;
+        s_extra[e][1] = (chain[n] == chain[j]) ? 2.f : 1.f;
+        float phi = 0.f, psi = 0.f;
+        if (j != n) {     // the j == i edge is 0 by construction (self-edge dihedrals)
+            // phi_ij = dih(C_i, N_j, CA_j, C_j) ; psi_ij = dih(N_i, CA_i, C_i, N_j)
+            phi = pair_dihedral(&s_pos[32][6], &s_pos[e][0], &s_pos[e][3], &s_pos[e][6]);
+            psi = pair_dihedral(&s_pos[32][0], &s_pos[32][3], &s_pos[32][6], &s_pos[e][0]);
+        }
+        s_extra[e][2] = phi;
+        s_extra[e][3] = psi;
+    }
+    __syncthreads();
+    const int f = tid;
+    float acc[32];
+#pragma unroll
+    for (int e = 0; e < 32; e++) acc[e] = 0.f;
+    for (int m = 0; m < EF_RBF; m += 4) {
+        float w0 = WT[(size_t)(65 + m) * 128 + f], w1 = WT[(size_t)(66 + m) * 128 + f];
+        float w2 = WT[(size_t)(67 + m) * 128 + f], w3 = WT[(size_t)(68 + m) * 128 + f];
+#pragma unroll
+        for (int e = 0; e < 32; e++) {
+            float4 r = *reinterpret_cast<const float4 *>(rbf + e * EF_STRIDE + m);
+            acc[e] = fmaf(w0, r.x, acc[e]);
+            acc[e] = fmaf(w1, r.y, acc[e]);
+            acc[e] = fmaf(w2, r.z, acc[e]);
+            acc[e] = fmaf(w3, r.w, acc[e]);
+        }
+    }
+    __syncthreads();
+    float *pre = rbf;                                            // reuse as [32][128]
+    const float bf = bias[f], w465 = WT[(size_t)465 * 128 + f], w466 = WT[(size_t)466 * 128 + f],
+                w467 = WT[(size_t)467 * 128 + f];
+#pragma unroll
+    for (int e = 0; e < 32; e++) {
+        if (e < K) {
+            int rp = (int)s_extra[e][0];
+            float v = acc[e] + bf + WT[(size_t)rp * 128 + f];
+            v = fmaf(w465, s_extra[e][1], v);
+            v = fmaf(w466, s_extra[e][2], v);
+            v = fmaf(w467, s_extra[e][3], v);
+            pre[e * 128 + f] = v;
+        }
+    }
+    __syncthreads();
+    // LayerNorm per edge: each 64-lane wave takes edges wave, wave+2, ...; 2 features per lane
+    const int lane = tid & 63, wid = tid >> 6;
+    for (int e = wid; e < K; e += EF_THREADS / 64) {
+        float v0 = pre[e * 128 + lane], v1 = pre[e * 128 + 64 + lane];
+        float s = v0 + v1;
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        float mean = s * (1.f / 128.f);
+        float d0 = v0 - mean, d1 = v1 - mean;
+        float q = d0 * d0 + d1 * d1;
+        for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+        float rstd = 1.f / sqrtf(q * (1.f / 128.f) + 1e-5f);
+        float *o = hE0 + ((size_t)n * K + e) * 128;
+        o[lane] = d0 * rstd * ln_g[lane] + ln_b[lane];
+        o[64 + lane] = d1 * rstd * ln_g[64 + lane] + ln_b[64 + lane];
+    }
+}
+
+pp_status pp_launch_prepare(pp_ctx *c, hipStream_t s) {
+    const int N = c->N;
+    hipLaunchKernelGGL(k_frames, dim3((N + 127) / 128), dim3(128), 0, s, c->b.X, N, c->frames, c->bbpos);
+    size_t smem = (size_t)c->L * sizeof(float);
+    if (smem > 64 * 1024) {
+        PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_knn),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    }
+    hipLaunchKernelGGL(k_knn, dim3(N), dim3(KNN_THREADS), smem, s, c->b.X, c->b.residue_mask, c->L, c->K,
+                       c->eidx, c->mask_att);
+    const pp_plan *p = c->plan;
+    size_t smem2 = (size_t)32 * EF_STRIDE * sizeof(float);
+    hipLaunchKernelGGL(k_edge_embed, dim3(N), dim3(EF_THREADS), smem2, s, c->bbpos, c->eidx, c->b.residue_index,
+                       c->b.chain_indices, c->K, p->edge_emb_T, p->w + p->off.edge_emb_b,
+                       p->w + p->off.norm_edges_g, p->w + p->off.norm_edges_b, c->hE0);
+    PP_HIP_CHECK(hipGetLastError());
+    return PP_OK;
+}

@@ -1,0 +1,228 @@
+"""ctypes binding of ``csrc/libpackppi_hip.so`` (the C ABI declared in ``include/packppi_hip.h``).
+
+There is no CPU fallback: if the library is missing or a call fails, a ``RuntimeError`` is
+raised (the reference CLIs only catch/re-raise ``RuntimeError``, eval_diffusion.py:61-64).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+
+from . import constants as rc
+from .weights import check_state_dict
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libpackppi_hip.so")
+_lib = None
+
+SYMBOLS = ("pp_version", "pp_last_error", "pp_plan_create", "pp_plan_destroy", "pp_plan_set_clash_params",
+           "pp_complex_prepare", "pp_ctx_destroy", "pp_ctx_get_graph", "pp_score", "pp_sample", "pp_atom14",
+           "pp_clash", "pp_proximal", "pp_time_kernel")
+
+
+class PPTables(C.Structure):
+    _fields_ = [("default_frames", C.c_void_p), ("atom14_to_group", C.c_void_p), ("atom14_mask", C.c_void_p),
+                ("lit_positions", C.c_void_p), ("between_radius", C.c_void_p)]
+
+
+class PPBatch(C.Structure):
+    _fields_ = [("B", C.c_int32), ("L", C.c_int32), ("X", C.c_void_p), ("atom_mask", C.c_void_p),
+                ("residue_type", C.c_void_p), ("residue_mask", C.c_void_p), ("residue_index", C.c_void_p),
+                ("chain_indices", C.c_void_p), ("BB_D", C.c_void_p), ("BB_D_sincos", C.c_void_p),
+                ("SC_D", C.c_void_p), ("SC_D_mask", C.c_void_p), ("chi_1pi_periodic_mask", C.c_void_p),
+                ("chi_2pi_periodic_mask", C.c_void_p)]
+
+
+def load():
+    """Load the shared library (once).  Fails loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise RuntimeError(f"{_LIB_PATH} is missing: build it with `python -m packppi_amd.build` "
+                           "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    lib = C.CDLL(_LIB_PATH)
+    vp, f, i = C.c_void_p, C.c_float, C.c_int
+    lib.pp_version.restype = C.c_int
+    lib.pp_last_error.restype = C.c_char_p
+    lib.pp_plan_create.argtypes = [vp, C.c_size_t, C.POINTER(PPTables), i, C.POINTER(vp)]
+    lib.pp_plan_destroy.argtypes = [vp]
+    lib.pp_plan_destroy.restype = None
+    lib.pp_plan_set_clash_params.argtypes = [vp, f, vp, vp, vp]
+    lib.pp_complex_prepare.argtypes = [vp, C.POINTER(PPBatch), vp, C.POINTER(vp)]
+    lib.pp_ctx_destroy.argtypes = [vp]
+    lib.pp_ctx_destroy.restype = None
+    lib.pp_ctx_get_graph.argtypes = [vp, vp, vp, vp]
+    lib.pp_score.argtypes = [vp, vp, f, vp, vp, vp]
+    lib.pp_sample.argtypes = [vp, vp, vp, i, i, vp, vp]
+    lib.pp_atom14.argtypes = [vp, vp, vp, vp]
+    lib.pp_clash.argtypes = [vp, vp, vp, vp, vp]
+    lib.pp_proximal.argtypes = [vp, vp, f, i, vp, vp, vp, vp]
+    lib.pp_time_kernel.argtypes = [vp, i, i, C.POINTER(C.c_float), vp]
+    _lib = lib
+    return lib
+
+
+def _check(status, what):
+    if status != 0:
+        msg = load().pp_last_error()
+        raise RuntimeError(f"{what} failed (pp_status {status}): {msg.decode() if msg else ''}")
+
+
+def _stream(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+class Plan:
+    """Device-resident weights + chemistry tables (one per GPU)."""
+
+    def __init__(self, state_dict, device):
+        """``state_dict=None`` builds a geometry-only plan (atom14 / clash / proximal)."""
+        lib = load()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("packppi_amd runs on an MI355X HIP device only (got device '%s')" % device)
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        self.has_network = state_dict is not None
+        if self.has_network:
+            sd = check_state_dict(state_dict)
+            flat = np.ascontiguousarray(torch.cat([v.reshape(-1) for v in sd.values()]).numpy(), dtype=np.float32)
+            wptr, wn = flat.ctypes.data, flat.size
+        else:
+            wptr, wn = None, 0
+        self._keep = [
+            np.ascontiguousarray(rc.default_frames, np.float32), np.ascontiguousarray(rc.atom14_to_group, np.int32),
+            np.ascontiguousarray(rc.atom14_mask, np.float32), np.ascontiguousarray(rc.lit_positions, np.float32),
+            np.ascontiguousarray(rc.between_radius, np.float32)]
+        tab = PPTables(*[a.ctypes.data for a in self._keep])
+        h = C.c_void_p()
+        _check(lib.pp_plan_create(wptr, wn, C.byref(tab), self.device.index, C.byref(h)), "pp_plan_create")
+        self.handle = h
+        self._clash_params = None
+
+    def set_clash_params(self, vtf, tol):
+        key = (float(vtf), float(tol))
+        if self._clash_params == key:
+            return
+        lo, up = rc.make_atom14_dists_bounds(overlap_tolerance=float(tol), bond_length_tolerance_factor=float(vtf))
+        lo, up = np.ascontiguousarray(lo, np.float32), np.ascontiguousarray(up, np.float32)
+        _check(load().pp_plan_set_clash_params(self.handle, float(tol), lo.ctypes.data, up.ctypes.data,
+                                               _stream(self.device)), "pp_plan_set_clash_params")
+        self._clash_params = key
+
+    def __del__(self):
+        h = getattr(self, "handle", None)
+        if h and _lib is not None:
+            _lib.pp_plan_destroy(h)
+            self.handle = None
+
+
+_BATCH_SPEC = (("X", torch.float32), ("atom_mask", torch.float32), ("residue_type", torch.int64),
+               ("residue_mask", torch.float32), ("residue_index", torch.int64), ("chain_indices", torch.int64),
+               ("BB_D", torch.float32), ("BB_D_sincos", torch.float32), ("SC_D", torch.float32),
+               ("SC_D_mask", torch.float32), ("chi_1pi_periodic_mask", torch.bool),
+               ("chi_2pi_periodic_mask", torch.bool))
+
+
+class Context:
+    """One batch of complexes on one GPU: cached kNN graph, edge embedding, frames, workspaces."""
+
+    def __init__(self, plan: Plan, batch):
+        lib = load()
+        self.plan = plan
+        dev = plan.device
+        B, L = batch["residue_type"].shape
+        self.B, self.L, self.K = int(B), int(L), min(32, int(L))
+        self._t = {}
+        for key, dt in _BATCH_SPEC:
+            t = batch.get(key) if hasattr(batch, "get") else getattr(batch, key, None)
+            if t is None:
+                if plan.has_network or key in ("X", "residue_type", "BB_D"):
+                    raise RuntimeError(f"batch.{key} is missing")
+                self._t[key] = None
+                continue
+            if t.device.type != "cuda" or (t.device.index is not None and t.device.index != dev.index):
+                raise RuntimeError(f"batch.{key} is on {t.device}, expected {dev} (call batch.to(device) first)")
+            self._t[key] = t.to(dt).contiguous()
+        pb = PPBatch(self.B, self.L, *[(self._t[k].data_ptr() if self._t[k] is not None else None)
+                                       for k, _ in _BATCH_SPEC])
+        h = C.c_void_p()
+        _check(lib.pp_complex_prepare(plan.handle, C.byref(pb), _stream(dev), C.byref(h)), "pp_complex_prepare")
+        self.handle = h
+
+    def _new(self, *shape, dtype=torch.float32):
+        return torch.empty(*shape, dtype=dtype, device=self.plan.device)
+
+    def _chi(self, chi):
+        chi = chi.to(device=self.plan.device, dtype=torch.float32).reshape(self.B, self.L, 4).contiguous()
+        return chi
+
+    def graph(self):
+        E = self._new(self.B, self.L, self.K, dtype=torch.int64)
+        hE = self._new(self.B, self.L, self.K, 128)
+        _check(load().pp_ctx_get_graph(self.handle, _ptr(E), _ptr(hE), _stream(self.plan.device)), "pp_ctx_get_graph")
+        return E, hE
+
+    def score(self, chi, t: float):
+        chi = self._chi(chi)
+        score, hV = self._new(self.B, self.L, 4), self._new(self.B, self.L, 128)
+        _check(load().pp_score(self.handle, _ptr(chi), float(t), _ptr(score), _ptr(hV), _stream(self.plan.device)),
+               "pp_score")
+        return score, hV
+
+    def sample(self, chi, schedule, mode="ode", sde_noise=None):
+        chi = self._chi(chi).clone()
+        sched = np.ascontiguousarray(torch.as_tensor(schedule, dtype=torch.float32).cpu().numpy())
+        if mode not in ("ode", "sde"):
+            raise NotImplementedError(mode)
+        nz = None
+        if mode == "sde":
+            if sde_noise is None:
+                raise RuntimeError("sde sampling needs the per-step noise tensor")
+            nz = sde_noise.to(device=self.plan.device, dtype=torch.float32).contiguous()
+            assert nz.numel() == (len(sched) - 1) * 2 * self.B * self.L * 4
+        _check(load().pp_sample(self.handle, _ptr(chi), sched.ctypes.data, int(len(sched)), 0 if mode == "ode" else 1,
+                                _ptr(nz), _stream(self.plan.device)), "pp_sample")
+        return chi
+
+    def atom14(self, chi):
+        chi = self._chi(chi)
+        xyz = self._new(self.B, self.L, 14, 3)
+        _check(load().pp_atom14(self.handle, _ptr(chi), _ptr(xyz), _stream(self.plan.device)), "pp_atom14")
+        return xyz
+
+    def clash(self, chi, vtf=12.0, tol=0.5, need_grad=False):
+        self.plan.set_clash_params(vtf, tol)
+        chi = self._chi(chi)
+        per_res = self._new(self.B, self.L)
+        dchi = self._new(self.B, self.L, 4) if need_grad else None
+        _check(load().pp_clash(self.handle, _ptr(chi), _ptr(per_res), _ptr(dchi), _stream(self.plan.device)), "pp_clash")
+        return (per_res, dchi) if need_grad else per_res
+
+    def proximal(self, chi, vtf, tol, lamda, num_steps, want_traj=True):
+        self.plan.set_clash_params(vtf, tol)
+        chi = self._chi(chi)
+        traj = self._new(num_steps, self.B, self.L, 4) if want_traj else None
+        last = self._new(self.B, self.L, 4)
+        losses = self._new(num_steps)
+        _check(load().pp_proximal(self.handle, _ptr(chi), float(lamda), int(num_steps), _ptr(traj), _ptr(last),
+                                  _ptr(losses), _stream(self.plan.device)), "pp_proximal")
+        return traj, last, losses
+
+    def time_kernel(self, which: int, iters: int = 20) -> float:
+        """Average ms per launch of the node-message (0) / edge-update (1) kernel, HIP events on the current stream."""
+        ms = C.c_float(0.0)
+        _check(load().pp_time_kernel(self.handle, int(which), int(iters), C.byref(ms), _stream(self.plan.device)),
+               "pp_time_kernel")
+        return float(ms.value)
+
+    def __del__(self):
+        h = getattr(self, "handle", None)
+        if h and _lib is not None:
+            _lib.pp_ctx_destroy(h)
+            self.handle = None

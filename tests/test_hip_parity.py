@@ -1,0 +1,204 @@
+"""GPU parity: the HIP path (through the C ABI) vs the reference's golden vectors and the CPU oracle.
+
+Tolerances (BASELINE.json north_star): chi within 1e-4 rad, atom_rmsd within 1e-3 A^2 of the reference
+CPU path on identical initial noise.  Intermediate tensors are held to "fp32, different summation order".
+"""
+import numpy as np
+import pytest
+import torch
+
+from .conftest import load_golden, wrapped_absdiff
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+OPS = ["g2_ops_L8", "g2_ops_L33", "g2_ops_L64", "g2_ops_B3"]
+
+
+@pytest.fixture(scope="module")
+def model(weights):
+    from packppi_amd.module import TDiffusionModule
+    return TDiffusionModule(weights, device=DEV)
+
+
+def _gpu(batch):
+    return batch.to(DEV)
+
+
+@pytest.mark.parametrize("name", OPS)
+def test_graph(name, model):
+    b, g = load_golden(name)
+    ctx = model._context(_gpu(b))
+    E, hE = ctx.graph()
+    valid = b.residue_mask.bool()
+    E, hE = E.cpu(), hE.cpu()
+    # Same neighbour SET per residue.  The slot order among exactly equal CA distances (common on ideal-geometry
+    # synthetic backbones: every i,i+1 pair is 3.80 A) is unspecified in torch.topk; this build breaks ties by
+    # lower index.  Nothing downstream depends on the slot order except fp32 summation order.
+    mine_sorted, perm_m = E.sort(-1)
+    ref_sorted, perm_r = g["E_idx"].sort(-1)
+
+    def valid_sets(idx):     # padded partners (mask 0) are all tied at 2*rowmax: which of them fill the list is arbitrary
+        ok = torch.gather(b.residue_mask[:, None].expand(-1, idx.shape[1], -1), 2, idx) > 0
+        return torch.where(ok, idx, torch.full_like(idx, -1)).sort(-1)[0]
+
+    assert torch.equal(valid_sets(E)[valid], valid_sets(g["E_idx"])[valid])
+    ca = b.X[:, :, 1, :]
+    for E_any in (E, g["E_idx"]):          # both lists are ascending in distance
+        d = (ca[:, :, None, :] - torch.gather(ca[:, None].expand(-1, ca.shape[1], -1, -1), 2,
+                                              E_any[..., None].expand(-1, -1, -1, 3))).norm(dim=-1)
+        ok = torch.gather(b.residue_mask[:, None].expand(-1, ca.shape[1], -1), 2, E_any) > 0
+        d = torch.where(ok, d, torch.full_like(d, 1e9))        # padded partners fill the tail of the list
+        assert ((d[..., 1:] - d[..., :-1])[valid] > -1e-5).all()
+
+    def by_neighbour(h, perm):
+        return torch.gather(h, 2, perm[..., None].expand(-1, -1, -1, 128))
+
+    # the j == i edge carries exactly-zero dihedrals here: compare with that oracle variant tightly,
+    # and with the reference's own tensor at the size of its arccos rounding noise
+    from oracle import ref_cpu as O
+    E_o, hE_o = O.encode_static(model.state_dict(), b, zero_self_dihedral=True)
+    hm = by_neighbour(hE, perm_m)
+    real = (torch.gather(b.residue_mask[:, None].expand(-1, E.shape[1], -1), 2, mine_sorted) > 0) & valid[..., None]
+    assert (hm - by_neighbour(hE_o, E_o.sort(-1)[1]))[real].abs().max() < 2e-5
+    assert (hm - by_neighbour(g["hE0"], perm_r))[real].abs().max() < 5e-3
+
+
+@pytest.mark.parametrize("name", OPS)
+def test_network(name, model):
+    b, g = load_golden(name)
+    gb = _gpu(b)
+    B, L = b.residue_type.shape
+    valid = b.residue_mask.bool()
+    chi = g["init_chi_seed7"]
+    for tval, tn in ((1.0, "t1"), (0.5, "t05"), (1.0 / 30, "t30")):
+        t = torch.tensor([tval]).repeat_interleave(B * L)
+        score, hV = model.network(gb, chi.to(DEV), t)
+        assert (hV.cpu() - g[f"hV_{tn}"])[valid].abs().max() < 2e-3, tn
+        assert (score.cpu() - g[f"score_{tn}"])[valid].abs().max() < 1e-3, tn
+    # against the oracle with the same self-edge convention the agreement is at fp32 rounding level
+    from oracle import ref_cpu as O
+    t = torch.tensor([0.5]).repeat_interleave(B * L)
+    s_o, h_o = O.network(model.state_dict(), b, chi, t, zero_self_dihedral=True)
+    score, hV = model.network(gb, chi.to(DEV), t)
+    assert (hV.cpu() - h_o)[valid].abs().max() < 1e-4
+    assert (score.cpu() - s_o)[valid].abs().max() < 5e-5
+
+
+@pytest.mark.parametrize("name", OPS)
+def test_atom14_clash(name, model):
+    from packppi_amd.functional import compute_residue_clash, get_atom14_coords
+    b, g = load_golden(name)
+    gb = _gpu(b)
+    chi = g["init_chi_seed7"].to(DEV)
+    xyz = get_atom14_coords(gb.X, gb.residue_type, gb.BB_D, chi).cpu()
+    assert (xyz - g["atom14_init"]).abs().max() < 2e-5
+    assert torch.equal(xyz[..., :4, :], b.X[..., :4, :])
+    pr = compute_residue_clash(gb, chi, 12.0, 0.5).cpu()
+    assert (pr - g["clash_init"]).abs().max() < 2e-5
+    pr = compute_residue_clash(gb, gb.SC_D, 12.0, 0.1).cpu()
+    assert (pr - g["clash_true_tol01"]).abs().max() < 2e-5
+    from packppi_amd.functional import _ctx_for
+    _, grad = _ctx_for(gb).clash(chi, 12.0, 0.5, need_grad=True)
+    ref = g["clash_grad_init"]
+    assert (grad.cpu() - ref).abs().max() < 1e-5 + 1e-4 * ref.abs().max()
+
+
+@pytest.mark.parametrize("name", OPS)
+def test_metrics(name, model):
+    b, g = load_golden(name)
+    m = model.analyze_samples(_gpu(b), g["init_chi_seed7"].to(DEV))
+    for k, v in m.items():
+        assert abs(float(v) - float(g["metric." + k])) < 1e-4 * max(1.0, abs(float(v))), k
+
+
+@pytest.mark.parametrize("name,steps", [("g3_sampling_L64", (30, 100)), ("g3_sampling_L300", (30, 100)),
+                                        ("g3_sampling_B3", (30,))])
+def test_sampling_ode(name, steps, model):
+    b, g = load_golden(name)
+    ctx = model._context(_gpu(b))
+    for n in steps:
+        chi = ctx.sample(g["init_chi_seed11"].to(DEV), torch.linspace(1, 0, n + 1)).cpu()
+        d = wrapped_absdiff(chi, g[f"chi_ode_{n}"])[b.SC_D_mask.bool()]
+        assert d.max() < 1e-4, (n, float(d.max()))
+        assert torch.equal(chi[~b.SC_D_mask.bool()], torch.zeros_like(chi[~b.SC_D_mask.bool()]))
+
+
+def test_sampling_is_deterministic(model):
+    b, g = load_golden("g3_sampling_L64")
+    ctx = model._context(_gpu(b))
+    a = ctx.sample(g["init_chi_seed11"].to(DEV), torch.linspace(1, 0, 31))
+    c = ctx.sample(g["init_chi_seed11"].to(DEV), torch.linspace(1, 0, 31))
+    assert torch.equal(a, c)
+
+
+def test_sampling_sde(weights):
+    from packppi_amd.module import TDiffusionModule
+    b, g = load_golden("g3_sampling_sde_L33")
+    m = TDiffusionModule(weights, sample_cfg=dict(mode="sde"), device=DEV)
+    n = 30
+    torch.manual_seed(99)
+    N = b.residue_type.numel()
+    noise = torch.stack([torch.stack((torch.normal(mean=0, std=1, size=(N, 4)),
+                                      torch.normal(mean=0, std=1, size=(N, 4)))) for _ in range(n)])
+    chi = m._context(_gpu(b)).sample(g["init_chi_seed11"].to(DEV), torch.linspace(1, 0, n + 1), "sde", noise).cpu()
+    d = wrapped_absdiff(chi, g["chi_sde_30_seed99"])[b.SC_D_mask.bool()]
+    assert d.max() < 1e-4, float(d.max())
+
+
+@pytest.mark.parametrize("name", ["g3_proximal_L64", "g3_proximal_L120"])
+def test_proximal(name, model):
+    from packppi_amd.functional import find_clash_mask, proximal_optimizer
+    b, g = load_golden(name)
+    gb = _gpu(b)
+    init = g["init_chi_seed11"].to(DEV)
+    # The optimisation is a non-smooth (hinge) objective driven by Adam's g/sqrt(v) normalisation: perturbations
+    # grow ~1.2-1.4x per step.  Measured on these fixtures: the REFERENCE ITSELF moves by 2.8e-4 (L=64) / 3.7e-5
+    # (L=120) rad between fp32 and fp64 after 50 steps, this path by 7.6e-4 / 4.5e-3 from the fp32 reference, while
+    # both agree to <4e-6 rad through step 10 and the analytic gradient is as close to the fp64 gradient as the
+    # reference's fp32 autograd is (1.6e-7 vs 1.1e-7 abs).  So: tight bound on the early steps and on the loss
+    # curve, statistical bound on the 50-step angles (DESIGN.md "Proximal parity").
+    for n in (5, 50):
+        chis, losses = proximal_optimizer(gb, init, 12.0, 0.5, 1.0, n)
+        assert len(chis) == n and len(losses) == n
+        assert np.allclose(np.array(losses), g[f"prox_losses_{n}"].numpy(), rtol=2e-4, atol=1e-6)
+        assert wrapped_absdiff(chis[0].cpu(), g[f"prox_chi_first_{n}"]).max() < 1e-5
+        d = wrapped_absdiff(chis[-1].cpu(), g[f"prox_chi_last_{n}"])
+        mask = find_clash_mask(gb, init, 12.0, 0.5)
+        if n == 5:
+            assert d.max() < 1e-5
+        else:
+            assert d.max() < 2e-2 and (d > 1e-4).sum() <= 0.1 * mask.sum(), (float(d.max()), int((d > 1e-4).sum()))
+        assert torch.equal(chis[-1][~mask], init[~mask])
+    # sampling(use_proximal=True) end to end, 30 steps, injected noise
+    model.schedule = torch.linspace(1, 0, 31)
+    orig = model.add_sc_noise
+    model.add_sc_noise = lambda batch, t: (init.clone(), None)
+    try:
+        res = model.sampling(gb, use_proximal=True).cpu()
+    finally:
+        model.add_sc_noise = orig
+    d = wrapped_absdiff(res, g["chi_ode_30_proximal"])[b.SC_D_mask.bool()]
+    assert (d > 2e-4).float().mean() < 0.1 and d.max() < 2e-2, float(d.max())
+
+
+def test_T1124_100_steps(model):
+    """BASELINE config 2: data/T1124_lig.pdb, 100 steps, vs the reference CPU output on identical noise."""
+    b, g = load_golden("g4_T1124")
+    gb = _gpu(b)
+    chi = model._context(gb).sample(g["init_chi_seed1124"].to(DEV), torch.linspace(1, 0, 101))
+    d = wrapped_absdiff(chi.cpu(), g["chi_ode_100"])[b.SC_D_mask.bool()]
+    assert d.max() < 1e-4, float(d.max())
+    m = model.analyze_samples(gb, chi)
+    assert abs(float(m["atom_rmsd"]) - float(g["metric.atom_rmsd"])) < 1e-3
+    from packppi_amd.functional import compute_residue_clash
+    pr = compute_residue_clash(gb, g["chi_ode_100"].to(DEV), 12.0, 0.5).cpu()
+    assert (pr - g["clash_final"]).abs().max() < 2e-5
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    import packppi_amd.lib as L
+    monkeypatch.setattr(L, "_lib", None)
+    monkeypatch.setattr(L, "_LIB_PATH", "/nonexistent/libpackppi_hip.so")
+    with pytest.raises(RuntimeError):
+        L.load()
