@@ -7,27 +7,27 @@
 //                   or (last layer) decoder (TorsionalDiffusion.py:105-109), reverse step
 //                   (schedule.py:198-235, TorsionalDiffusion.py:268-280) and the next embedding.
 //
-// Blocks of 128 threads own 4 consecutive nodes; thread f owns output feature f for all four, so
-// every weight (transposed copy, [in][out]) is read once per block, coalesced, and reused 4x.
-// Activations sit in LDS as float4 (one component per node).
+// This work is ~3% of the FLOPs but a long dependent chain over only B*L rows, so it is laid out for
+// latency: a block of 512 threads owns 4 consecutive nodes; thread (f = tid & 127, ks = tid >> 7) owns
+// output feature f for all four nodes over the ks-th quarter of the reduction dimension; the four
+// partial sums meet in LDS.  Weights are read from transposed copies ([in][out]) so a wave's loads are
+// contiguous; activations sit in LDS as float4 (one component per node).  The cheap epilogues
+// (LayerNorm, bias, ReLU) are replicated in the four ks-groups to keep control flow uniform.
 #include "pp_internal.h"
 
-#define NT 128
+#define NT 512
 #define NB 4
 
 struct NodeArgs {
     int N;
     const float *rmask;          // [N]
-    // embedding inputs
     const int64_t *rtype;        // [N]
     const float *bb_sincos;      // [N][6]
     const float *sc_mask;        // [N][4]
     const uint8_t *m1pi, *m2pi;  // [N][4]
     const float *frames;         // [N][12]
     const StepParams *steps;
-    // weights
     const float *embT, *emb_b, *emb_g, *emb_beta;
-    // state
     float *hV, *S, *msum;
     float *ptsN, *PAn, *PCn, *ptsE, *PAe, *PCe;
     float *score;
@@ -46,6 +46,15 @@ struct UpdW {
     const float *d0_inT, *d0_in_b, *d0_outT, *d0_out_b, *d2_inT, *d2_in_b, *d2_outT, *d2_out_b;
 };
 
+struct Smem {
+    float4 part[2][4 * 512];   // ping-pong partial sums  (64 KB)
+    float4 a[512];             // wide activation vector (FFN hidden, decoder scratch)
+    float4 h[128];             // current node vector
+    float4 p[24];              // local points / small inputs
+    float4 red[2][8];          // LayerNorm partials, ping-pong
+    int flip, rflip;
+};
+
 __device__ __forceinline__ float4 f4(float v) { return make_float4(v, v, v, v); }
 __device__ __forceinline__ float4 fma4(float w, float4 a, float4 c) {
     return make_float4(fmaf(w, a.x, c.x), fmaf(w, a.y, c.y), fmaf(w, a.z, c.z), fmaf(w, a.w, c.w));
@@ -53,14 +62,29 @@ __device__ __forceinline__ float4 fma4(float w, float4 a, float4 c) {
 __device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ float4 sub4(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
 __device__ __forceinline__ float4 mul4(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
-__device__ __forceinline__ float4 relu4(float4 a) { return make_float4(fmaxf(a.x, 0.f), fmaxf(a.y, 0.f), fmaf(0.f, 0.f, fmaxf(a.z, 0.f)), fmaxf(a.w, 0.f)); }
+__device__ __forceinline__ float4 scale4(float4 a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
+__device__ __forceinline__ float4 relu4(float4 a) { return make_float4(fmaxf(a.x, 0.f), fmaxf(a.y, 0.f), fmaxf(a.z, 0.f), fmaxf(a.w, 0.f)); }
+__device__ __forceinline__ float comp(float4 v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w)); }
 
-// acc += sum_k WT[k*ldo + col] * act[k]
+// partial sum over the ks-th quarter of the reduction dimension
 template <int KIN>
-__device__ __forceinline__ float4 dense4(const float *__restrict__ WT, int ldo, int col, const float4 *act, float4 acc) {
-#pragma unroll 8
-    for (int k = 0; k < KIN; k++) acc = fma4(WT[(size_t)k * ldo + col], act[k], acc);
+__device__ __forceinline__ float4 dense_slice(const float *__restrict__ WT, int ldo, int col, const float4 *act, int ks) {
+    constexpr int KL = KIN / 4;
+    const float *w = WT + (size_t)(ks * KL) * ldo + col;
+    const float4 *a = act + ks * KL;
+    float4 acc = f4(0.f);
+#pragma unroll 16
+    for (int i = 0; i < KL; i++) acc = fma4(w[(size_t)i * ldo], a[i], acc);
     return acc;
+}
+
+// meet the four K-slices: every thread returns the full sum for its column (one barrier, ping-pong buffer)
+__device__ __forceinline__ float4 meet(Smem &sm, int &flip, float4 partial, int stride, int col, int ks) {
+    float4 *buf = sm.part[flip];
+    flip ^= 1;
+    buf[ks * stride + col] = partial;
+    __syncthreads();
+    return add4(add4(buf[col], buf[stride + col]), add4(buf[2 * stride + col], buf[3 * stride + col]));
 }
 
 __device__ __forceinline__ float4 wave_sum4(float4 v) {
@@ -70,24 +94,25 @@ __device__ __forceinline__ float4 wave_sum4(float4 v) {
     return v;
 }
 
-// LayerNorm over the 128 features held one-per-thread, four nodes at once (eps 1e-5, biased variance).
-__device__ __forceinline__ float4 layernorm4(float4 v, float g, float b, float4 *s_red) {
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+// LayerNorm over 128 features (one per thread of a ks-group = 2 waves), four nodes at once, eps 1e-5, two-pass
+__device__ __forceinline__ float4 layernorm4(Smem &sm, int &rflip, float4 v, float g, float b) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, grp = wid & ~1;
     float4 s = wave_sum4(v);
-    if (lane == 0) s_red[wid] = s;
+    float4 *r = sm.red[rflip];
+    rflip ^= 1;
+    if (lane == 0) r[wid] = s;
     __syncthreads();
-    float4 mean = add4(s_red[0], s_red[1]);
-    mean = make_float4(mean.x * (1.f / 128.f), mean.y * (1.f / 128.f), mean.z * (1.f / 128.f), mean.w * (1.f / 128.f));
-    __syncthreads();
-    float4 d = sub4(v, mean);
+    const float4 mean = scale4(add4(r[grp], r[grp + 1]), 1.f / 128.f);
+    const float4 d = sub4(v, mean);
     float4 q = wave_sum4(mul4(d, d));
-    if (lane == 0) s_red[wid] = q;
+    r = sm.red[rflip];
+    rflip ^= 1;
+    if (lane == 0) r[wid] = q;
     __syncthreads();
-    float4 var = add4(s_red[0], s_red[1]);
-    __syncthreads();
-    float4 r = make_float4(1.f / sqrtf(var.x * (1.f / 128.f) + 1e-5f), 1.f / sqrtf(var.y * (1.f / 128.f) + 1e-5f),
-                           1.f / sqrtf(var.z * (1.f / 128.f) + 1e-5f), 1.f / sqrtf(var.w * (1.f / 128.f) + 1e-5f));
-    return make_float4(d.x * r.x * g + b, d.y * r.y * g + b, d.z * r.z * g + b, d.w * r.w * g + b);
+    const float4 var = scale4(add4(r[grp], r[grp + 1]), 1.f / 128.f);
+    const float4 rs = make_float4(1.f / sqrtf(var.x + 1e-5f), 1.f / sqrtf(var.y + 1e-5f), 1.f / sqrtf(var.z + 1e-5f),
+                                  1.f / sqrtf(var.w + 1e-5f));
+    return make_float4(d.x * rs.x * g + b, d.y * rs.y * g + b, d.z * rs.z * g + b, d.w * rs.w * g + b);
 }
 
 __device__ __forceinline__ void store_rows(float *dst, int ld, int n0, int N, int col, float4 v) {
@@ -104,28 +129,40 @@ __device__ __forceinline__ float4 load_rows(const float *src, int ld, int n0, in
     if (n0 + 3 < N) v.w = src[(size_t)(n0 + 3) * ld + col];
     return v;
 }
-__device__ __forceinline__ float comp(float4 v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w)); }
 
-// Inputs of one message function from h (LDS, float4[128]): points (local + global), W_A h + b, W_C h.
-__device__ void message_inputs(const PreW &w, const float4 *s_h, float4 *s_p, const float *frames, int n0, int N,
+// Inputs of one message function from h = sm.h: points (local + global), W_A h + b, W_C h.
+// One meeting round for all 128 + 128 + 24 outputs.
+__device__ void message_inputs(Smem &sm, int &flip, const PreW &w, const float *frames, int n0, int N,
                                float *pts, float *PA, float *PC) {
-    const int f = threadIdx.x;
-    float4 a = dense4<128>(w.AT, 128, f, s_h, f4(w.in_b[f]));
-    float4 c = dense4<128>(w.CT, 128, f, s_h, f4(0.f));
-    store_rows(PA, 128, n0, N, f, a);
-    store_rows(PC, 128, n0, N, f, c);
-    if (f < 24) {
-        float4 p = dense4<128>(w.ptsT, 24, f, s_h, f4(w.pts_b[f]));
-        s_p[f] = p;
+    const int f = threadIdx.x & 127, ks = threadIdx.x >> 7;
+    float4 pa = dense_slice<128>(w.AT, 128, f, sm.h, ks);
+    float4 pc = dense_slice<128>(w.CT, 128, f, sm.h, ks);
+    float4 pp = f < 24 ? dense_slice<128>(w.ptsT, 24, f, sm.h, ks) : f4(0.f);
+    float4 *buf = sm.part[flip];
+    flip ^= 1;
+    buf[ks * 384 + f] = pa;
+    buf[ks * 384 + 128 + f] = pc;
+    if (f < 24) buf[ks * 384 + 256 + f] = pp;
+    __syncthreads();
+    if (ks == 0) {
+        float4 a = add4(add4(buf[f], buf[384 + f]), add4(buf[768 + f], buf[1152 + f]));
+        store_rows(PA, 128, n0, N, f, add4(a, f4(w.in_b[f])));
+    } else if (ks == 1) {
+        float4 c = add4(add4(buf[128 + f], buf[512 + f]), add4(buf[896 + f], buf[1280 + f]));
+        store_rows(PC, 128, n0, N, f, c);
+    } else if (ks == 2 && f < 24) {
+        float4 p = add4(add4(buf[256 + f], buf[640 + f]), add4(buf[1024 + f], buf[1408 + f]));
+        p = add4(p, f4(w.pts_b[f]));
+        sm.p[f] = p;
         store_rows(pts, 48, n0, N, f, p);
     }
     __syncthreads();
-    if (f < 32) {                      // (point q, node i): p_glob = R p_loc + t
-        int q = f >> 2, i = f & 3;
+    if (threadIdx.x < 32) {            // (point q, node i): p_glob = R p_loc + t
+        int q = threadIdx.x >> 2, i = threadIdx.x & 3;
         int n = n0 + i;
         if (n < N) {
             const float *fr = frames + (size_t)n * 12;
-            float x = comp(s_p[3 * q], i), y = comp(s_p[3 * q + 1], i), z = comp(s_p[3 * q + 2], i);
+            float x = comp(sm.p[3 * q], i), y = comp(sm.p[3 * q + 1], i), z = comp(sm.p[3 * q + 2], i);
             for (int r = 0; r < 3; r++)
                 pts[(size_t)n * 48 + 24 + 3 * q + r] = (fr[3 * r] * x + fr[3 * r + 1] * y + fr[3 * r + 2] * z) + fr[9 + r];
         }
@@ -133,17 +170,16 @@ __device__ void message_inputs(const PreW &w, const float4 *s_h, float4 *s_p, co
     __syncthreads();
 }
 
-// Node embedding for 4 nodes -> float4 (before LN) for feature f.
-__device__ __forceinline__ float4 embed_pre(const NodeArgs &A, const float *chi, int step, int n0, float4 *s_in) {
-    const int f = threadIdx.x;
-    // s_in[0..5] bb sincos, [6..13] sc sincos*mask, [14..17] residue type (as float)
-    if (f < 6) s_in[f] = load_rows(A.bb_sincos, 6, n0, A.N, f);
-    else if (f < 14) {
-        int k = (f - 6) >> 1, sc = (f - 6) & 1;
+// Node embedding for 4 nodes -> float4 (before LN) for feature f (all ks-groups compute the same thing)
+__device__ __forceinline__ float4 embed_pre(Smem &sm, const NodeArgs &A, const float *chi, int step, int n0) {
+    const int t = threadIdx.x, f = t & 127;
+    if (t < 6) sm.p[t] = load_rows(A.bb_sincos, 6, n0, A.N, t);
+    else if (t < 14) {
+        int k = (t - 6) >> 1, sc = (t - 6) & 1;
         float4 x = load_rows(chi, 4, n0, A.N, k), m = load_rows(A.sc_mask, 4, n0, A.N, k);
         float4 v = sc ? make_float4(cosf(x.x), cosf(x.y), cosf(x.z), cosf(x.w))
                       : make_float4(sinf(x.x), sinf(x.y), sinf(x.z), sinf(x.w));
-        s_in[f] = mul4(v, m);
+        sm.p[t] = mul4(v, m);
     }
     __syncthreads();
     float4 acc = f4(A.emb_b[f]);
@@ -151,7 +187,7 @@ __device__ __forceinline__ float4 embed_pre(const NodeArgs &A, const float *chi,
     int t2 = n0 + 2 < A.N ? (int)A.rtype[n0 + 2] : 0, t3 = n0 + 3 < A.N ? (int)A.rtype[n0 + 3] : 0;
     acc = add4(acc, make_float4(A.embT[t0 * 128 + f], A.embT[t1 * 128 + f], A.embT[t2 * 128 + f], A.embT[t3 * 128 + f]));
 #pragma unroll
-    for (int k = 0; k < 14; k++) acc = fma4(A.embT[(21 + k) * 128 + f], s_in[k], acc);
+    for (int k = 0; k < 14; k++) acc = fma4(A.embT[(21 + k) * 128 + f], sm.p[k], acc);
     const float *te = A.steps[step].temb;
     float tacc = 0.f;
 #pragma unroll
@@ -161,16 +197,17 @@ __device__ __forceinline__ float4 embed_pre(const NodeArgs &A, const float *chi,
 
 __global__ void __launch_bounds__(NT)
 k_node_embed(NodeArgs A, PreW pre0, const float *chi, int step) {
-    __shared__ float4 s_h[128];
-    __shared__ float4 s_in[24];
-    __shared__ float4 s_red[2];
-    const int f = threadIdx.x, n0 = blockIdx.x * NB;
-    float4 v = embed_pre(A, chi, step, n0, s_in);
-    float4 h = layernorm4(v, A.emb_g[f], A.emb_beta[f], s_red);
-    store_rows(A.hV, 128, n0, A.N, f, h);
-    s_h[f] = h;
+    __shared__ Smem sm;
+    int flip = 0, rflip = 0;
+    const int f = threadIdx.x & 127, ks = threadIdx.x >> 7, n0 = blockIdx.x * NB;
+    float4 v = embed_pre(sm, A, chi, step, n0);
+    float4 h = layernorm4(sm, rflip, v, A.emb_g[f], A.emb_beta[f]);
+    if (ks == 0) {
+        store_rows(A.hV, 128, n0, A.N, f, h);
+        sm.h[f] = h;
+    }
     __syncthreads();
-    message_inputs(pre0, s_h, s_in, A.frames, n0, A.N, A.ptsN, A.PAn, A.PCn);
+    message_inputs(sm, flip, pre0, A.frames, n0, A.N, A.ptsN, A.PAn, A.PCn);
 }
 
 // (x + pi) % (2 pi) - pi with torch.remainder semantics in fp32
@@ -182,15 +219,23 @@ __device__ __forceinline__ float wrap_pi(float x) {
     return r - PIf;
 }
 
+// small dense layer used by the decoder: width <= 128 outputs, K split over the four ks-groups
+template <int KIN>
+__device__ __forceinline__ float4 dense_small(Smem &sm, int &flip, const float *WT, int width, const float4 *act,
+                                              const float *bias) {
+    const int f = threadIdx.x & 127, ks = threadIdx.x >> 7;
+    float4 p = f < width ? dense_slice<KIN>(WT, width, f, act, ks) : f4(0.f);
+    float4 r = meet(sm, flip, p, 128, f, ks);
+    return f < width ? add4(r, f4(bias[f])) : f4(0.f);
+}
+
 __global__ void __launch_bounds__(NT)
 k_node_update(NodeArgs A, UpdW W, int last_mode, float *chi, int step, int sde, const float *noise, int embed_next,
               PreW pre0) {
-    __shared__ float4 s_a[512];
-    __shared__ float4 s_h[128];
-    __shared__ float4 s_p[24];
-    __shared__ float4 s_red[2];
-    const int f = threadIdx.x, n0 = blockIdx.x * NB, N = A.N;
-    s_a[f] = load_rows(A.S, 128, n0, N, f);
+    __shared__ Smem sm;
+    int flip = 0, rflip = 0;
+    const int t = threadIdx.x, f = t & 127, ks = t >> 7, n0 = blockIdx.x * NB, N = A.N;
+    if (ks == 0) sm.a[f] = load_rows(A.S, 128, n0, N, f);
     __syncthreads();
     float4 ms = f4(0.f);
     if (n0 + 0 < N) ms.x = A.msum[n0 + 0];
@@ -198,60 +243,61 @@ k_node_update(NodeArgs A, UpdW W, int last_mode, float *chi, int step, int sde, 
     if (n0 + 2 < N) ms.z = A.msum[n0 + 2];
     if (n0 + 3 < N) ms.w = A.msum[n0 + 3];
     // mean_j mask_j (W_out y_j + b) = W_out mean_j(mask_j y_j) + b mean_j(mask_j)
-    float bo = W.out_b[f];
-    float4 m = dense4<128>(W.outT, 128, f, s_a, make_float4(bo * ms.x, bo * ms.y, bo * ms.z, bo * ms.w));
+    float4 m = meet(sm, flip, dense_slice<128>(W.outT, 128, f, sm.a, ks), 128, f, ks);
+    m = add4(m, scale4(ms, W.out_b[f]));
     float4 h0 = load_rows(A.hV, 128, n0, N, f);
-    float4 h1 = layernorm4(add4(h0, m), W.g0[f], W.b0[f], s_red);
-    s_h[f] = h1;
+    float4 h1 = layernorm4(sm, rflip, add4(h0, m), W.g0[f], W.b0[f]);
+    if (ks == 0) sm.h[f] = h1;
     __syncthreads();
+    // FFN 128 -> 512: each thread builds the ks-th K-quarter of 4 hidden units, then owns hidden unit t
+    {
+        float4 *buf = sm.part[flip];
+        flip ^= 1;
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        float4 hd = dense4<128>(W.ffn_inT, 512, f + 128 * j, s_h, f4(W.ffn_in_b[f + 128 * j]));
-        s_a[f + 128 * j] = make_float4(fmaxf(hd.x, 0.f), fmaxf(hd.y, 0.f), fmaxf(hd.z, 0.f), fmaxf(hd.w, 0.f));
+        for (int j = 0; j < 4; j++) buf[ks * 512 + f + 128 * j] = dense_slice<128>(W.ffn_inT, 512, f + 128 * j, sm.h, ks);
+        __syncthreads();
+        float4 hd = add4(add4(buf[t], buf[512 + t]), add4(buf[1024 + t], buf[1536 + t]));
+        sm.a[t] = relu4(add4(hd, f4(W.ffn_in_b[t])));
+        __syncthreads();
+    }
+    float4 o = meet(sm, flip, dense_slice<512>(W.ffn_outT, 128, f, sm.a, ks), 128, f, ks);
+    o = add4(o, f4(W.ffn_out_b[f]));
+    float4 h2 = layernorm4(sm, rflip, add4(h1, o), W.g1[f], W.b1[f]);
+    h2 = mul4(h2, load_rows(A.rmask, 1, n0, N, 0));
+    if (ks == 0) {
+        store_rows(A.hV, 128, n0, N, f, h2);
+        sm.h[f] = h2;
     }
     __syncthreads();
-    float4 o = dense4<512>(W.ffn_outT, 128, f, s_a, f4(W.ffn_out_b[f]));
-    float4 h2 = layernorm4(add4(h1, o), W.g1[f], W.b1[f], s_red);
-    h2 = mul4(h2, load_rows(A.rmask, 1, n0, N, 0));
-    store_rows(A.hV, 128, n0, N, f, h2);
-    __syncthreads();
-    s_h[f] = h2;
-    __syncthreads();
     if (last_mode == PP_NU_MID) {
-        message_inputs(W.pre_edge, s_h, s_p, A.frames, n0, N, A.ptsE, A.PAe, A.PCe);
-        message_inputs(W.pre_next, s_h, s_p, A.frames, n0, N, A.ptsN, A.PAn, A.PCn);
+        message_inputs(sm, flip, W.pre_edge, A.frames, n0, N, A.ptsE, A.PAe, A.PCe);
+        message_inputs(sm, flip, W.pre_next, A.frames, n0, N, A.ptsN, A.PAn, A.PCn);
         return;
     }
     // decoder: 128 -> 64 -> 32 -> relu -> 16 -> 4
-    if (f < 64) {
-        float4 v = dense4<128>(W.d0_inT, 64, f, s_h, f4(W.d0_in_b[f]));
-        s_a[f] = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
-    }
+    float4 v = relu4(dense_small<128>(sm, flip, W.d0_inT, 64, sm.h, W.d0_in_b));
+    if (ks == 0 && f < 64) sm.a[f] = v;
     __syncthreads();
-    if (f < 32) {
-        float4 v = dense4<64>(W.d0_outT, 32, f, s_a, f4(W.d0_out_b[f]));
-        s_a[64 + f] = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
-    }
+    v = relu4(dense_small<64>(sm, flip, W.d0_outT, 32, sm.a, W.d0_out_b));
+    if (ks == 0 && f < 32) sm.a[64 + f] = v;
     __syncthreads();
-    if (f < 16) {
-        float4 v = dense4<32>(W.d2_inT, 16, f, s_a + 64, f4(W.d2_in_b[f]));
-        s_a[96 + f] = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
-    }
+    v = relu4(dense_small<32>(sm, flip, W.d2_inT, 16, sm.a + 64, W.d2_in_b));
+    if (ks == 0 && f < 16) sm.a[96 + f] = v;
     __syncthreads();
-    if (f < 4) {
-        float4 v = dense4<16>(W.d2_outT, 4, f, s_a + 96, f4(W.d2_out_b[f]));
-        s_a[112 + f] = v;
+    v = dense_small<16>(sm, flip, W.d2_outT, 4, sm.a + 96, W.d2_out_b);
+    if (ks == 0 && f < 4) {
+        sm.a[112 + f] = v;
         store_rows(A.score, 4, n0, N, f, v);
     }
     __syncthreads();
     if (last_mode != PP_NU_STEP) return;
     // reverse step on (node i, chi k) = 16 threads
-    if (f < 16) {
-        int i = f >> 2, k = f & 3, n = n0 + i;
+    if (t < 16) {
+        int i = t >> 2, k = t & 3, n = n0 + i;
         if (n < N) {
             const StepParams sp = A.steps[step];
             float x = chi[(size_t)n * 4 + k];
-            float sw = comp(s_a[112 + k], i) * sp.w;
+            float sw = comp(sm.a[112 + k], i) * sp.w;
             bool m1 = A.m1pi[(size_t)n * 4 + k] != 0, m2 = A.m2pi[(size_t)n * 4 + k] != 0;
             float y = x;
             if (!sde) {
@@ -268,14 +314,14 @@ k_node_update(NodeArgs A, UpdW W, int last_mode, float *chi, int step, int sde, 
     }
     __syncthreads();
     if (!embed_next) return;
-    __threadfence_block();
-    float4 v = embed_pre(A, chi, step + 1, n0, s_p);
-    float4 h = layernorm4(v, A.emb_g[f], A.emb_beta[f], s_red);
-    store_rows(A.hV, 128, n0, N, f, h);
+    float4 e = embed_pre(sm, A, chi, step + 1, n0);
+    float4 h = layernorm4(sm, rflip, e, A.emb_g[f], A.emb_beta[f]);
+    if (ks == 0) {
+        store_rows(A.hV, 128, n0, N, f, h);
+        sm.h[f] = h;
+    }
     __syncthreads();
-    s_h[f] = h;
-    __syncthreads();
-    message_inputs(pre0, s_h, s_p, A.frames, n0, N, A.ptsN, A.PAn, A.PCn);
+    message_inputs(sm, flip, pre0, A.frames, n0, N, A.ptsN, A.PAn, A.PCn);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -340,9 +386,10 @@ pp_status pp_launch_node_update(pp_ctx *c, int layer, int last_mode, float *chi,
     W.d2_inT = p->d2_in_T; W.d2_in_b = p->w + p->off.d2_in_b;
     W.d2_outT = p->d2_out_T; W.d2_out_b = p->w + p->off.d2_out_b;
     PreW pre0 = make_pre(p, 0, false);
+    // step >= 0: re-embed for step + 1 afterwards; step < 0 encodes "last step (-step-1), no re-embed"
     int embed_next = (last_mode == PP_NU_STEP && step >= 0) ? 1 : 0;
     int st = step;
-    if (last_mode == PP_NU_STEP && step < 0) { st = -step - 1; embed_next = 0; }   // negative: last step, no re-embed
+    if (last_mode == PP_NU_STEP && step < 0) { st = -step - 1; embed_next = 0; }
     hipLaunchKernelGGL(k_node_update, dim3((c->N + NB - 1) / NB), dim3(NT), 0, s, A, W, last_mode, chi, st,
                        mode == PP_MODE_SDE ? 1 : 0, noise, embed_next, pre0);
     PP_HIP_CHECK(hipGetLastError());
