@@ -31,15 +31,26 @@ def _cfg(obj, defaults):
     return SimpleNamespace(**out)
 
 
-class _Stub:
+class _Stub(dict):
+    """Inert stand-in for any class the unpickler cannot import (OmegaConf nodes, Lightning callbacks, ...)."""
+
     def __init__(self, *a, **k):
-        pass
+        dict.__init__(self)
 
     def __setstate__(self, state):
         pass
 
     def __call__(self, *a, **k):
         return _Stub()
+
+    def append(self, x):
+        pass
+
+    def extend(self, xs):
+        pass
+
+    def add(self, x):
+        pass
 
 
 class _TolerantUnpickler(pickle.Unpickler):

@@ -1,0 +1,76 @@
+"""Sharding independent complexes over the GPUs of a node.
+
+The sampling path has no cross-complex term (``network`` is per batch row; ``proximal_optimizer`` asserts B == 1),
+so complexes are dealt to ranks, every rank runs the whole path on its own shard, and the ONLY collective is an
+all-gather of fixed-width per-complex metric rows (RCCL over xGMI when the process group backend is "nccl";
+KB-sized, latency bound).  One process per GPU, launched by ``torchrun``.
+"""
+from typing import Dict, List, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+METRIC_KEYS = tuple(f"chi_{i}_{s}" for i in range(4) for s in ("ae_rad", "ae_deg", "acc")) + ("atom_rmsd",)
+
+
+def shard_complexes(lengths: Sequence[int], world_size: int) -> List[List[int]]:
+    """Longest-processing-time-first assignment of complex indices to ranks (cost ~ residues)."""
+    order = sorted(range(len(lengths)), key=lambda i: (-int(lengths[i]), i))
+    load = [0] * world_size
+    out: List[List[int]] = [[] for _ in range(world_size)]
+    for i in order:
+        r = min(range(world_size), key=lambda k: (load[k], k))
+        out[r].append(i)
+        load[r] += int(lengths[i])
+    return [sorted(s) for s in out]
+
+
+def metrics_to_row(metric: Dict[str, torch.Tensor]) -> torch.Tensor:
+    return torch.stack([torch.as_tensor(metric[k], dtype=torch.float32).reshape(()) for k in METRIC_KEYS])
+
+
+def gather_metric_rows(ids: torch.Tensor, rows: torch.Tensor, group=None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """All-gather ragged (ids [n_r], rows [n_r, W]) from every rank; returns them sorted by complex id.
+
+    Counts are exchanged first so each rank pads its block to the maximum; works for gloo (CPU tensors) and
+    nccl/RCCL (device tensors) alike."""
+    if not dist.is_available() or not dist.is_initialized():
+        order = torch.argsort(ids)
+        return ids[order], rows[order]
+    world = dist.get_world_size(group)
+    dev = rows.device
+    n = torch.tensor([ids.numel()], device=dev, dtype=torch.int64)
+    counts = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(counts, n, group=group)
+    counts = [int(c.item()) for c in counts]
+    cap = max(max(counts), 1)
+    W = rows.shape[1] if rows.dim() == 2 else len(METRIC_KEYS)
+    block = torch.zeros(cap, W + 1, device=dev, dtype=torch.float32)
+    if ids.numel():
+        block[: ids.numel(), 0] = ids.to(torch.float32)
+        block[: ids.numel(), 1:] = rows.to(torch.float32)
+    blocks = [torch.empty_like(block) for _ in range(world)]
+    dist.all_gather(blocks, block, group=group)
+    all_rows = torch.cat([b[:c] for b, c in zip(blocks, counts)], 0)
+    order = torch.argsort(all_rows[:, 0])
+    all_rows = all_rows[order]
+    return all_rows[:, 0].to(torch.int64), all_rows[:, 1:]
+
+
+def sample_sharded(model, complexes, use_proximal=False, group=None):
+    """Run ``model.sampling`` + ``analyze_samples`` on this rank's share of ``complexes`` (list of B=1 batches
+    already on the rank's device) and gather every complex's metric row on every rank.
+    Returns (chi per local complex id, ids_all, rows_all)."""
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    mine = shard_complexes([int(c["max_size"]) for c in complexes], world)[rank]
+    chis, rows = {}, []
+    for i in mine:
+        chi = model.sampling(complexes[i], use_proximal=use_proximal)
+        chis[i] = chi
+        rows.append(metrics_to_row(model.analyze_samples(complexes[i], chi)))
+    dev = model.device
+    ids = torch.tensor(mine, device=dev, dtype=torch.int64)
+    rows_t = torch.stack(rows).to(dev) if rows else torch.zeros(0, len(METRIC_KEYS), device=dev)
+    ids_all, rows_all = gather_metric_rows(ids, rows_t, group)
+    return chis, ids_all, rows_all
