@@ -1,27 +1,32 @@
 // Edge-level stages of InvariantPointMessagePassing (layers.py:65-148) as fused FP32-MFMA kernels.
 //
-// One wave64 owns one residue i and its K<=32 edges (i, j); a workgroup is 4 waves (4 residues).
-// All per-edge activations stay in registers for the whole MLP chain, in the accumulator layout of
-// v_mfma_f32_32x32x2_f32 computing  Y^T[feature][edge] = W[feature][k] * X^T[k][edge]:
-//
+// A workgroup of 4 waves owns ONE residue i and its K<=32 edges (i, j).  Every activation tensor of the
+// chain lives in the accumulator layout of v_mfma_f32_32x32x2_f32 for the transposed product
+//      Y^T[feature][edge] = W[feature][k] * X^T[k][edge]:
 //      lane l = (edge j = l & 31, half h = l >> 5),  register r of tile t  <->  feature
 //      F(t, r, h) = 32 t + 8 (r >> 2) + 4 h + (r & 3).
+// With that k-ordering the D registers of one layer ARE the B operands of the next, and the A operand of
+// 4 consecutive k-steps is one float4 of a row of the nn.Linear weight in its native [out][in] layout.
 //
-// With that k-ordering the D registers of one layer ARE the B operands of the next layer (no LDS
-// round trip, no shuffles), and the A operand of 4 consecutive k-steps is one float4 of a row of the
-// nn.Linear weight in its native [out][in] layout.  Weights stream L2 -> registers -> LDS in
-// [128 rows][32 (or 72) cols] chunks, double buffered, shared by the 4 waves of the workgroup.
+// N-split: wave w computes output tile w (32 of the 128 features; for the 512-wide FFN hidden layer,
+// tile 4c + w of hidden block c).  A finished tile is published to a 16 KB LDS exchange buffer
+// (same [tile][quad][lane] float4 layout it has in registers) and every wave reads back the full
+// 128-vector it needs as B operands.  Weights stream L2 -> registers -> LDS in [128 rows][32 | 24 cols]
+// chunks, double buffered; each wave reads its own 32 rows of the shared chunk.  53 KB of LDS and <=168
+// VGPRs per workgroup let up to 3 workgroups share a CU, so one workgroup's barrier / LDS latency is covered
+// by another's MFMAs, and 739 residues x 4 waves spread evenly over the 1024 SIMDs.
 //
 // The 456-wide first layer is never materialised: W_in [h_V_i | h_E_ij | h_V_j | geom] =
 // (W_A h_V_i + b) + W_C h_V_j  (node-level, precomputed per residue in pp_node.hip, gathered here)
-// + W_B h_E_ij + W_G geom_ij (MFMA here).
+// + W_B h_E_ij + W_G geom_ij (MFMA here; the 72 invariant-point features are built in registers).
 #include "pp_internal.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 #define ET 256
-#define LDS_BUF_FLOATS (128 * 76)
+#define WBUF_FLOATS (128 * 36)          // one weight chunk slot, row stride 36 (32 cols) or 28 (24 cols)
+#define XBUF_FLOATS (4 * 4 * 64 * 4)    // exchange buffer: [tile][quad][lane] float4
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
@@ -38,7 +43,7 @@ struct EdgeArgs {
     float *hE_out;             // [N][K][128]   (edge kernel)
     float *S, *msum;           // node kernel outputs
     // weights, native layouts
-    const float *w_in, *b_mid_dummy;
+    const float *w_in;
     const float *w_mid, *b_mid, *w_out, *b_out;
     const float *g2, *be2, *g3, *be3;
     const float *ffn_in, *ffn_in_b, *ffn_out, *ffn_out_b;
@@ -46,100 +51,107 @@ struct EdgeArgs {
 
 template <int NC>
 struct ChunkRegs {
-    f32x4v v[(128 * NC / 4) / ET];
+    f32x4v v[(128 * NC / 4 + ET - 1) / ET];
 };
 
+// [128 rows][NC cols] of a row-major matrix (row stride ld) -> registers -> LDS (row stride NC + 4)
 template <int NC>
 __device__ __forceinline__ void chunk_load(const float *__restrict__ g, int ld, ChunkRegs<NC> &r, int tid) {
-    constexpr int PER_ROW = NC / 4, PER_T = (128 * PER_ROW) / ET;
+    constexpr int PER_ROW = NC / 4, TOTAL = 128 * PER_ROW, PER_T = (TOTAL + ET - 1) / ET;
 #pragma unroll
     for (int m = 0; m < PER_T; m++) {
         int idx = tid + ET * m;
-        int row = idx / PER_ROW, c4 = idx - row * PER_ROW;
-        r.v[m] = *reinterpret_cast<const f32x4v *>(g + (size_t)row * ld + 4 * c4);
+        if (TOTAL % ET == 0 || idx < TOTAL) {
+            int row = idx / PER_ROW, c4 = idx - row * PER_ROW;
+            r.v[m] = *reinterpret_cast<const f32x4v *>(g + (size_t)row * ld + 4 * c4);
+        }
     }
 }
 template <int NC>
 __device__ __forceinline__ void chunk_store(float *lds, const ChunkRegs<NC> &r, int tid) {
-    constexpr int PER_ROW = NC / 4, PER_T = (128 * PER_ROW) / ET;
+    constexpr int PER_ROW = NC / 4, TOTAL = 128 * PER_ROW, PER_T = (TOTAL + ET - 1) / ET;
 #pragma unroll
     for (int m = 0; m < PER_T; m++) {
         int idx = tid + ET * m;
-        int row = idx / PER_ROW, c4 = idx - row * PER_ROW;
-        *reinterpret_cast<f32x4v *>(lds + row * (NC + 4) + 4 * c4) = r.v[m];
+        if (TOTAL % ET == 0 || idx < TOTAL) {
+            int row = idx / PER_ROW, c4 = idx - row * PER_ROW;
+            *reinterpret_cast<f32x4v *>(lds + row * (NC + 4) + 4 * c4) = r.v[m];
+        }
     }
 }
 
-// acc[t] += W[32t.., chunk cols] * x   (SWAP: acc[t] += x * W^T, edges on rows / features on lanes)
+// acc += W[32 wave .. +32, chunk cols] * x     (SWAP: acc += x * W^T, edges on rows / features on lanes)
 template <bool SWAP>
-__device__ __forceinline__ void mfma_chunk32(const float *lds, const f32x16 &x, f32x16 (&acc)[4], int lane) {
-    const float *base = lds + (lane & 31) * 36 + 4 * (lane >> 5);
+__device__ __forceinline__ void mfma_tile32(const float *lds, int wave, const f32x16 &x, f32x16 &acc, int lane) {
+    const float *base = lds + (32 * wave + (lane & 31)) * 36 + 4 * (lane >> 5);
 #pragma unroll
-    for (int t = 0; t < 4; t++) {
+    for (int q = 0; q < 4; q++) {
+        f32x4v a = *reinterpret_cast<const f32x4v *>(base + 8 * q);
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            f32x4v a = *reinterpret_cast<const f32x4v *>(base + 32 * 36 * t + 8 * q);
-#pragma unroll
-            for (int p = 0; p < 4; p++) {
-                if (SWAP) acc[t] = MFMA(x[4 * q + p], a[p], acc[t]);
-                else acc[t] = MFMA(a[p], x[4 * q + p], acc[t]);
-            }
+        for (int p = 0; p < 4; p++) {
+            if (SWAP) acc = MFMA(x[4 * q + p], a[p], acc);
+            else acc = MFMA(a[p], x[4 * q + p], acc);
         }
     }
 }
 
-// geometry block: 72 inputs = 36 k-steps; lane half h supplies input 36 h + m at step m
-__device__ __forceinline__ void mfma_chunk72(const float *lds, const float (&g)[36], f32x16 (&acc)[4], int lane) {
-    const float *base = lds + (lane & 31) * 76 + 36 * (lane >> 5);
+// geometry chunk: 24 inputs = 12 k-steps; lane half h supplies input 12 h + m at step m
+__device__ __forceinline__ void mfma_tile24(const float *lds, int wave, const float (&g)[12], f32x16 &acc, int lane) {
+    const float *base = lds + (32 * wave + (lane & 31)) * 28 + 12 * (lane >> 5);
 #pragma unroll
-    for (int t = 0; t < 4; t++) {
+    for (int q = 0; q < 3; q++) {
+        f32x4v a = *reinterpret_cast<const f32x4v *>(base + 4 * q);
 #pragma unroll
-        for (int q = 0; q < 9; q++) {
-            f32x4v a = *reinterpret_cast<const f32x4v *>(base + 32 * 76 * t + 4 * q);
-#pragma unroll
-            for (int p = 0; p < 4; p++) acc[t] = MFMA(a[p], g[4 * q + p], acc[t]);
-        }
+        for (int p = 0; p < 4; p++) acc = MFMA(a[p], g[4 * q + p], acc);
     }
 }
 
-// row-major [128] vector <-> accumulator layout
-__device__ __forceinline__ void load_dl(const float *__restrict__ row, int h, f32x16 (&d)[4]) {
+// one tile (16 registers) <-> 32 consecutive features of a row-major vector
+__device__ __forceinline__ void load_tile(const float *__restrict__ row32, int h, f32x16 &d) {
 #pragma unroll
-    for (int t = 0; t < 4; t++)
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            f32x4v a = *reinterpret_cast<const f32x4v *>(row + 32 * t + 8 * q + 4 * h);
-            d[t][4 * q] = a[0]; d[t][4 * q + 1] = a[1]; d[t][4 * q + 2] = a[2]; d[t][4 * q + 3] = a[3];
-        }
+    for (int q = 0; q < 4; q++) {
+        f32x4v a = *reinterpret_cast<const f32x4v *>(row32 + 8 * q + 4 * h);
+        d[4 * q] = a[0]; d[4 * q + 1] = a[1]; d[4 * q + 2] = a[2]; d[4 * q + 3] = a[3];
+    }
 }
-__device__ __forceinline__ void add_dl(const float *__restrict__ row, int h, f32x16 (&d)[4]) {
+__device__ __forceinline__ void add_tile(const float *__restrict__ row32, int h, f32x16 &d) {
 #pragma unroll
-    for (int t = 0; t < 4; t++)
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            f32x4v a = *reinterpret_cast<const f32x4v *>(row + 32 * t + 8 * q + 4 * h);
-            d[t][4 * q] += a[0]; d[t][4 * q + 1] += a[1]; d[t][4 * q + 2] += a[2]; d[t][4 * q + 3] += a[3];
-        }
+    for (int q = 0; q < 4; q++) {
+        f32x4v a = *reinterpret_cast<const f32x4v *>(row32 + 8 * q + 4 * h);
+        d[4 * q] += a[0]; d[4 * q + 1] += a[1]; d[4 * q + 2] += a[2]; d[4 * q + 3] += a[3];
+    }
 }
-__device__ __forceinline__ void store_dl(float *__restrict__ row, int h, const f32x16 (&d)[4]) {
+__device__ __forceinline__ void store_tile(float *__restrict__ row32, int h, const f32x16 &d) {
 #pragma unroll
-    for (int t = 0; t < 4; t++)
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            f32x4v a = {d[t][4 * q], d[t][4 * q + 1], d[t][4 * q + 2], d[t][4 * q + 3]};
-            *reinterpret_cast<f32x4v *>(row + 32 * t + 8 * q + 4 * h) = a;
-        }
+    for (int q = 0; q < 4; q++) {
+        f32x4v a = {d[4 * q], d[4 * q + 1], d[4 * q + 2], d[4 * q + 3]};
+        *reinterpret_cast<f32x4v *>(row32 + 8 * q + 4 * h) = a;
+    }
 }
-__device__ __forceinline__ void relu_dl(f32x16 (&d)[4]) {
+__device__ __forceinline__ void relu_tile(f32x16 &d) {
 #pragma unroll
-    for (int t = 0; t < 4; t++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) d[t][r] = fmaxf(d[t][r], 0.f);
+    for (int r = 0; r < 16; r++) d[r] = fmaxf(d[r], 0.f);
 }
 
-// LayerNorm over the 128 features of this lane's edge (64 here, 64 in lane ^ 32), eps 1e-5.
-__device__ __forceinline__ void layernorm_dl(f32x16 (&v)[4], const float *__restrict__ gamma,
-                                             const float *__restrict__ beta, int h) {
+// exchange buffer: tile t, quad q, lane l -> float4
+__device__ __forceinline__ void xbuf_put(float *xbuf, int t, int lane, const f32x16 &d) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        f32x4v a = {d[4 * q], d[4 * q + 1], d[4 * q + 2], d[4 * q + 3]};
+        *reinterpret_cast<f32x4v *>(xbuf + ((t * 4 + q) * 64 + lane) * 4) = a;
+    }
+}
+__device__ __forceinline__ void xbuf_get(const float *xbuf, int t, int lane, f32x16 &d) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        f32x4v a = *reinterpret_cast<const f32x4v *>(xbuf + ((t * 4 + q) * 64 + lane) * 4);
+        d[4 * q] = a[0]; d[4 * q + 1] = a[1]; d[4 * q + 2] = a[2]; d[4 * q + 3] = a[3];
+    }
+}
+
+// LayerNorm statistics over the 128 features of this lane's edge (64 here, 64 in lane ^ 32); v is centred in
+// place; returns 1/std, writes the mean
+__device__ __forceinline__ float ln_center(f32x16 (&v)[4], float &mean_out) {
     float s = 0.f;
 #pragma unroll
     for (int t = 0; t < 4; t++)
@@ -147,6 +159,7 @@ __device__ __forceinline__ void layernorm_dl(f32x16 (&v)[4], const float *__rest
         for (int r = 0; r < 16; r++) s += v[t][r];
     s += __shfl_xor(s, 32);
     const float mean = s * (1.f / 128.f);
+    mean_out = mean;
     float q = 0.f;
 #pragma unroll
     for (int t = 0; t < 4; t++)
@@ -157,21 +170,23 @@ __device__ __forceinline__ void layernorm_dl(f32x16 (&v)[4], const float *__rest
             q = fmaf(d, d, q);
         }
     q += __shfl_xor(q, 32);
-    const float rstd = 1.f / sqrtf(q * (1.f / 128.f) + 1e-5f);
+    return 1.f / sqrtf(q * (1.f / 128.f) + 1e-5f);
+}
+// centred tile -> tile * rstd * gamma + beta
+__device__ __forceinline__ void ln_affine_tile(f32x16 &v, float rstd, const float *__restrict__ gamma32,
+                                               const float *__restrict__ beta32, int h) {
 #pragma unroll
-    for (int t = 0; t < 4; t++)
+    for (int q = 0; q < 4; q++) {
+        f32x4v g = *reinterpret_cast<const f32x4v *>(gamma32 + 8 * q + 4 * h);
+        f32x4v b = *reinterpret_cast<const f32x4v *>(beta32 + 8 * q + 4 * h);
 #pragma unroll
-        for (int qq = 0; qq < 4; qq++) {
-            f32x4v g = *reinterpret_cast<const f32x4v *>(gamma + 32 * t + 8 * qq + 4 * h);
-            f32x4v b = *reinterpret_cast<const f32x4v *>(beta + 32 * t + 8 * qq + 4 * h);
-#pragma unroll
-            for (int p = 0; p < 4; p++) v[t][4 * qq + p] = fmaf(v[t][4 * qq + p] * rstd, g[p], b[p]);
-        }
+        for (int p = 0; p < 4; p++) v[4 * q + p] = fmaf(v[4 * q + p] * rstd, g[p], b[p]);
+    }
 }
 
-// 72 invariant point features of edge (i, j); returns the 36 this lane half feeds to the MFMA.
+// 72 invariant point features of edge (i, j); g[c][m] = feature 24 c + 12 h + m (what this lane half feeds the MFMA)
 __device__ __forceinline__ void edge_geometry(const float *__restrict__ pts_i, const float *__restrict__ fr,
-                                              const float *__restrict__ pts_j, int h, float (&g)[36]) {
+                                              const float *__restrict__ pts_j, int h, float (&g)[3][12]) {
     float geom[72];
     float R[9], tr[3];
 #pragma unroll
@@ -195,73 +210,96 @@ __device__ __forceinline__ void edge_geometry(const float *__restrict__ pts_i, c
         geom[64 + q] = sqrtf(ex * ex + ey * ey + ez * ez + 1e-8f);
     }
 #pragma unroll
-    for (int m = 0; m < 36; m++) g[m] = h ? geom[36 + m] : geom[m];
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int m = 0; m < 12; m++) g[c][m] = h ? geom[24 * c + 12 + m] : geom[24 * c + m];
 }
 
-// One pipeline stage: prefetch the next weight chunk into registers, compute on the current LDS
-// buffer, then publish the prefetched chunk into the other buffer.
+// One pipeline stage: prefetch the next weight chunk into registers, compute on the current LDS slot,
+// publish the prefetched chunk into the other slot, barrier.
 #define STAGE(COMPUTE, NEXT_NC, NEXT_PTR, NEXT_LD)                         \
     {                                                                      \
         ChunkRegs<NEXT_NC> _r;                                             \
         chunk_load<NEXT_NC>((NEXT_PTR), (NEXT_LD), _r, tid);               \
-        if (active) { COMPUTE; }                                           \
-        chunk_store<NEXT_NC>(cur ? buf0 : buf1, _r, tid);                  \
+        { COMPUTE; }                                                       \
+        chunk_store<NEXT_NC>(cur ? wbuf0 : wbuf1, _r, tid);                \
         __syncthreads();                                                   \
         cur ^= 1;                                                          \
     }
-#define CURBUF (cur ? buf1 : buf0)
+#define CURBUF (cur ? wbuf1 : wbuf0)
+
+// shared first layer: acc (tile `wave`) = PA_i + PC_j + W_B h_E + W_G geom, ReLU, published to xbuf;
+// leaves the next layer's first chunk (NEXT_*) staged
+#define FIRST_LAYER(NEXT_PTR, NEXT_LD)                                                                  \
+    {                                                                                                   \
+        ChunkRegs<32> r0;                                                                               \
+        chunk_load<32>(wB, PP_MSG_IN, r0, tid);                                                         \
+        chunk_store<32>(wbuf0, r0, tid);                                                                \
+        __syncthreads();                                                                                \
+    }                                                                                                   \
+    STAGE(mfma_tile32<false>(CURBUF, wave, x[0], acc, lane), 32, wB + 32, PP_MSG_IN)                    \
+    STAGE(mfma_tile32<false>(CURBUF, wave, x[1], acc, lane), 32, wB + 64, PP_MSG_IN)                    \
+    STAGE(mfma_tile32<false>(CURBUF, wave, x[2], acc, lane), 32, wB + 96, PP_MSG_IN)                    \
+    STAGE(mfma_tile32<false>(CURBUF, wave, x[3], acc, lane), 24, wG, PP_MSG_IN)                         \
+    /* x[] is dead from here to the exchange: build the 72 point features in its place */              \
+    edge_geometry(A.pts + (size_t)n * 48, A.frames + (size_t)n * 12, A.pts + (size_t)nbr * 48, h, g);   \
+    STAGE(mfma_tile24(CURBUF, wave, g[0], acc, lane), 24, wG + 24, PP_MSG_IN)                           \
+    STAGE(mfma_tile24(CURBUF, wave, g[1], acc, lane), 24, wG + 48, PP_MSG_IN)                           \
+    {                                                                                                   \
+        ChunkRegs<32> _r;                                                                               \
+        chunk_load<32>((NEXT_PTR), (NEXT_LD), _r, tid);                                                 \
+        mfma_tile24(CURBUF, wave, g[2], acc, lane);                                                     \
+        relu_tile(acc);                                                                                 \
+        xbuf_put(xbuf, wave, lane, acc);                                                                \
+        chunk_store<32>(cur ? wbuf0 : wbuf1, _r, tid);                                                  \
+        __syncthreads();                                                                                \
+        cur ^= 1;                                                                                       \
+    }
 
 // ---------------------------------------------------------------------------------------------
 // node message: S[i] = (1/K) sum_j mask_ij relu(W_mid relu(W_in [..]) + b), msum[i] = (1/K) sum_j mask_ij
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(ET, 1)
+__global__ void __launch_bounds__(ET, 3)
 k_node_message(EdgeArgs A) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *buf0 = smem, *buf1 = smem + LDS_BUF_FLOATS;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float *wbuf0 = smem, *wbuf1 = smem + WBUF_FLOATS, *xbuf = smem + 2 * WBUF_FLOATS;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, h = lane >> 5;
-    const int n = blockIdx.x * 4 + wave;
-    const bool active = (n < A.N) && (A.rmask[n < A.N ? n : 0] != 0.f);
+    const int n = blockIdx.x;
     const int K = A.K;
     int cur = 0;
+    if (A.rmask[n] == 0.f) {              // masked / padded residue: whole workgroup leaves
+        if (tid < 128) A.S[(size_t)n * 128 + tid] = 0.f;
+        if (tid == 0) A.msum[n] = 0.f;
+        return;
+    }
 
-    f32x16 x[4], acc[4];
-    float g[36];
-    if (active) {
-        const int jj = j < K ? j : K - 1;
-        const int nbr = A.eidx[(size_t)n * K + jj];
-        load_dl(A.hE_in + ((size_t)n * K + jj) * 128, h, x);
-        load_dl(A.PA + (size_t)n * 128, h, acc);
-        add_dl(A.PC + (size_t)nbr * 128, h, acc);
-        edge_geometry(A.pts + (size_t)n * 48, A.frames + (size_t)n * 12, A.pts + (size_t)nbr * 48, h, g);
+    f32x16 x[4], acc;
+    float g[3][12];
+    const int jj = j < K ? j : K - 1;
+    const int nbr = A.eidx[(size_t)n * K + jj];
+    {
+        const float *hrow = A.hE_in + ((size_t)n * K + jj) * 128;
+#pragma unroll
+        for (int t = 0; t < 4; t++) load_tile(hrow + 32 * t, h, x[t]);
+        load_tile(A.PA + (size_t)n * 128 + 32 * wave, h, acc);
+        add_tile(A.PC + (size_t)nbr * 128 + 32 * wave, h, acc);
     }
     const float *wB = A.w_in + 128, *wG = A.w_in + 384;
-    {   // prologue: chunk 0 of W_B
-        ChunkRegs<32> r0;
-        chunk_load<32>(wB, PP_MSG_IN, r0, tid);
-        chunk_store<32>(buf0, r0, tid);
-        __syncthreads();
-    }
-    STAGE(mfma_chunk32<false>(CURBUF, x[0], acc, lane), 32, wB + 32, PP_MSG_IN)
-    STAGE(mfma_chunk32<false>(CURBUF, x[1], acc, lane), 32, wB + 64, PP_MSG_IN)
-    STAGE(mfma_chunk32<false>(CURBUF, x[2], acc, lane), 32, wB + 96, PP_MSG_IN)
-    STAGE(mfma_chunk32<false>(CURBUF, x[3], acc, lane), 72, wG, PP_MSG_IN)
-    STAGE(mfma_chunk72(CURBUF, g, acc, lane), 32, A.w_mid, 128)
-    if (active) {
-        relu_dl(acc);
+    FIRST_LAYER(A.w_mid, 128)
+    {
 #pragma unroll
-        for (int t = 0; t < 4; t++) {
-            x[t] = acc[t];
-            const float b = A.b_mid[32 * t + j];          // SWAP form: feature on the lane
+        for (int t = 0; t < 4; t++) xbuf_get(xbuf, t, lane, x[t]);
+        const float b = A.b_mid[32 * wave + j];           // SWAP form: feature on the lane
 #pragma unroll
-            for (int r = 0; r < 16; r++) acc[t][r] = b;
-        }
+        for (int r = 0; r < 16; r++) acc[r] = b;
     }
-    STAGE(mfma_chunk32<true>(CURBUF, x[0], acc, lane), 32, A.w_mid + 32, 128)
-    STAGE(mfma_chunk32<true>(CURBUF, x[1], acc, lane), 32, A.w_mid + 64, 128)
-    STAGE(mfma_chunk32<true>(CURBUF, x[2], acc, lane), 32, A.w_mid + 96, 128)
-    if (active) {
-        mfma_chunk32<true>(CURBUF, x[3], acc, lane);
+    STAGE(mfma_tile32<true>(CURBUF, wave, x[0], acc, lane), 32, A.w_mid + 32, 128)
+    STAGE(mfma_tile32<true>(CURBUF, wave, x[1], acc, lane), 32, A.w_mid + 64, 128)
+    STAGE(mfma_tile32<true>(CURBUF, wave, x[2], acc, lane), 32, A.w_mid + 96, 128)
+    {
+        mfma_tile32<true>(CURBUF, wave, x[3], acc, lane);
         // rows (registers) are edges e = 8 (r>>2) + 4 h + (r&3); mask and reduce over them
         float m16[16];
         const float *mrow = A.mask_att + (size_t)n * 32;
@@ -270,134 +308,144 @@ k_node_message(EdgeArgs A) {
             f32x4v mm = *reinterpret_cast<const f32x4v *>(mrow + 8 * q + 4 * h);
             m16[4 * q] = mm[0]; m16[4 * q + 1] = mm[1]; m16[4 * q + 2] = mm[2]; m16[4 * q + 3] = mm[3];
         }
-        float ms = 0.f;
+        float s = 0.f, ms = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; r++) ms += m16[r];
-        ms += __shfl_xor(ms, 32);
-#pragma unroll
-        for (int t = 0; t < 4; t++) {
-            float s = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; r++) s = fmaf(fmaxf(acc[t][r], 0.f), m16[r], s);
-            s += __shfl_xor(s, 32);
-            if (h == 0) A.S[(size_t)n * 128 + 32 * t + j] = s * A.inv_K;
+        for (int r = 0; r < 16; r++) {
+            s = fmaf(fmaxf(acc[r], 0.f), m16[r], s);
+            ms += m16[r];
         }
-        if (lane == 0) A.msum[n] = ms * A.inv_K;
-    } else if (n < A.N) {
-        for (int f = lane; f < 128; f += 64) A.S[(size_t)n * 128 + f] = 0.f;
-        if (lane == 0) A.msum[n] = 0.f;
+        s += __shfl_xor(s, 32);
+        ms += __shfl_xor(ms, 32);
+        if (h == 0) A.S[(size_t)n * 128 + 32 * wave + j] = s * A.inv_K;
+        if (tid == 0) A.msum[n] = ms * A.inv_K;
     }
 }
 
 // ---------------------------------------------------------------------------------------------
 // edge update: h_E <- mask * LN3(x1 + FFN(x1)),  x1 = LN2(h_E + mask * MLP3([..]))
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(ET, 1)
+__global__ void __launch_bounds__(ET, 3)
 k_edge_update(EdgeArgs A) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *buf0 = smem, *buf1 = smem + LDS_BUF_FLOATS;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float *wbuf0 = smem, *wbuf1 = smem + WBUF_FLOATS, *xbuf = smem + 2 * WBUF_FLOATS;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, h = lane >> 5;
-    const int n = blockIdx.x * 4 + wave;
-    const bool active = (n < A.N) && (A.rmask[n < A.N ? n : 0] != 0.f);
+    const int n = blockIdx.x;
     const int K = A.K;
     const int jj = j < K ? j : K - 1;
     int cur = 0;
+    if (A.rmask[n] == 0.f) {              // masked / padded residue: its edges are zero, whole workgroup leaves
+        if (j < K) {
+            f32x4v z = {0.f, 0.f, 0.f, 0.f};
+            float *orow = A.hE_out + ((size_t)n * K + j) * 128 + 32 * wave;
+#pragma unroll
+            for (int q = 0; q < 4; q++) *reinterpret_cast<f32x4v *>(orow + 8 * q + 4 * h) = z;
+        }
+        return;
+    }
 
-    f32x16 x[4], acc[4], out[4];
-    float g[36];
-    float me = 0.f;
-    const float *hrow = A.hE_in + ((size_t)(n < A.N ? n : 0) * K + jj) * 128;
-    if (active) {
-        const int nbr = A.eidx[(size_t)n * K + jj];
-        me = A.mask_att[(size_t)n * 32 + j];
-        load_dl(hrow, h, x);
-        load_dl(A.PA + (size_t)n * 128, h, acc);
-        add_dl(A.PC + (size_t)nbr * 128, h, acc);
-        edge_geometry(A.pts + (size_t)n * 48, A.frames + (size_t)n * 12, A.pts + (size_t)nbr * 48, h, g);
+    f32x16 x[4], acc, out;
+    float g[3][12];
+    const float *hrow = A.hE_in + ((size_t)n * K + jj) * 128;
+    const int nbr = A.eidx[(size_t)n * K + jj];
+    const float me = A.mask_att[(size_t)n * 32 + j];
+    {
+#pragma unroll
+        for (int t = 0; t < 4; t++) load_tile(hrow + 32 * t, h, x[t]);
+        load_tile(A.PA + (size_t)n * 128 + 32 * wave, h, acc);
+        add_tile(A.PC + (size_t)nbr * 128 + 32 * wave, h, acc);
     }
     const float *wB = A.w_in + 128, *wG = A.w_in + 384;
+    FIRST_LAYER(A.w_mid, 128)
+    // ---- second layer -------------------------------------------------------------------------
     {
-        ChunkRegs<32> r0;
-        chunk_load<32>(wB, PP_MSG_IN, r0, tid);
-        chunk_store<32>(buf0, r0, tid);
+#pragma unroll
+        for (int t = 0; t < 4; t++) xbuf_get(xbuf, t, lane, x[t]);
+        load_tile(A.b_mid + 32 * wave, h, acc);
+    }
+    STAGE(mfma_tile32<false>(CURBUF, wave, x[0], acc, lane), 32, A.w_mid + 32, 128)
+    STAGE(mfma_tile32<false>(CURBUF, wave, x[1], acc, lane), 32, A.w_mid + 64, 128)
+    STAGE(mfma_tile32<false>(CURBUF, wave, x[2], acc, lane), 32, A.w_mid + 96, 128)
+    STAGE(mfma_tile32<false>(CURBUF, wave, x[3], acc, lane); relu_tile(acc); xbuf_put(xbuf, wave, lane, acc), 32,
+          A.w_out, 128)
+    // ---- third layer --------------------------------------------------------------------------
+    {
+#pragma unroll
+        for (int t = 0; t < 4; t++) xbuf_get(xbuf, t, lane, x[t]);
+        load_tile(A.b_out + 32 * wave, h, acc);
+    }
+    STAGE(mfma_tile32<false>(CURBUF, wave, x[0], acc, lane), 32, A.w_out + 32, 128)
+    STAGE(mfma_tile32<false>(CURBUF, wave, x[1], acc, lane), 32, A.w_out + 64, 128)
+    STAGE(mfma_tile32<false>(CURBUF, wave, x[2], acc, lane), 32, A.w_out + 96, 128)
+    // last chunk; then publish v = h_E + mask * m for the first LayerNorm; stage W1 chunk (c=0, s=0)
+    {
+        ChunkRegs<32> _r;
+        chunk_load<32>(A.ffn_in, 128, _r, tid);
+        mfma_tile32<false>(CURBUF, wave, x[3], acc, lane);
+        f32x16 v;
+        load_tile(hrow + 32 * wave, h, v);
+#pragma unroll
+        for (int r = 0; r < 16; r++) v[r] = fmaf(acc[r], me, v[r]);
+        xbuf_put(xbuf, wave, lane, v);
+        chunk_store<32>(cur ? wbuf0 : wbuf1, _r, tid);
         __syncthreads();
+        cur ^= 1;
     }
-    STAGE(mfma_chunk32<false>(CURBUF, x[0], acc, lane), 32, wB + 32, PP_MSG_IN)
-    STAGE(mfma_chunk32<false>(CURBUF, x[1], acc, lane), 32, wB + 64, PP_MSG_IN)
-    STAGE(mfma_chunk32<false>(CURBUF, x[2], acc, lane), 32, wB + 96, PP_MSG_IN)
-    STAGE(mfma_chunk32<false>(CURBUF, x[3], acc, lane), 72, wG, PP_MSG_IN)
-    STAGE(mfma_chunk72(CURBUF, g, acc, lane), 32, A.w_mid, 128)
-    if (active) {
-        relu_dl(acc);
+    f32x16 res;          // this wave's tile of x1 (the FFN residual)
+    {
+        // x1 = LN2(v): every wave normalises the full vector (it needs all of x1 as B operands)
 #pragma unroll
-        for (int t = 0; t < 4; t++) x[t] = acc[t];
-        load_dl(A.b_mid, h, acc);
+        for (int t = 0; t < 4; t++) xbuf_get(xbuf, t, lane, x[t]);
+        xbuf_get(xbuf, wave, lane, res);
+        float mean;
+        const float rstd = ln_center(x, mean);
+#pragma unroll
+        for (int t = 0; t < 4; t++) ln_affine_tile(x[t], rstd, A.g2 + 32 * t, A.be2 + 32 * t, h);
+#pragma unroll
+        for (int r = 0; r < 16; r++) res[r] -= mean;
+        ln_affine_tile(res, rstd, A.g2 + 32 * wave, A.be2 + 32 * wave, h);
+        load_tile(A.ffn_out_b + 32 * wave, h, out);
     }
-    STAGE(mfma_chunk32<false>(CURBUF, x[0], acc, lane), 32, A.w_mid + 32, 128)
-    STAGE(mfma_chunk32<false>(CURBUF, x[1], acc, lane), 32, A.w_mid + 64, 128)
-    STAGE(mfma_chunk32<false>(CURBUF, x[2], acc, lane), 32, A.w_mid + 96, 128)
-    STAGE(mfma_chunk32<false>(CURBUF, x[3], acc, lane), 32, A.w_out, 128)
-    if (active) {
-        relu_dl(acc);
-#pragma unroll
-        for (int t = 0; t < 4; t++) x[t] = acc[t];
-        load_dl(A.b_out, h, acc);
-    }
-    STAGE(mfma_chunk32<false>(CURBUF, x[0], acc, lane), 32, A.w_out + 32, 128)
-    STAGE(mfma_chunk32<false>(CURBUF, x[1], acc, lane), 32, A.w_out + 64, 128)
-    STAGE(mfma_chunk32<false>(CURBUF, x[2], acc, lane), 32, A.w_out + 96, 128)
-    STAGE(mfma_chunk32<false>(CURBUF, x[3], acc, lane), 32, A.ffn_in, 128)
-    if (active) {
-        // x1 = LN2(h_E + mask * m)
-        load_dl(hrow, h, x);
-#pragma unroll
-        for (int t = 0; t < 4; t++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) x[t][r] = fmaf(acc[t][r], me, x[t][r]);
-        layernorm_dl(x, A.g2, A.be2, h);
-        load_dl(A.ffn_out_b, h, out);
-    }
-    // FFN 128 -> 512 -> 128 in four hidden blocks of 128
+    // ---- FFN 128 -> 512 -> 128 in four hidden blocks of 128 -------------------------------------------
 #pragma unroll
     for (int c = 0; c < 4; c++) {
         const float *w1 = A.ffn_in + (size_t)(128 * c) * 128;      // rows 128c.. of [512][128]
         const float *w2 = A.ffn_out + 128 * c;                     // cols 128c.. of [128][512]
-        if (active) load_dl(A.ffn_in_b + 128 * c, h, acc);
-        STAGE(mfma_chunk32<false>(CURBUF, x[0], acc, lane), 32, w1 + 32, 128)
-        STAGE(mfma_chunk32<false>(CURBUF, x[1], acc, lane), 32, w1 + 64, 128)
-        STAGE(mfma_chunk32<false>(CURBUF, x[2], acc, lane), 32, w1 + 96, 128)
-        STAGE(mfma_chunk32<false>(CURBUF, x[3], acc, lane), 32, w2, 512)
-        if (active) relu_dl(acc);
-        STAGE(mfma_chunk32<false>(CURBUF, acc[0], out, lane), 32, w2 + 32, 512)
-        STAGE(mfma_chunk32<false>(CURBUF, acc[1], out, lane), 32, w2 + 64, 512)
-        STAGE(mfma_chunk32<false>(CURBUF, acc[2], out, lane), 32, w2 + 96, 512)
+        load_tile(A.ffn_in_b + 128 * c + 32 * wave, h, acc);
+        STAGE(mfma_tile32<false>(CURBUF, wave, x[0], acc, lane), 32, w1 + 32, 128)
+        STAGE(mfma_tile32<false>(CURBUF, wave, x[1], acc, lane), 32, w1 + 64, 128)
+        STAGE(mfma_tile32<false>(CURBUF, wave, x[2], acc, lane), 32, w1 + 96, 128)
+        STAGE(mfma_tile32<false>(CURBUF, wave, x[3], acc, lane); relu_tile(acc); xbuf_put(xbuf, wave, lane, acc), 32,
+              w2, 512)
+        // second FFN layer over this hidden block: B operands come tile by tile from the exchange buffer
+        STAGE(xbuf_get(xbuf, 0, lane, acc); mfma_tile32<false>(CURBUF, wave, acc, out, lane), 32, w2 + 32, 512)
+        STAGE(xbuf_get(xbuf, 1, lane, acc); mfma_tile32<false>(CURBUF, wave, acc, out, lane), 32, w2 + 64, 512)
+        STAGE(xbuf_get(xbuf, 2, lane, acc); mfma_tile32<false>(CURBUF, wave, acc, out, lane), 32, w2 + 96, 512)
         if (c < 3) {
-            STAGE(mfma_chunk32<false>(CURBUF, acc[3], out, lane), 32, A.ffn_in + (size_t)(128 * (c + 1)) * 128, 128)
+            STAGE(xbuf_get(xbuf, 3, lane, acc); mfma_tile32<false>(CURBUF, wave, acc, out, lane), 32,
+                  A.ffn_in + (size_t)(128 * (c + 1)) * 128, 128)
         } else {
-            if (active) mfma_chunk32<false>(CURBUF, acc[3], out, lane);
+            xbuf_get(xbuf, 3, lane, acc);
+            mfma_tile32<false>(CURBUF, wave, acc, out, lane);
+            __syncthreads();          // every wave is done reading the hidden tiles before they are overwritten
         }
     }
-    if (n < A.N && j < K) {
-        float *orow = A.hE_out + ((size_t)n * K + j) * 128;
-        if (active) {
+    // ---- h_E = mask * LN3(x1 + ffn) ---------------------------------------------------------------------
 #pragma unroll
-            for (int t = 0; t < 4; t++)
+    for (int r = 0; r < 16; r++) out[r] += res[r];
+    xbuf_put(xbuf, wave, lane, out);
+    __syncthreads();
 #pragma unroll
-                for (int r = 0; r < 16; r++) out[t][r] += x[t][r];
-            layernorm_dl(out, A.g3, A.be3, h);
+    for (int t = 0; t < 4; t++) xbuf_get(xbuf, t, lane, x[t]);
+    float mean3;
+    const float rstd = ln_center(x, mean3);
 #pragma unroll
-            for (int t = 0; t < 4; t++)
+    for (int r = 0; r < 16; r++) out[r] -= mean3;
+    ln_affine_tile(out, rstd, A.g3 + 32 * wave, A.be3 + 32 * wave, h);
 #pragma unroll
-                for (int r = 0; r < 16; r++) out[t][r] *= me;
-        } else {
-#pragma unroll
-            for (int t = 0; t < 4; t++)
-#pragma unroll
-                for (int r = 0; r < 16; r++) out[t][r] = 0.f;
-        }
-        store_dl(orow, h, out);
-    }
+    for (int r = 0; r < 16; r++) out[r] *= me;
+    if (j < K) store_tile(A.hE_out + ((size_t)n * K + j) * 128 + 32 * wave, h, out);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -416,7 +464,6 @@ static EdgeArgs edge_args(pp_ctx *c, int layer, bool edge) {
     A.S = c->S; A.msum = c->msum;
     const float *w = p->w;
     A.w_in = w + (edge ? o.em_in_w : o.nm_in_w);
-    A.b_mid_dummy = nullptr;
     A.w_mid = w + (edge ? o.em_mid_w : o.nm_mid_w);
     A.b_mid = w + (edge ? o.em_mid_b : o.nm_mid_b);
     A.w_out = w + (edge ? o.em_out_w : o.nm_out_w);
@@ -428,32 +475,18 @@ static EdgeArgs edge_args(pp_ctx *c, int layer, bool edge) {
     return A;
 }
 
-static const size_t EDGE_SMEM = 2 * LDS_BUF_FLOATS * sizeof(float);
+static const size_t EDGE_SMEM = (2 * WBUF_FLOATS + XBUF_FLOATS) * sizeof(float);
 
 pp_status pp_launch_node_message(pp_ctx *c, int layer, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_node_message),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)EDGE_SMEM));
-        PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_edge_update),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)EDGE_SMEM));
-        attr_set = true;
-    }
     EdgeArgs A = edge_args(c, layer, false);
-    hipLaunchKernelGGL(k_node_message, dim3((c->N + 3) / 4), dim3(ET), EDGE_SMEM, s, A);
+    hipLaunchKernelGGL(k_node_message, dim3(c->N), dim3(ET), EDGE_SMEM, s, A);
     PP_HIP_CHECK(hipGetLastError());
     return PP_OK;
 }
 
 pp_status pp_launch_edge_update(pp_ctx *c, int layer, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_edge_update),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)EDGE_SMEM));
-        attr_set = true;
-    }
     EdgeArgs A = edge_args(c, layer, true);
-    hipLaunchKernelGGL(k_edge_update, dim3((c->N + 3) / 4), dim3(ET), EDGE_SMEM, s, A);
+    hipLaunchKernelGGL(k_edge_update, dim3(c->N), dim3(ET), EDGE_SMEM, s, A);
     PP_HIP_CHECK(hipGetLastError());
     return PP_OK;
 }
