@@ -1,5 +1,7 @@
 // C ABI of libpackppi_hip.so: plan / ctx lifetime and the per-call kernel schedules.
 #include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <new>
@@ -365,6 +367,11 @@ extern "C" pp_status pp_time_kernel(pp_ctx *c, int which, int iters, float *avg_
     if (!c->plan->has_network) FAIL(PP_ERR_INVALID, "pp_time_kernel: plan was created without network weights");
     hipStream_t s = static_cast<hipStream_t>(stream);
     PP_HIP_CHECK(hipSetDevice(c->plan->device));
+    if (getenv("PP_DEBUG")) {
+        int a = 0, b = 0;
+        pp_edge_occupancy(&a, &b);
+        fprintf(stderr, "[pp] resident workgroups/CU: k_node_message %d, k_edge_update %d\n", a, b);
+    }
     hipEvent_t e0, e1;
     PP_HIP_CHECK(hipEventCreate(&e0));
     PP_HIP_CHECK(hipEventCreate(&e1));

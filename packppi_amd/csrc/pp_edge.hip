@@ -28,7 +28,17 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 #define WBUF_FLOATS (128 * 36)          // one weight chunk slot, row stride 36 (32 cols) or 28 (24 cols)
 #define XBUF_FLOATS (4 * 4 * 64 * 4)    // exchange buffer: [tile][quad][lane] float4
 
+// Timing-only ablation switches (tools/debug/ablate_edge.py); never defined in a shipped build.
+#ifdef PP_X_NOMFMA
+#define MFMA(a, b, c) ((c) + (a) * (b))
+#else
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+#endif
+#ifdef PP_X_NOBARRIER
+#define STAGE_SYNC() __builtin_amdgcn_sched_barrier(0)
+#else
+#define STAGE_SYNC() __syncthreads()
+#endif
 
 struct EdgeArgs {
     int N, K;
@@ -58,6 +68,10 @@ struct ChunkRegs {
 template <int NC>
 __device__ __forceinline__ void chunk_load(const float *__restrict__ g, int ld, ChunkRegs<NC> &r, int tid) {
     constexpr int PER_ROW = NC / 4, TOTAL = 128 * PER_ROW, PER_T = (TOTAL + ET - 1) / ET;
+#ifdef PP_X_NOLOAD
+    for (int m = 0; m < PER_T; m++) r.v[m] = f32x4v{0.001f * tid, 0.f, 0.f, 0.f};
+    return;
+#endif
 #pragma unroll
     for (int m = 0; m < PER_T; m++) {
         int idx = tid + ET * m;
@@ -70,6 +84,9 @@ __device__ __forceinline__ void chunk_load(const float *__restrict__ g, int ld, 
 template <int NC>
 __device__ __forceinline__ void chunk_store(float *lds, const ChunkRegs<NC> &r, int tid) {
     constexpr int PER_ROW = NC / 4, TOTAL = 128 * PER_ROW, PER_T = (TOTAL + ET - 1) / ET;
+#ifdef PP_X_NOSTORE
+    return;
+#endif
 #pragma unroll
     for (int m = 0; m < PER_T; m++) {
         int idx = tid + ET * m;
@@ -223,7 +240,7 @@ __device__ __forceinline__ void edge_geometry(const float *__restrict__ pts_i, c
         chunk_load<NEXT_NC>((NEXT_PTR), (NEXT_LD), _r, tid);               \
         { COMPUTE; }                                                       \
         chunk_store<NEXT_NC>(cur ? wbuf0 : wbuf1, _r, tid);                \
-        __syncthreads();                                                   \
+        STAGE_SYNC();                                                      \
         cur ^= 1;                                                          \
     }
 #define CURBUF (cur ? wbuf1 : wbuf0)
@@ -476,6 +493,12 @@ static EdgeArgs edge_args(pp_ctx *c, int layer, bool edge) {
 }
 
 static const size_t EDGE_SMEM = (2 * WBUF_FLOATS + XBUF_FLOATS) * sizeof(float);
+
+// resident workgroups per CU the runtime predicts for the two kernels (measurement aid)
+void pp_edge_occupancy(int *node_msg, int *edge_upd) {
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(node_msg, reinterpret_cast<const void *>(k_node_message), ET, EDGE_SMEM);
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(edge_upd, reinterpret_cast<const void *>(k_edge_update), ET, EDGE_SMEM);
+}
 
 pp_status pp_launch_node_message(pp_ctx *c, int layer, hipStream_t s) {
     EdgeArgs A = edge_args(c, layer, false);

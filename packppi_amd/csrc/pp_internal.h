@@ -125,6 +125,8 @@ pp_status pp_launch_clash(pp_ctx *c, const float *xyz, float *per_res, float *dc
 pp_status pp_launch_proximal(pp_ctx *c, const float *chi, float lamda, int nsteps, float *traj,
                              float *chi_last, float *losses, hipStream_t s);
 
+void pp_edge_occupancy(int *node_msg, int *edge_upd);
+
 // last_mode values for pp_launch_node_update
 #define PP_NU_MID 0        // layers 0,1: update + edge-message inputs + next layer's node-message inputs
 #define PP_NU_SCORE 1      // layer 2, single evaluation: update + decoder

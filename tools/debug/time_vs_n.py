@@ -6,7 +6,8 @@ from packppi_amd.featurize import protein_to_batch
 from packppi_amd.module import TDiffusionModule
 from packppi_amd.weights import make_random_state_dict
 m = TDiffusionModule(make_random_state_dict(20251003), device="cuda:0")
-for L in (128, 256, 384, 512, 640, 768, 1024, 1536):
+Ls = [int(a) for a in sys.argv[1:]] or [128, 256, 384, 512, 640, 768, 1024, 1536]
+for L in Ls:
     b = protein_to_batch(synth.make_complex(L, 77)).to("cuda:0")
     ctx = m._context(b)
     chi = ctx.sample(b.SC_D, torch.linspace(1, 0, 3))
