@@ -66,6 +66,32 @@ static size_t put_T(std::vector<float> &arena, const float *W, int rows, int ld,
     return at;
 }
 
+// append the [128 rows][ncols] block of W (row stride ld) starting at (row0, col0), row-major contiguous
+static void put_chunk(std::vector<float> &arena, const float *W, int ld, int row0, int col0, int ncols) {
+    size_t at = arena.size();
+    arena.resize(at + (size_t)128 * ncols);
+    float *d = arena.data() + at;
+    for (int r = 0; r < 128; r++)
+        for (int c = 0; c < ncols; c++) d[(size_t)r * ncols + c] = W[(size_t)(row0 + r) * ld + col0 + c];
+}
+// chunk stream of one message MLP: W_in[:,128:256] x4, W_in[:,384:456] x3 (24 cols), W_mid x4 [, W_out x4, FFN blocks]
+static size_t put_stream(std::vector<float> &arena, const float *w, const LayerOff &L, bool edge) {
+    size_t at = (arena.size() + 3) & ~size_t(3);
+    arena.resize(at);
+    const float *win = w + (edge ? L.em_in_w : L.nm_in_w), *wmid = w + (edge ? L.em_mid_w : L.nm_mid_w);
+    for (int s = 0; s < 4; s++) put_chunk(arena, win, 456, 0, 128 + 32 * s, 32);
+    for (int g = 0; g < 3; g++) put_chunk(arena, win, 456, 0, 384 + 24 * g, 24);
+    for (int s = 0; s < 4; s++) put_chunk(arena, wmid, 128, 0, 32 * s, 32);
+    if (edge) {
+        for (int s = 0; s < 4; s++) put_chunk(arena, w + L.em_out_w, 128, 0, 32 * s, 32);
+        for (int c = 0; c < 4; c++) {
+            for (int s = 0; s < 4; s++) put_chunk(arena, w + L.ed_in_w, 128, 128 * c, 32 * s, 32);
+            for (int s = 0; s < 4; s++) put_chunk(arena, w + L.ed_out_w, 512, 0, 128 * c + 32 * s, 32);
+        }
+    }
+    return at;
+}
+
 template <typename T>
 static pp_status upload(T **dst, const T *src, size_t n) {
     PP_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(dst), n * sizeof(T)));
@@ -101,10 +127,10 @@ extern "C" pp_status pp_plan_create(const float *weights, size_t n_weights, cons
     if ((st = upload(&p->w, weights, off.total)) != PP_OK) return st;
 
     std::vector<float> arena;
-    arena.reserve(1u << 20);
+    arena.reserve(3u << 20);
     size_t o_node_emb = put_T(arena, weights + off.node_emb_w, 128, 51, 0, 51);
     size_t o_edge_emb = put_T(arena, weights + off.edge_emb_w, 128, 468, 0, 468);
-    size_t o_l[3][9];
+    size_t o_l[3][11];
     for (int l = 0; l < 3; l++) {
         const LayerOff &L = off.layer[l];
         o_l[l][0] = put_T(arena, weights + L.pts_node_w, 24, 128, 0, 128);
@@ -116,6 +142,8 @@ extern "C" pp_status pp_plan_create(const float *weights, size_t n_weights, cons
         o_l[l][6] = put_T(arena, weights + L.nm_out_w, 128, 128, 0, 128);
         o_l[l][7] = put_T(arena, weights + L.nd_in_w, 512, 128, 0, 128);
         o_l[l][8] = put_T(arena, weights + L.nd_out_w, 128, 512, 0, 512);
+        o_l[l][9] = put_stream(arena, weights, L, false);
+        o_l[l][10] = put_stream(arena, weights, L, true);
     }
     size_t o_d0i = put_T(arena, weights + off.d0_in_w, 64, 128, 0, 128);
     size_t o_d0o = put_T(arena, weights + off.d0_out_w, 32, 64, 0, 64);
@@ -131,6 +159,7 @@ extern "C" pp_status pp_plan_create(const float *weights, size_t n_weights, cons
         t.em_A_T = p->wT + o_l[l][4]; t.em_C_T = p->wT + o_l[l][5];
         t.nm_out_T = p->wT + o_l[l][6];
         t.nd_in_T = p->wT + o_l[l][7]; t.nd_out_T = p->wT + o_l[l][8];
+        t.nm_stream = p->wT + o_l[l][9]; t.em_stream = p->wT + o_l[l][10];
     }
     p->d0_in_T = p->wT + o_d0i; p->d0_out_T = p->wT + o_d0o;
     p->d2_in_T = p->wT + o_d2i; p->d2_out_T = p->wT + o_d2o;
@@ -179,7 +208,7 @@ extern "C" void pp_ctx_destroy(pp_ctx *c) {
     if (!c) return;
     void *ptrs[] = {c->eidx, c->mask_att, c->frames, c->bbpos, c->hE0, c->hE, c->hV, c->S, c->msum, c->ptsN, c->PAn,
                     c->PCn, c->ptsE, c->PAe, c->PCe, c->score, c->chi_tmp, c->steps, c->xyz, c->axes, c->brad,
-                    c->per_res, c->dchi, c->px, c->pm, c->pv, c->pz, c->pxeff, c->pmask, c->scal};
+                    c->per_res, c->dchi, c->px, c->pm, c->pv, c->pz, c->pxeff, c->pmask, c->scal, c->dbg};
     for (void *q : ptrs) if (q) hipFree(q);
     if (c->steps_host) hipHostFree(c->steps_host);
     delete c;
@@ -216,6 +245,7 @@ extern "C" pp_status pp_complex_prepare(pp_plan *plan, const pp_batch *b, void *
     ALLOC(xyz, N * 42); ALLOC(axes, N * 24); ALLOC(brad, N); ALLOC(per_res, N); ALLOC(dchi, N * 4);
     ALLOC(px, N * 4); ALLOC(pm, N * 4); ALLOC(pv, N * 4); ALLOC(pz, N * 4); ALLOC(pxeff, N * 4); ALLOC(pmask, N);
     ALLOC(scal, 64);
+    if (getenv("PP_STAMP")) { ALLOC(dbg, N * 4 * 64 * 4); }
     c->max_steps = 1024;
     if (net) { ALLOC(steps, (size_t)c->max_steps); }
 #undef ALLOC
@@ -387,4 +417,12 @@ extern "C" pp_status pp_time_kernel(pp_ctx *c, int which, int iters, float *avg_
     hipEventDestroy(e1);
     *avg_ms = ms / (float)iters;
     return st;
+}
+
+// Diagnostic builds (-DPP_X_STAMP, env PP_STAMP=1): copy the s_memtime stamps of the last edge-kernel launch to the host.
+extern "C" pp_status pp_debug_stamps(pp_ctx *c, unsigned long long *host, size_t n_words) {
+    if (!c || !c->dbg) FAIL(PP_ERR_INVALID, "pp_debug_stamps: no stamp buffer (set PP_STAMP=1)");
+    PP_HIP_CHECK(hipDeviceSynchronize());
+    PP_HIP_CHECK(hipMemcpy(host, c->dbg, n_words * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return PP_OK;
 }

@@ -6,13 +6,14 @@
 //      lane l = (edge j = l & 31, half h = l >> 5),  register r of tile t  <->  feature
 //      F(t, r, h) = 32 t + 8 (r >> 2) + 4 h + (r & 3).
 // With that k-ordering the D registers of one layer ARE the B operands of the next, and the A operand of
-// 4 consecutive k-steps is one float4 of a row of the nn.Linear weight in its native [out][in] layout.
+// 4 consecutive k-steps is one float4 of a row of the nn.Linear weight ([out][in]: no transposition needed).
 //
 // N-split: wave w computes output tile w (32 of the 128 features; for the 512-wide FFN hidden layer,
 // tile 4c + w of hidden block c).  A finished tile is published to a 16 KB LDS exchange buffer
 // (same [tile][quad][lane] float4 layout it has in registers) and every wave reads back the full
 // 128-vector it needs as B operands.  Weights stream L2 -> registers -> LDS in [128 rows][32 | 24 cols]
-// chunks, double buffered; each wave reads its own 32 rows of the shared chunk.  53 KB of LDS and <=168
+// chunks (pre-packed contiguously in consumption order), two chunks in flight, double-buffered LDS; each wave
+// reads its own 32 rows of the shared chunk.  53 KB of LDS and <=168
 // VGPRs per workgroup let up to 3 workgroups share a CU, so one workgroup's barrier / LDS latency is covered
 // by another's MFMAs, and 739 residues x 4 waves spread evenly over the 1024 SIMDs.
 //
@@ -52,48 +53,44 @@ struct EdgeArgs {
     const float *hE_in;        // [N][K][128]
     float *hE_out;             // [N][K][128]   (edge kernel)
     float *S, *msum;           // node kernel outputs
-    // weights, native layouts
-    const float *w_in;
-    const float *w_mid, *b_mid, *w_out, *b_out;
+    const float *wstream;      // this kernel's weight chunks, packed in consumption order
+    const float *b_mid, *b_out;
     const float *g2, *be2, *g3, *be3;
-    const float *ffn_in, *ffn_in_b, *ffn_out, *ffn_out_b;
+    const float *ffn_in_b, *ffn_out_b;
+    unsigned long long *dbg;   // PP_X_STAMP builds only: [N][4 waves][64 stages][4 stamps]
 };
 
-template <int NC>
-struct ChunkRegs {
-    f32x4v v[(128 * NC / 4 + ET - 1) / ET];
+// one weight chunk in flight through registers: [128 rows][NC cols], NC = 32 (4 float4 per thread) or 24 (3)
+struct WRegs {
+    f32x4v v[4];
 };
 
-// [128 rows][NC cols] of a row-major matrix (row stride ld) -> registers -> LDS (row stride NC + 4)
+// The weight chunks are pre-packed (pp_plan_create) in the order the kernel consumes them, each [128 rows][NC cols]
+// chunk contiguous: a chunk is one linear 16 KB (12 KB) read that spreads over every L2 channel.  (Reading the chunks
+// in place from the [out][in] matrices put all 128 rows of a chunk of the 2 KB-stride FFN matrix on one or two
+// channels and made the kernel L2-bound.)   global chunk -> registers -> LDS (row stride NC + 4)
 template <int NC>
-__device__ __forceinline__ void chunk_load(const float *__restrict__ g, int ld, ChunkRegs<NC> &r, int tid) {
-    constexpr int PER_ROW = NC / 4, TOTAL = 128 * PER_ROW, PER_T = (TOTAL + ET - 1) / ET;
+__device__ __forceinline__ void chunk_load(const float *__restrict__ g, WRegs &r, int tid) {
+    constexpr int PER_ROW = NC / 4, PER_T = (128 * PER_ROW) / ET;
+    static_assert((128 * PER_ROW) % ET == 0 && PER_T <= 4, "chunk shape");
 #ifdef PP_X_NOLOAD
     for (int m = 0; m < PER_T; m++) r.v[m] = f32x4v{0.001f * tid, 0.f, 0.f, 0.f};
     return;
 #endif
 #pragma unroll
-    for (int m = 0; m < PER_T; m++) {
-        int idx = tid + ET * m;
-        if (TOTAL % ET == 0 || idx < TOTAL) {
-            int row = idx / PER_ROW, c4 = idx - row * PER_ROW;
-            r.v[m] = *reinterpret_cast<const f32x4v *>(g + (size_t)row * ld + 4 * c4);
-        }
-    }
+    for (int m = 0; m < PER_T; m++) r.v[m] = *reinterpret_cast<const f32x4v *>(g + 4 * (tid + ET * m));
 }
 template <int NC>
-__device__ __forceinline__ void chunk_store(float *lds, const ChunkRegs<NC> &r, int tid) {
-    constexpr int PER_ROW = NC / 4, TOTAL = 128 * PER_ROW, PER_T = (TOTAL + ET - 1) / ET;
+__device__ __forceinline__ void chunk_store(float *lds, const WRegs &r, int tid) {
+    constexpr int PER_ROW = NC / 4, PER_T = (128 * PER_ROW) / ET;
 #ifdef PP_X_NOSTORE
     return;
 #endif
 #pragma unroll
     for (int m = 0; m < PER_T; m++) {
         int idx = tid + ET * m;
-        if (TOTAL % ET == 0 || idx < TOTAL) {
-            int row = idx / PER_ROW, c4 = idx - row * PER_ROW;
-            *reinterpret_cast<f32x4v *>(lds + row * (NC + 4) + 4 * c4) = r.v[m];
-        }
+        int row = idx / PER_ROW, c4 = idx - row * PER_ROW;
+        *reinterpret_cast<f32x4v *>(lds + row * (NC + 4) + 4 * c4) = r.v[m];
     }
 }
 
@@ -232,46 +229,68 @@ __device__ __forceinline__ void edge_geometry(const float *__restrict__ pts_i, c
         for (int m = 0; m < 12; m++) g[c][m] = h ? geom[24 * c + 12 + m] : geom[24 * c + m];
 }
 
-// One pipeline stage: prefetch the next weight chunk into registers, compute on the current LDS slot,
-// publish the prefetched chunk into the other slot, barrier.
-#define STAGE(COMPUTE, NEXT_NC, NEXT_PTR, NEXT_LD)                         \
+// Weight pipeline, prefetch distance 2: at the start of stage k chunk k is visible in LDS slot k&1 and chunk k+1 is in
+// flight into one register set.  The stage issues the loads of chunk k+2 into the other set, computes on chunk k,
+// then publishes chunk k+1 into the other LDS slot (last read one stage ago) and barriers.  A load therefore has two
+// stages of MFMA time to land.  RS / RL name the register sets stored / loaded in this stage (they alternate).
+#ifdef PP_X_STAMP
+#define STAMP(i)                                                                                        \
+    {                                                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                              \
+        unsigned long long _t = __builtin_amdgcn_s_memtime();                                           \
+        if (lane == 0 && stage_no < 64) A.dbg[(((size_t)n * 4 + wave) * 64 + stage_no) * 4 + (i)] = _t; \
+        __builtin_amdgcn_sched_barrier(0);                                                              \
+    }
+#define NEXT_STAGE() stage_no++
+#else
+#define STAMP(i)
+#define NEXT_STAGE()
+#endif
+#define STAGE2(COMPUTE, RS, RS_NC, RL, RL_NC, RL_PTR)                      \
     {                                                                      \
-        ChunkRegs<NEXT_NC> _r;                                             \
-        chunk_load<NEXT_NC>((NEXT_PTR), (NEXT_LD), _r, tid);               \
+        STAMP(0)                                                           \
+        chunk_load<RL_NC>((RL_PTR), RL, tid);                              \
         { COMPUTE; }                                                       \
-        chunk_store<NEXT_NC>(cur ? wbuf0 : wbuf1, _r, tid);                \
+        STAMP(1)                                                           \
+        chunk_store<RS_NC>(cur ? wbuf0 : wbuf1, RS, tid);                  \
+        STAMP(2)                                                           \
+        STAGE_SYNC();                                                      \
+        STAMP(3)                                                           \
+        NEXT_STAGE();                                                      \
+        cur ^= 1;                                                          \
+    }
+// last stages of a kernel: nothing further to load
+#define STAGE2_NOLOAD(COMPUTE, RS, RS_NC)                                  \
+    {                                                                      \
+        { COMPUTE; }                                                       \
+        chunk_store<RS_NC>(cur ? wbuf0 : wbuf1, RS, tid);                  \
         STAGE_SYNC();                                                      \
         cur ^= 1;                                                          \
     }
 #define CURBUF (cur ? wbuf1 : wbuf0)
 
-// shared first layer: acc (tile `wave`) = PA_i + PC_j + W_B h_E + W_G geom, ReLU, published to xbuf;
-// leaves the next layer's first chunk (NEXT_*) staged
-#define FIRST_LAYER(NEXT_PTR, NEXT_LD)                                                                  \
-    {                                                                                                   \
-        ChunkRegs<32> r0;                                                                               \
-        chunk_load<32>(wB, PP_MSG_IN, r0, tid);                                                         \
-        chunk_store<32>(wbuf0, r0, tid);                                                                \
-        __syncthreads();                                                                                \
-    }                                                                                                   \
-    STAGE(mfma_tile32<false>(CURBUF, wave, x[0], acc, lane), 32, wB + 32, PP_MSG_IN)                    \
-    STAGE(mfma_tile32<false>(CURBUF, wave, x[1], acc, lane), 32, wB + 64, PP_MSG_IN)                    \
-    STAGE(mfma_tile32<false>(CURBUF, wave, x[2], acc, lane), 32, wB + 96, PP_MSG_IN)                    \
-    STAGE(mfma_tile32<false>(CURBUF, wave, x[3], acc, lane), 24, wG, PP_MSG_IN)                         \
-    /* x[] is dead from here to the exchange: build the 72 point features in its place */              \
-    edge_geometry(A.pts + (size_t)n * 48, A.frames + (size_t)n * 12, A.pts + (size_t)nbr * 48, h, g);   \
-    STAGE(mfma_tile24(CURBUF, wave, g[0], acc, lane), 24, wG + 24, PP_MSG_IN)                           \
-    STAGE(mfma_tile24(CURBUF, wave, g[1], acc, lane), 24, wG + 48, PP_MSG_IN)                           \
-    {                                                                                                   \
-        ChunkRegs<32> _r;                                                                               \
-        chunk_load<32>((NEXT_PTR), (NEXT_LD), _r, tid);                                                 \
-        mfma_tile24(CURBUF, wave, g[2], acc, lane);                                                     \
-        relu_tile(acc);                                                                                 \
-        xbuf_put(xbuf, wave, lane, acc);                                                                \
-        chunk_store<32>(cur ? wbuf0 : wbuf1, _r, tid);                                                  \
-        __syncthreads();                                                                                \
-        cur ^= 1;                                                                                       \
-    }
+// Stream offsets (floats) of chunk k: chunks 0..3 are 32 columns wide, 4..6 (geometry) 24, the rest 32.
+#define CH32 (128 * 32)
+#define CH24 (128 * 24)
+#define CHUNK_OFF(k) ((k) < 4 ? (k) * CH32 : ((k) < 7 ? 4 * CH32 + ((k) - 4) * CH24 : 4 * CH32 + 3 * CH24 + ((k) - 7) * CH32))
+
+// shared first layer (chunks 0..6 = W_B x4, W_G x3): acc (tile `wave`) = PA_i + PC_j + W_B h_E + W_G geom, ReLU,
+// published to xbuf.  On exit: chunk 7 visible in LDS, chunk 8 in flight in RA.
+#define FIRST_LAYER()                                                                                     \
+    chunk_load<32>(ws + CHUNK_OFF(0), RA, tid);                                                           \
+    chunk_store<32>(wbuf0, RA, tid);                                                                      \
+    chunk_load<32>(ws + CHUNK_OFF(1), RB, tid);                                                           \
+    __syncthreads();                                                                                      \
+    STAGE2(mfma_tile32<false>(CURBUF, wave, x[0], acc, lane), RB, 32, RA, 32, ws + CHUNK_OFF(2))          \
+    STAGE2(mfma_tile32<false>(CURBUF, wave, x[1], acc, lane), RA, 32, RB, 32, ws + CHUNK_OFF(3))          \
+    STAGE2(mfma_tile32<false>(CURBUF, wave, x[2], acc, lane), RB, 32, RA, 24, ws + CHUNK_OFF(4))          \
+    STAGE2(mfma_tile32<false>(CURBUF, wave, x[3], acc, lane), RA, 24, RB, 24, ws + CHUNK_OFF(5))          \
+    /* x[] is dead from here to the exchange: build the 72 point features in its place */                \
+    edge_geometry(A.pts + (size_t)n * 48, A.frames + (size_t)n * 12, A.pts + (size_t)nbr * 48, h, g);     \
+    STAGE2(mfma_tile24(CURBUF, wave, g[0], acc, lane), RB, 24, RA, 24, ws + CHUNK_OFF(6))                 \
+    STAGE2(mfma_tile24(CURBUF, wave, g[1], acc, lane), RA, 24, RB, 32, ws + CHUNK_OFF(7))                 \
+    STAGE2(mfma_tile24(CURBUF, wave, g[2], acc, lane); relu_tile(acc); xbuf_put(xbuf, wave, lane, acc),   \
+           RB, 32, RA, 32, ws + CHUNK_OFF(8))
 
 // ---------------------------------------------------------------------------------------------
 // node message: S[i] = (1/K) sum_j mask_ij relu(W_mid relu(W_in [..]) + b), msum[i] = (1/K) sum_j mask_ij
@@ -286,6 +305,9 @@ k_node_message(EdgeArgs A) {
     const int n = blockIdx.x;
     const int K = A.K;
     int cur = 0;
+#ifdef PP_X_STAMP
+    int stage_no = 0;
+#endif
     if (A.rmask[n] == 0.f) {              // masked / padded residue: whole workgroup leaves
         if (tid < 128) A.S[(size_t)n * 128 + tid] = 0.f;
         if (tid == 0) A.msum[n] = 0.f;
@@ -303,8 +325,9 @@ k_node_message(EdgeArgs A) {
         load_tile(A.PA + (size_t)n * 128 + 32 * wave, h, acc);
         add_tile(A.PC + (size_t)nbr * 128 + 32 * wave, h, acc);
     }
-    const float *wB = A.w_in + 128, *wG = A.w_in + 384;
-    FIRST_LAYER(A.w_mid, 128)
+    const float *ws = A.wstream;          // chunks: W_B 0..3, W_G 4..6, W_mid 7..10
+    WRegs RA, RB;
+    FIRST_LAYER()
     {
 #pragma unroll
         for (int t = 0; t < 4; t++) xbuf_get(xbuf, t, lane, x[t]);
@@ -312,9 +335,9 @@ k_node_message(EdgeArgs A) {
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[r] = b;
     }
-    STAGE(mfma_tile32<true>(CURBUF, wave, x[0], acc, lane), 32, A.w_mid + 32, 128)
-    STAGE(mfma_tile32<true>(CURBUF, wave, x[1], acc, lane), 32, A.w_mid + 64, 128)
-    STAGE(mfma_tile32<true>(CURBUF, wave, x[2], acc, lane), 32, A.w_mid + 96, 128)
+    STAGE2(mfma_tile32<true>(CURBUF, wave, x[0], acc, lane), RA, 32, RB, 32, ws + CHUNK_OFF(9))
+    STAGE2(mfma_tile32<true>(CURBUF, wave, x[1], acc, lane), RB, 32, RA, 32, ws + CHUNK_OFF(10))
+    STAGE2_NOLOAD(mfma_tile32<true>(CURBUF, wave, x[2], acc, lane), RA, 32)
     {
         mfma_tile32<true>(CURBUF, wave, x[3], acc, lane);
         // rows (registers) are edges e = 8 (r>>2) + 4 h + (r&3); mask and reduce over them
@@ -341,7 +364,7 @@ k_node_message(EdgeArgs A) {
 // ---------------------------------------------------------------------------------------------
 // edge update: h_E <- mask * LN3(x1 + FFN(x1)),  x1 = LN2(h_E + mask * MLP3([..]))
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(ET, 3)
+__global__ void __launch_bounds__(ET, 2)
 k_edge_update(EdgeArgs A) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *wbuf0 = smem, *wbuf1 = smem + WBUF_FLOATS, *xbuf = smem + 2 * WBUF_FLOATS;
@@ -352,6 +375,9 @@ k_edge_update(EdgeArgs A) {
     const int K = A.K;
     const int jj = j < K ? j : K - 1;
     int cur = 0;
+#ifdef PP_X_STAMP
+    int stage_no = 0;
+#endif
     if (A.rmask[n] == 0.f) {              // masked / padded residue: its edges are zero, whole workgroup leaves
         if (j < K) {
             f32x4v z = {0.f, 0.f, 0.f, 0.f};
@@ -373,84 +399,77 @@ k_edge_update(EdgeArgs A) {
         load_tile(A.PA + (size_t)n * 128 + 32 * wave, h, acc);
         add_tile(A.PC + (size_t)nbr * 128 + 32 * wave, h, acc);
     }
-    const float *wB = A.w_in + 128, *wG = A.w_in + 384;
-    FIRST_LAYER(A.w_mid, 128)
-    // ---- second layer -------------------------------------------------------------------------
+    const float *ws = A.wstream;   // chunks: W_B 0..3, W_G 4..6, W_mid 7..10, W_out 11..14, then per c: W1 x4, W2 x4
+    WRegs RA, RB;
+    FIRST_LAYER()
+    // ---- second layer (chunks 7..10) -------------------------------------------------------------
     {
 #pragma unroll
         for (int t = 0; t < 4; t++) xbuf_get(xbuf, t, lane, x[t]);
         load_tile(A.b_mid + 32 * wave, h, acc);
     }
-    STAGE(mfma_tile32<false>(CURBUF, wave, x[0], acc, lane), 32, A.w_mid + 32, 128)
-    STAGE(mfma_tile32<false>(CURBUF, wave, x[1], acc, lane), 32, A.w_mid + 64, 128)
-    STAGE(mfma_tile32<false>(CURBUF, wave, x[2], acc, lane), 32, A.w_mid + 96, 128)
-    STAGE(mfma_tile32<false>(CURBUF, wave, x[3], acc, lane); relu_tile(acc); xbuf_put(xbuf, wave, lane, acc), 32,
-          A.w_out, 128)
-    // ---- third layer --------------------------------------------------------------------------
+    STAGE2(mfma_tile32<false>(CURBUF, wave, x[0], acc, lane), RA, 32, RB, 32, ws + CHUNK_OFF(9))
+    STAGE2(mfma_tile32<false>(CURBUF, wave, x[1], acc, lane), RB, 32, RA, 32, ws + CHUNK_OFF(10))
+    STAGE2(mfma_tile32<false>(CURBUF, wave, x[2], acc, lane), RA, 32, RB, 32, ws + CHUNK_OFF(11))
+    STAGE2(mfma_tile32<false>(CURBUF, wave, x[3], acc, lane); relu_tile(acc); xbuf_put(xbuf, wave, lane, acc),
+           RB, 32, RA, 32, ws + CHUNK_OFF(12))
+    // ---- third layer (chunks 11..14) --------------------------------------------------------------
     {
 #pragma unroll
         for (int t = 0; t < 4; t++) xbuf_get(xbuf, t, lane, x[t]);
         load_tile(A.b_out + 32 * wave, h, acc);
     }
-    STAGE(mfma_tile32<false>(CURBUF, wave, x[0], acc, lane), 32, A.w_out + 32, 128)
-    STAGE(mfma_tile32<false>(CURBUF, wave, x[1], acc, lane), 32, A.w_out + 64, 128)
-    STAGE(mfma_tile32<false>(CURBUF, wave, x[2], acc, lane), 32, A.w_out + 96, 128)
-    // last chunk; then publish v = h_E + mask * m for the first LayerNorm; stage W1 chunk (c=0, s=0)
-    {
-        ChunkRegs<32> _r;
-        chunk_load<32>(A.ffn_in, 128, _r, tid);
-        mfma_tile32<false>(CURBUF, wave, x[3], acc, lane);
-        f32x16 v;
-        load_tile(hrow + 32 * wave, h, v);
-#pragma unroll
-        for (int r = 0; r < 16; r++) v[r] = fmaf(acc[r], me, v[r]);
-        xbuf_put(xbuf, wave, lane, v);
-        chunk_store<32>(cur ? wbuf0 : wbuf1, _r, tid);
-        __syncthreads();
-        cur ^= 1;
-    }
-    f32x16 res;          // this wave's tile of x1 (the FFN residual)
+    STAGE2(mfma_tile32<false>(CURBUF, wave, x[0], acc, lane), RA, 32, RB, 32, ws + CHUNK_OFF(13))
+    STAGE2(mfma_tile32<false>(CURBUF, wave, x[1], acc, lane), RB, 32, RA, 32, ws + CHUNK_OFF(14))
+    STAGE2(mfma_tile32<false>(CURBUF, wave, x[2], acc, lane), RA, 32, RB, 32, ws + CHUNK_OFF(15))
+    // last chunk; then publish v = h_E + mask * m for the first LayerNorm
+    STAGE2(mfma_tile32<false>(CURBUF, wave, x[3], acc, lane); {
+               f32x16 v;
+               load_tile(hrow + 32 * wave, h, v);
+               _Pragma("unroll") for (int r = 0; r < 16; r++) v[r] = fmaf(acc[r], me, v[r]);
+               xbuf_put(xbuf, wave, lane, v);
+           },
+           RB, 32, RA, 32, ws + CHUNK_OFF(16))
     {
         // x1 = LN2(v): every wave normalises the full vector (it needs all of x1 as B operands)
 #pragma unroll
         for (int t = 0; t < 4; t++) xbuf_get(xbuf, t, lane, x[t]);
-        xbuf_get(xbuf, wave, lane, res);
         float mean;
         const float rstd = ln_center(x, mean);
 #pragma unroll
         for (int t = 0; t < 4; t++) ln_affine_tile(x[t], rstd, A.g2 + 32 * t, A.be2 + 32 * t, h);
-#pragma unroll
-        for (int r = 0; r < 16; r++) res[r] -= mean;
-        ln_affine_tile(res, rstd, A.g2 + 32 * wave, A.be2 + 32 * wave, h);
         load_tile(A.ffn_out_b + 32 * wave, h, out);
     }
-    // ---- FFN 128 -> 512 -> 128 in four hidden blocks of 128 -------------------------------------------
+    // ---- FFN 128 -> 512 -> 128 in four hidden blocks of 128 (chunks 15 + 8c ..) ------------------------
 #pragma unroll
     for (int c = 0; c < 4; c++) {
-        const float *w1 = A.ffn_in + (size_t)(128 * c) * 128;      // rows 128c.. of [512][128]
-        const float *w2 = A.ffn_out + 128 * c;                     // cols 128c.. of [128][512]
+        const float *wc = ws + CHUNK_OFF(15 + 8 * c);             // this block's 8 chunks: W1 s=0..3, W2 s'=0..3
         load_tile(A.ffn_in_b + 128 * c + 32 * wave, h, acc);
-        STAGE(mfma_tile32<false>(CURBUF, wave, x[0], acc, lane), 32, w1 + 32, 128)
-        STAGE(mfma_tile32<false>(CURBUF, wave, x[1], acc, lane), 32, w1 + 64, 128)
-        STAGE(mfma_tile32<false>(CURBUF, wave, x[2], acc, lane), 32, w1 + 96, 128)
-        STAGE(mfma_tile32<false>(CURBUF, wave, x[3], acc, lane); relu_tile(acc); xbuf_put(xbuf, wave, lane, acc), 32,
-              w2, 512)
+        STAGE2(mfma_tile32<false>(CURBUF, wave, x[0], acc, lane), RA, 32, RB, 32, wc + 2 * CH32)
+        STAGE2(mfma_tile32<false>(CURBUF, wave, x[1], acc, lane), RB, 32, RA, 32, wc + 3 * CH32)
+        STAGE2(mfma_tile32<false>(CURBUF, wave, x[2], acc, lane), RA, 32, RB, 32, wc + 4 * CH32)
+        STAGE2(mfma_tile32<false>(CURBUF, wave, x[3], acc, lane); relu_tile(acc); xbuf_put(xbuf, wave, lane, acc),
+               RB, 32, RA, 32, wc + 5 * CH32)
         // second FFN layer over this hidden block: B operands come tile by tile from the exchange buffer
-        STAGE(xbuf_get(xbuf, 0, lane, acc); mfma_tile32<false>(CURBUF, wave, acc, out, lane), 32, w2 + 32, 512)
-        STAGE(xbuf_get(xbuf, 1, lane, acc); mfma_tile32<false>(CURBUF, wave, acc, out, lane), 32, w2 + 64, 512)
-        STAGE(xbuf_get(xbuf, 2, lane, acc); mfma_tile32<false>(CURBUF, wave, acc, out, lane), 32, w2 + 96, 512)
+        STAGE2(xbuf_get(xbuf, 0, lane, acc); mfma_tile32<false>(CURBUF, wave, acc, out, lane), RA, 32, RB, 32, wc + 6 * CH32)
+        STAGE2(xbuf_get(xbuf, 1, lane, acc); mfma_tile32<false>(CURBUF, wave, acc, out, lane), RB, 32, RA, 32, wc + 7 * CH32)
         if (c < 3) {
-            STAGE(xbuf_get(xbuf, 3, lane, acc); mfma_tile32<false>(CURBUF, wave, acc, out, lane), 32,
-                  A.ffn_in + (size_t)(128 * (c + 1)) * 128, 128)
+            STAGE2(xbuf_get(xbuf, 2, lane, acc); mfma_tile32<false>(CURBUF, wave, acc, out, lane), RA, 32, RB, 32, wc + 8 * CH32)
+            STAGE2(xbuf_get(xbuf, 3, lane, acc); mfma_tile32<false>(CURBUF, wave, acc, out, lane), RB, 32, RA, 32,
+                   wc + 9 * CH32)
         } else {
+            STAGE2_NOLOAD(xbuf_get(xbuf, 2, lane, acc); mfma_tile32<false>(CURBUF, wave, acc, out, lane), RA, 32)
             xbuf_get(xbuf, 3, lane, acc);
             mfma_tile32<false>(CURBUF, wave, acc, out, lane);
             __syncthreads();          // every wave is done reading the hidden tiles before they are overwritten
         }
     }
     // ---- h_E = mask * LN3(x1 + ffn) ---------------------------------------------------------------------
-#pragma unroll
-    for (int r = 0; r < 16; r++) out[r] += res[r];
+    // residual: this wave's tile of x1 (wave is scalar: four uniform branches, static register indices)
+    if (wave == 0) { _Pragma("unroll") for (int r = 0; r < 16; r++) out[r] += x[0][r]; }
+    else if (wave == 1) { _Pragma("unroll") for (int r = 0; r < 16; r++) out[r] += x[1][r]; }
+    else if (wave == 2) { _Pragma("unroll") for (int r = 0; r < 16; r++) out[r] += x[2][r]; }
+    else { _Pragma("unroll") for (int r = 0; r < 16; r++) out[r] += x[3][r]; }
     xbuf_put(xbuf, wave, lane, out);
     __syncthreads();
 #pragma unroll
@@ -480,15 +499,14 @@ static EdgeArgs edge_args(pp_ctx *c, int layer, bool edge) {
     A.hE_out = c->hE;
     A.S = c->S; A.msum = c->msum;
     const float *w = p->w;
-    A.w_in = w + (edge ? o.em_in_w : o.nm_in_w);
-    A.w_mid = w + (edge ? o.em_mid_w : o.nm_mid_w);
+    A.wstream = edge ? p->lt[layer].em_stream : p->lt[layer].nm_stream;
     A.b_mid = w + (edge ? o.em_mid_b : o.nm_mid_b);
-    A.w_out = w + (edge ? o.em_out_w : o.nm_out_w);
     A.b_out = w + (edge ? o.em_out_b : o.nm_out_b);
     A.g2 = w + o.norm_g[2]; A.be2 = w + o.norm_b[2];
     A.g3 = w + o.norm_g[3]; A.be3 = w + o.norm_b[3];
-    A.ffn_in = w + o.ed_in_w; A.ffn_in_b = w + o.ed_in_b;
-    A.ffn_out = w + o.ed_out_w; A.ffn_out_b = w + o.ed_out_b;
+    A.ffn_in_b = w + o.ed_in_b;
+    A.ffn_out_b = w + o.ed_out_b;
+    A.dbg = c->dbg;
     return A;
 }
 

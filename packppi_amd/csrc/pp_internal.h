@@ -37,6 +37,7 @@ struct LayerT {
     const float *nm_out_T;                           // [128][128]
     const float *nd_in_T;                            // [128][512]
     const float *nd_out_T;                           // [512][128]
+    const float *nm_stream, *em_stream;              // MFMA weight chunks packed in consumption order (pp_edge.hip)
 };
 
 struct pp_plan {
@@ -101,6 +102,7 @@ struct pp_ctx {
     float *px, *pm, *pv, *pz, *pxeff;   // proximal: param, Adam moments, anchor, effective chi  [N][4]
     uint8_t *pmask;           // [N]
     float *scal;              // small scalar scratch
+    unsigned long long *dbg;  // stamp buffer of PP_X_STAMP diagnostic builds (else unused)
 };
 
 void pp_set_error(const std::string &msg);
