@@ -8,15 +8,20 @@
 //                   (schedule.py:198-235, TorsionalDiffusion.py:268-280) and the next embedding.
 //
 // This work is ~3% of the FLOPs but a long dependent chain over only B*L rows, so it is laid out for
-// latency: a block of 512 threads owns 4 consecutive nodes; thread (f = tid & 127, ks = tid >> 7) owns
-// output feature f for all four nodes over the ks-th quarter of the reduction dimension; the four
-// partial sums meet in LDS.  Weights are read from transposed copies ([in][out]) so a wave's loads are
-// contiguous; activations sit in LDS as float4 (one component per node).  The cheap epilogues
-// (LayerNorm, bias, ReLU) are replicated in the four ks-groups to keep control flow uniform.
+// latency: a block of 512 threads owns NB = 4 NG consecutive residues; thread (f = tid & 127, ks = tid >> 7) owns
+// output feature f for all of them over the ks-th quarter of the reduction dimension; the four partial sums meet
+// in LDS.  Weights are read from transposed copies ([in][out]) so a wave's loads are contiguous; activations
+// sit in LDS as float4 groups (one component per residue).  The kernel is bound by the L2 round trip of each
+// dependent dense phase, not by bytes: NG = 1 (185 blocks at T1124) runs in 27 us, NG = 2 (93 blocks) in 74 us.
+// The cheap epilogues (LayerNorm, bias, ReLU) are replicated in the four ks-groups to keep control flow uniform.
 #include "pp_internal.h"
 
 #define NT 512
-#define NB 4
+#ifndef PP_NODE_GROUPS
+#define PP_NODE_GROUPS 1
+#endif
+#define NG PP_NODE_GROUPS
+#define NB (4 * NG)
 
 struct NodeArgs {
     int N;
@@ -46,87 +51,118 @@ struct UpdW {
     const float *d0_inT, *d0_in_b, *d0_outT, *d0_out_b, *d2_inT, *d2_in_b, *d2_outT, *d2_out_b;
 };
 
+// one feature's values for the NB residues of the block
+struct VN {
+    float4 g[NG];
+};
+
 struct Smem {
-    float4 part[2][4 * 512];   // ping-pong partial sums  (64 KB)
-    float4 a[512];             // wide activation vector (FFN hidden, decoder scratch)
-    float4 h[128];             // current node vector
-    float4 p[24];              // local points / small inputs
-    float4 red[2][8];          // LayerNorm partials, ping-pong
-    int flip, rflip;
+    VN part[2][4 * 384];       // ping-pong partial sums (4 K-slices x up to 384 columns)
+    VN a[512];                 // wide activation vector (FFN hidden, decoder scratch)
+    VN h[128];                 // current node vector
+    VN p[24];                  // local points / small inputs
+    VN red[2][8];              // LayerNorm partials, ping-pong
 };
 
 __device__ __forceinline__ float4 f4(float v) { return make_float4(v, v, v, v); }
-__device__ __forceinline__ float4 fma4(float w, float4 a, float4 c) {
-    return make_float4(fmaf(w, a.x, c.x), fmaf(w, a.y, c.y), fmaf(w, a.z, c.z), fmaf(w, a.w, c.w));
-}
-__device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
-__device__ __forceinline__ float4 sub4(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
-__device__ __forceinline__ float4 mul4(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
-__device__ __forceinline__ float4 scale4(float4 a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
-__device__ __forceinline__ float4 relu4(float4 a) { return make_float4(fmaxf(a.x, 0.f), fmaxf(a.y, 0.f), fmaxf(a.z, 0.f), fmaxf(a.w, 0.f)); }
 __device__ __forceinline__ float comp(float4 v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w)); }
+
+#define VN_FOR _Pragma("unroll") for (int gi = 0; gi < NG; gi++)
+__device__ __forceinline__ VN vn(float v) { VN r; VN_FOR r.g[gi] = f4(v); return r; }
+__device__ __forceinline__ VN vfma(float w, const VN &a, VN c) {
+    VN_FOR c.g[gi] = make_float4(fmaf(w, a.g[gi].x, c.g[gi].x), fmaf(w, a.g[gi].y, c.g[gi].y), fmaf(w, a.g[gi].z, c.g[gi].z),
+                                 fmaf(w, a.g[gi].w, c.g[gi].w));
+    return c;
+}
+__device__ __forceinline__ VN vadd(VN a, const VN &b) {
+    VN_FOR a.g[gi] = make_float4(a.g[gi].x + b.g[gi].x, a.g[gi].y + b.g[gi].y, a.g[gi].z + b.g[gi].z, a.g[gi].w + b.g[gi].w);
+    return a;
+}
+__device__ __forceinline__ VN vsub(VN a, const VN &b) {
+    VN_FOR a.g[gi] = make_float4(a.g[gi].x - b.g[gi].x, a.g[gi].y - b.g[gi].y, a.g[gi].z - b.g[gi].z, a.g[gi].w - b.g[gi].w);
+    return a;
+}
+__device__ __forceinline__ VN vmul(VN a, const VN &b) {
+    VN_FOR a.g[gi] = make_float4(a.g[gi].x * b.g[gi].x, a.g[gi].y * b.g[gi].y, a.g[gi].z * b.g[gi].z, a.g[gi].w * b.g[gi].w);
+    return a;
+}
+__device__ __forceinline__ VN vscale(VN a, float s) {
+    VN_FOR a.g[gi] = make_float4(a.g[gi].x * s, a.g[gi].y * s, a.g[gi].z * s, a.g[gi].w * s);
+    return a;
+}
+__device__ __forceinline__ VN vrelu(VN a) {
+    VN_FOR a.g[gi] = make_float4(fmaxf(a.g[gi].x, 0.f), fmaxf(a.g[gi].y, 0.f), fmaxf(a.g[gi].z, 0.f), fmaxf(a.g[gi].w, 0.f));
+    return a;
+}
+__device__ __forceinline__ float vcomp(const VN &v, int i) { return comp(v.g[i >> 2], i & 3); }   // i: residue in block
 
 // partial sum over the ks-th quarter of the reduction dimension
 template <int KIN>
-__device__ __forceinline__ float4 dense_slice(const float *__restrict__ WT, int ldo, int col, const float4 *act, int ks) {
+__device__ __forceinline__ VN dense_slice(const float *__restrict__ WT, int ldo, int col, const VN *act, int ks) {
     constexpr int KL = KIN / 4;
     const float *w = WT + (size_t)(ks * KL) * ldo + col;
-    const float4 *a = act + ks * KL;
-    float4 acc = f4(0.f);
+    const VN *a = act + ks * KL;
+    VN acc = vn(0.f);
 #pragma unroll 16
-    for (int i = 0; i < KL; i++) acc = fma4(w[(size_t)i * ldo], a[i], acc);
+    for (int i = 0; i < KL; i++) acc = vfma(w[(size_t)i * ldo], a[i], acc);
     return acc;
 }
 
 // meet the four K-slices: every thread returns the full sum for its column (one barrier, ping-pong buffer)
-__device__ __forceinline__ float4 meet(Smem &sm, int &flip, float4 partial, int stride, int col, int ks) {
-    float4 *buf = sm.part[flip];
+__device__ __forceinline__ VN meet(Smem &sm, int &flip, const VN &partial, int stride, int col, int ks) {
+    VN *buf = sm.part[flip];
     flip ^= 1;
     buf[ks * stride + col] = partial;
     __syncthreads();
-    return add4(add4(buf[col], buf[stride + col]), add4(buf[2 * stride + col], buf[3 * stride + col]));
+    return vadd(vadd(buf[col], buf[stride + col]), vadd(buf[2 * stride + col], buf[3 * stride + col]));
 }
 
-__device__ __forceinline__ float4 wave_sum4(float4 v) {
+__device__ __forceinline__ VN wave_sum(VN v) {
     for (int o = 32; o > 0; o >>= 1) {
-        v.x += __shfl_xor(v.x, o); v.y += __shfl_xor(v.y, o); v.z += __shfl_xor(v.z, o); v.w += __shfl_xor(v.w, o);
+        VN_FOR {
+            v.g[gi].x += __shfl_xor(v.g[gi].x, o); v.g[gi].y += __shfl_xor(v.g[gi].y, o);
+            v.g[gi].z += __shfl_xor(v.g[gi].z, o); v.g[gi].w += __shfl_xor(v.g[gi].w, o);
+        }
     }
     return v;
 }
 
-// LayerNorm over 128 features (one per thread of a ks-group = 2 waves), four nodes at once, eps 1e-5, two-pass
-__device__ __forceinline__ float4 layernorm4(Smem &sm, int &rflip, float4 v, float g, float b) {
+// LayerNorm over 128 features (one per thread of a ks-group = 2 waves), NB residues at once, eps 1e-5, two-pass
+__device__ __forceinline__ VN layernorm(Smem &sm, int &rflip, const VN &v, float g, float b) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, grp = wid & ~1;
-    float4 s = wave_sum4(v);
-    float4 *r = sm.red[rflip];
+    VN s = wave_sum(v);
+    VN *r = sm.red[rflip];
     rflip ^= 1;
     if (lane == 0) r[wid] = s;
     __syncthreads();
-    const float4 mean = scale4(add4(r[grp], r[grp + 1]), 1.f / 128.f);
-    const float4 d = sub4(v, mean);
-    float4 q = wave_sum4(mul4(d, d));
+    const VN mean = vscale(vadd(r[grp], r[grp + 1]), 1.f / 128.f);
+    const VN d = vsub(v, mean);
+    VN q = wave_sum(vmul(d, d));
     r = sm.red[rflip];
     rflip ^= 1;
     if (lane == 0) r[wid] = q;
     __syncthreads();
-    const float4 var = scale4(add4(r[grp], r[grp + 1]), 1.f / 128.f);
-    const float4 rs = make_float4(1.f / sqrtf(var.x + 1e-5f), 1.f / sqrtf(var.y + 1e-5f), 1.f / sqrtf(var.z + 1e-5f),
-                                  1.f / sqrtf(var.w + 1e-5f));
-    return make_float4(d.x * rs.x * g + b, d.y * rs.y * g + b, d.z * rs.z * g + b, d.w * rs.w * g + b);
+    const VN var = vscale(vadd(r[grp], r[grp + 1]), 1.f / 128.f);
+    VN o;
+    VN_FOR o.g[gi] = make_float4(d.g[gi].x * (1.f / sqrtf(var.g[gi].x + 1e-5f)) * g + b,
+                                 d.g[gi].y * (1.f / sqrtf(var.g[gi].y + 1e-5f)) * g + b,
+                                 d.g[gi].z * (1.f / sqrtf(var.g[gi].z + 1e-5f)) * g + b,
+                                 d.g[gi].w * (1.f / sqrtf(var.g[gi].w + 1e-5f)) * g + b);
+    return o;
 }
 
-__device__ __forceinline__ void store_rows(float *dst, int ld, int n0, int N, int col, float4 v) {
-    if (n0 + 0 < N) dst[(size_t)(n0 + 0) * ld + col] = v.x;
-    if (n0 + 1 < N) dst[(size_t)(n0 + 1) * ld + col] = v.y;
-    if (n0 + 2 < N) dst[(size_t)(n0 + 2) * ld + col] = v.z;
-    if (n0 + 3 < N) dst[(size_t)(n0 + 3) * ld + col] = v.w;
+__device__ __forceinline__ void store_rows(float *dst, int ld, int n0, int N, int col, const VN &v) {
+#pragma unroll
+    for (int i = 0; i < NB; i++)
+        if (n0 + i < N) dst[(size_t)(n0 + i) * ld + col] = vcomp(v, i);
 }
-__device__ __forceinline__ float4 load_rows(const float *src, int ld, int n0, int N, int col) {
-    float4 v = f4(0.f);
-    if (n0 + 0 < N) v.x = src[(size_t)(n0 + 0) * ld + col];
-    if (n0 + 1 < N) v.y = src[(size_t)(n0 + 1) * ld + col];
-    if (n0 + 2 < N) v.z = src[(size_t)(n0 + 2) * ld + col];
-    if (n0 + 3 < N) v.w = src[(size_t)(n0 + 3) * ld + col];
+__device__ __forceinline__ VN load_rows(const float *src, int ld, int n0, int N, int col) {
+    VN v;
+    VN_FOR {
+        const int b = n0 + 4 * gi;
+        v.g[gi] = make_float4(b + 0 < N ? src[(size_t)(b + 0) * ld + col] : 0.f, b + 1 < N ? src[(size_t)(b + 1) * ld + col] : 0.f,
+                              b + 2 < N ? src[(size_t)(b + 2) * ld + col] : 0.f, b + 3 < N ? src[(size_t)(b + 3) * ld + col] : 0.f);
+    }
     return v;
 }
 
@@ -135,34 +171,33 @@ __device__ __forceinline__ float4 load_rows(const float *src, int ld, int n0, in
 __device__ void message_inputs(Smem &sm, int &flip, const PreW &w, const float *frames, int n0, int N,
                                float *pts, float *PA, float *PC) {
     const int f = threadIdx.x & 127, ks = threadIdx.x >> 7;
-    float4 pa = dense_slice<128>(w.AT, 128, f, sm.h, ks);
-    float4 pc = dense_slice<128>(w.CT, 128, f, sm.h, ks);
-    float4 pp = f < 24 ? dense_slice<128>(w.ptsT, 24, f, sm.h, ks) : f4(0.f);
-    float4 *buf = sm.part[flip];
+    VN pa = dense_slice<128>(w.AT, 128, f, sm.h, ks);
+    VN pc = dense_slice<128>(w.CT, 128, f, sm.h, ks);
+    VN *buf = sm.part[flip];
     flip ^= 1;
     buf[ks * 384 + f] = pa;
     buf[ks * 384 + 128 + f] = pc;
-    if (f < 24) buf[ks * 384 + 256 + f] = pp;
+    if (f < 24) buf[ks * 384 + 256 + f] = dense_slice<128>(w.ptsT, 24, f, sm.h, ks);
     __syncthreads();
     if (ks == 0) {
-        float4 a = add4(add4(buf[f], buf[384 + f]), add4(buf[768 + f], buf[1152 + f]));
-        store_rows(PA, 128, n0, N, f, add4(a, f4(w.in_b[f])));
+        VN a = vadd(vadd(buf[f], buf[384 + f]), vadd(buf[768 + f], buf[1152 + f]));
+        store_rows(PA, 128, n0, N, f, vadd(a, vn(w.in_b[f])));
     } else if (ks == 1) {
-        float4 c = add4(add4(buf[128 + f], buf[512 + f]), add4(buf[896 + f], buf[1280 + f]));
+        VN c = vadd(vadd(buf[128 + f], buf[512 + f]), vadd(buf[896 + f], buf[1280 + f]));
         store_rows(PC, 128, n0, N, f, c);
     } else if (ks == 2 && f < 24) {
-        float4 p = add4(add4(buf[256 + f], buf[640 + f]), add4(buf[1024 + f], buf[1408 + f]));
-        p = add4(p, f4(w.pts_b[f]));
+        VN p = vadd(vadd(buf[256 + f], buf[640 + f]), vadd(buf[1024 + f], buf[1408 + f]));
+        p = vadd(p, vn(w.pts_b[f]));
         sm.p[f] = p;
         store_rows(pts, 48, n0, N, f, p);
     }
     __syncthreads();
-    if (threadIdx.x < 32) {            // (point q, node i): p_glob = R p_loc + t
-        int q = threadIdx.x >> 2, i = threadIdx.x & 3;
+    if (threadIdx.x < 8 * NB) {            // (point q, residue i): p_glob = R p_loc + t
+        int q = threadIdx.x / NB, i = threadIdx.x % NB;
         int n = n0 + i;
         if (n < N) {
             const float *fr = frames + (size_t)n * 12;
-            float x = comp(sm.p[3 * q], i), y = comp(sm.p[3 * q + 1], i), z = comp(sm.p[3 * q + 2], i);
+            float x = vcomp(sm.p[3 * q], i), y = vcomp(sm.p[3 * q + 1], i), z = vcomp(sm.p[3 * q + 2], i);
             for (int r = 0; r < 3; r++)
                 pts[(size_t)n * 48 + 24 + 3 * q + r] = (fr[3 * r] * x + fr[3 * r + 1] * y + fr[3 * r + 2] * z) + fr[9 + r];
         }
@@ -170,38 +205,43 @@ __device__ void message_inputs(Smem &sm, int &flip, const PreW &w, const float *
     __syncthreads();
 }
 
-// Node embedding for 4 nodes -> float4 (before LN) for feature f (all ks-groups compute the same thing)
-__device__ __forceinline__ float4 embed_pre(Smem &sm, const NodeArgs &A, const float *chi, int step, int n0) {
+// Node embedding for the block's residues -> value (before LN) of feature f (all ks-groups compute the same thing)
+__device__ __forceinline__ VN embed_pre(Smem &sm, const NodeArgs &A, const float *chi, int step, int n0) {
     const int t = threadIdx.x, f = t & 127;
     if (t < 6) sm.p[t] = load_rows(A.bb_sincos, 6, n0, A.N, t);
     else if (t < 14) {
         int k = (t - 6) >> 1, sc = (t - 6) & 1;
-        float4 x = load_rows(chi, 4, n0, A.N, k), m = load_rows(A.sc_mask, 4, n0, A.N, k);
-        float4 v = sc ? make_float4(cosf(x.x), cosf(x.y), cosf(x.z), cosf(x.w))
-                      : make_float4(sinf(x.x), sinf(x.y), sinf(x.z), sinf(x.w));
-        sm.p[t] = mul4(v, m);
+        VN x = load_rows(chi, 4, n0, A.N, k), m = load_rows(A.sc_mask, 4, n0, A.N, k), v;
+        VN_FOR v.g[gi] = sc ? make_float4(cosf(x.g[gi].x), cosf(x.g[gi].y), cosf(x.g[gi].z), cosf(x.g[gi].w))
+                            : make_float4(sinf(x.g[gi].x), sinf(x.g[gi].y), sinf(x.g[gi].z), sinf(x.g[gi].w));
+        sm.p[t] = vmul(v, m);
     }
     __syncthreads();
-    float4 acc = f4(A.emb_b[f]);
-    int t0 = n0 + 0 < A.N ? (int)A.rtype[n0 + 0] : 0, t1 = n0 + 1 < A.N ? (int)A.rtype[n0 + 1] : 0;
-    int t2 = n0 + 2 < A.N ? (int)A.rtype[n0 + 2] : 0, t3 = n0 + 3 < A.N ? (int)A.rtype[n0 + 3] : 0;
-    acc = add4(acc, make_float4(A.embT[t0 * 128 + f], A.embT[t1 * 128 + f], A.embT[t2 * 128 + f], A.embT[t3 * 128 + f]));
+    VN acc = vn(A.emb_b[f]);
+    VN_FOR {
+        const int b = n0 + 4 * gi;
+        const int t0 = b + 0 < A.N ? (int)A.rtype[b + 0] : 0, t1 = b + 1 < A.N ? (int)A.rtype[b + 1] : 0;
+        const int t2 = b + 2 < A.N ? (int)A.rtype[b + 2] : 0, t3 = b + 3 < A.N ? (int)A.rtype[b + 3] : 0;
+        acc.g[gi].x += A.embT[t0 * 128 + f]; acc.g[gi].y += A.embT[t1 * 128 + f];
+        acc.g[gi].z += A.embT[t2 * 128 + f]; acc.g[gi].w += A.embT[t3 * 128 + f];
+    }
 #pragma unroll
-    for (int k = 0; k < 14; k++) acc = fma4(A.embT[(21 + k) * 128 + f], sm.p[k], acc);
+    for (int k = 0; k < 14; k++) acc = vfma(A.embT[(21 + k) * 128 + f], sm.p[k], acc);
     const float *te = A.steps[step].temb;
     float tacc = 0.f;
 #pragma unroll
     for (int k = 0; k < 16; k++) tacc = fmaf(A.embT[(35 + k) * 128 + f], te[k], tacc);
-    return add4(acc, f4(tacc));
+    return vadd(acc, vn(tacc));
 }
 
 __global__ void __launch_bounds__(NT)
 k_node_embed(NodeArgs A, PreW pre0, const float *chi, int step) {
-    __shared__ Smem sm;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    Smem &sm = *reinterpret_cast<Smem *>(smem_raw);
     int flip = 0, rflip = 0;
     const int f = threadIdx.x & 127, ks = threadIdx.x >> 7, n0 = blockIdx.x * NB;
-    float4 v = embed_pre(sm, A, chi, step, n0);
-    float4 h = layernorm4(sm, rflip, v, A.emb_g[f], A.emb_beta[f]);
+    VN v = embed_pre(sm, A, chi, step, n0);
+    VN h = layernorm(sm, rflip, v, A.emb_g[f], A.emb_beta[f]);
     if (ks == 0) {
         store_rows(A.hV, 128, n0, A.N, f, h);
         sm.h[f] = h;
@@ -221,49 +261,50 @@ __device__ __forceinline__ float wrap_pi(float x) {
 
 // small dense layer used by the decoder: width <= 128 outputs, K split over the four ks-groups
 template <int KIN>
-__device__ __forceinline__ float4 dense_small(Smem &sm, int &flip, const float *WT, int width, const float4 *act,
-                                              const float *bias) {
+__device__ __forceinline__ VN dense_small(Smem &sm, int &flip, const float *WT, int width, const VN *act,
+                                          const float *bias) {
     const int f = threadIdx.x & 127, ks = threadIdx.x >> 7;
-    float4 p = f < width ? dense_slice<KIN>(WT, width, f, act, ks) : f4(0.f);
-    float4 r = meet(sm, flip, p, 128, f, ks);
-    return f < width ? add4(r, f4(bias[f])) : f4(0.f);
+    VN p = f < width ? dense_slice<KIN>(WT, width, f, act, ks) : vn(0.f);
+    VN r = meet(sm, flip, p, 128, f, ks);
+    return f < width ? vadd(r, vn(bias[f])) : vn(0.f);
 }
 
 __global__ void __launch_bounds__(NT)
 k_node_update(NodeArgs A, UpdW W, int last_mode, float *chi, int step, int sde, const float *noise, int embed_next,
               PreW pre0) {
-    __shared__ Smem sm;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    Smem &sm = *reinterpret_cast<Smem *>(smem_raw);
     int flip = 0, rflip = 0;
     const int t = threadIdx.x, f = t & 127, ks = t >> 7, n0 = blockIdx.x * NB, N = A.N;
     if (ks == 0) sm.a[f] = load_rows(A.S, 128, n0, N, f);
     __syncthreads();
-    float4 ms = f4(0.f);
-    if (n0 + 0 < N) ms.x = A.msum[n0 + 0];
-    if (n0 + 1 < N) ms.y = A.msum[n0 + 1];
-    if (n0 + 2 < N) ms.z = A.msum[n0 + 2];
-    if (n0 + 3 < N) ms.w = A.msum[n0 + 3];
+    const VN ms = load_rows(A.msum, 1, n0, N, 0);
     // mean_j mask_j (W_out y_j + b) = W_out mean_j(mask_j y_j) + b mean_j(mask_j)
-    float4 m = meet(sm, flip, dense_slice<128>(W.outT, 128, f, sm.a, ks), 128, f, ks);
-    m = add4(m, scale4(ms, W.out_b[f]));
-    float4 h0 = load_rows(A.hV, 128, n0, N, f);
-    float4 h1 = layernorm4(sm, rflip, add4(h0, m), W.g0[f], W.b0[f]);
+    VN m = meet(sm, flip, dense_slice<128>(W.outT, 128, f, sm.a, ks), 128, f, ks);
+    m = vadd(m, vscale(ms, W.out_b[f]));
+    VN h1 = layernorm(sm, rflip, vadd(load_rows(A.hV, 128, n0, N, f), m), W.g0[f], W.b0[f]);
     if (ks == 0) sm.h[f] = h1;
     __syncthreads();
-    // FFN 128 -> 512: each thread builds the ks-th K-quarter of 4 hidden units, then owns hidden unit t
-    {
-        float4 *buf = sm.part[flip];
+    // FFN 128 -> 512 in two halves of 256 hidden units: thread (f, ks) builds the ks-th K-quarter of units f and
+    // f + 128 of the half, then threads 0..255 own one unit each
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+        VN *buf = sm.part[flip];
         flip ^= 1;
 #pragma unroll
-        for (int j = 0; j < 4; j++) buf[ks * 512 + f + 128 * j] = dense_slice<128>(W.ffn_inT, 512, f + 128 * j, sm.h, ks);
+        for (int jx = 0; jx < 2; jx++)
+            buf[ks * 256 + f + 128 * jx] = dense_slice<128>(W.ffn_inT, 512, 256 * half + f + 128 * jx, sm.h, ks);
         __syncthreads();
-        float4 hd = add4(add4(buf[t], buf[512 + t]), add4(buf[1024 + t], buf[1536 + t]));
-        sm.a[t] = relu4(add4(hd, f4(W.ffn_in_b[t])));
-        __syncthreads();
+        if (t < 256) {
+            VN hd = vadd(vadd(buf[t], buf[256 + t]), vadd(buf[512 + t], buf[768 + t]));
+            sm.a[256 * half + t] = vrelu(vadd(hd, vn(W.ffn_in_b[256 * half + t])));
+        }
     }
-    float4 o = meet(sm, flip, dense_slice<512>(W.ffn_outT, 128, f, sm.a, ks), 128, f, ks);
-    o = add4(o, f4(W.ffn_out_b[f]));
-    float4 h2 = layernorm4(sm, rflip, add4(h1, o), W.g1[f], W.b1[f]);
-    h2 = mul4(h2, load_rows(A.rmask, 1, n0, N, 0));
+    __syncthreads();
+    VN o = meet(sm, flip, dense_slice<512>(W.ffn_outT, 128, f, sm.a, ks), 128, f, ks);
+    o = vadd(o, vn(W.ffn_out_b[f]));
+    VN h2 = layernorm(sm, rflip, vadd(h1, o), W.g1[f], W.b1[f]);
+    h2 = vmul(h2, load_rows(A.rmask, 1, n0, N, 0));
     if (ks == 0) {
         store_rows(A.hV, 128, n0, N, f, h2);
         sm.h[f] = h2;
@@ -275,13 +316,13 @@ k_node_update(NodeArgs A, UpdW W, int last_mode, float *chi, int step, int sde, 
         return;
     }
     // decoder: 128 -> 64 -> 32 -> relu -> 16 -> 4
-    float4 v = relu4(dense_small<128>(sm, flip, W.d0_inT, 64, sm.h, W.d0_in_b));
+    VN v = vrelu(dense_small<128>(sm, flip, W.d0_inT, 64, sm.h, W.d0_in_b));
     if (ks == 0 && f < 64) sm.a[f] = v;
     __syncthreads();
-    v = relu4(dense_small<64>(sm, flip, W.d0_outT, 32, sm.a, W.d0_out_b));
+    v = vrelu(dense_small<64>(sm, flip, W.d0_outT, 32, sm.a, W.d0_out_b));
     if (ks == 0 && f < 32) sm.a[64 + f] = v;
     __syncthreads();
-    v = relu4(dense_small<32>(sm, flip, W.d2_inT, 16, sm.a + 64, W.d2_in_b));
+    v = vrelu(dense_small<32>(sm, flip, W.d2_inT, 16, sm.a + 64, W.d2_in_b));
     if (ks == 0 && f < 16) sm.a[96 + f] = v;
     __syncthreads();
     v = dense_small<16>(sm, flip, W.d2_outT, 4, sm.a + 96, W.d2_out_b);
@@ -291,13 +332,13 @@ k_node_update(NodeArgs A, UpdW W, int last_mode, float *chi, int step, int sde, 
     }
     __syncthreads();
     if (last_mode != PP_NU_STEP) return;
-    // reverse step on (node i, chi k) = 16 threads
-    if (t < 16) {
+    // reverse step on (residue i, chi k) = 4 NB threads
+    if (t < 4 * NB) {
         int i = t >> 2, k = t & 3, n = n0 + i;
         if (n < N) {
-            const StepParams sp = A.steps[step];
+            const StepParams &sp = A.steps[step];
             float x = chi[(size_t)n * 4 + k];
-            float sw = comp(sm.a[112 + k], i) * sp.w;
+            float sw = vcomp(sm.a[112 + k], i) * sp.w;
             bool m1 = A.m1pi[(size_t)n * 4 + k] != 0, m2 = A.m2pi[(size_t)n * 4 + k] != 0;
             float y = x;
             if (!sde) {
@@ -314,8 +355,8 @@ k_node_update(NodeArgs A, UpdW W, int last_mode, float *chi, int step, int sde, 
     }
     __syncthreads();
     if (!embed_next) return;
-    float4 e = embed_pre(sm, A, chi, step + 1, n0);
-    float4 h = layernorm4(sm, rflip, e, A.emb_g[f], A.emb_beta[f]);
+    VN e = embed_pre(sm, A, chi, step + 1, n0);
+    VN h = layernorm(sm, rflip, e, A.emb_g[f], A.emb_beta[f]);
     if (ks == 0) {
         store_rows(A.hV, 128, n0, N, f, h);
         sm.h[f] = h;
@@ -359,16 +400,32 @@ static PreW make_pre(const pp_plan *p, int layer, bool edge) {
     return w;
 }
 
+static pp_status node_attrs() {
+    static bool done = false;
+    if (!done) {
+        PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_node_embed),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Smem)));
+        PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_node_update),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Smem)));
+        done = true;
+    }
+    return PP_OK;
+}
+
 pp_status pp_launch_node_embed(pp_ctx *c, const float *chi, int step, hipStream_t s) {
+    pp_status st = node_attrs();
+    if (st != PP_OK) return st;
     NodeArgs A = make_args(c);
     PreW pre0 = make_pre(c->plan, 0, false);
-    hipLaunchKernelGGL(k_node_embed, dim3((c->N + NB - 1) / NB), dim3(NT), 0, s, A, pre0, chi, step);
+    hipLaunchKernelGGL(k_node_embed, dim3((c->N + NB - 1) / NB), dim3(NT), sizeof(Smem), s, A, pre0, chi, step);
     PP_HIP_CHECK(hipGetLastError());
     return PP_OK;
 }
 
 pp_status pp_launch_node_update(pp_ctx *c, int layer, int last_mode, float *chi, int step, int mode,
                                 const float *noise, hipStream_t s) {
+    pp_status st0 = node_attrs();
+    if (st0 != PP_OK) return st0;
     const pp_plan *p = c->plan;
     const LayerOff &o = p->off.layer[layer];
     const LayerT &t = p->lt[layer];
@@ -390,7 +447,7 @@ pp_status pp_launch_node_update(pp_ctx *c, int layer, int last_mode, float *chi,
     int embed_next = (last_mode == PP_NU_STEP && step >= 0) ? 1 : 0;
     int st = step;
     if (last_mode == PP_NU_STEP && step < 0) { st = -step - 1; embed_next = 0; }
-    hipLaunchKernelGGL(k_node_update, dim3((c->N + NB - 1) / NB), dim3(NT), 0, s, A, W, last_mode, chi, st,
+    hipLaunchKernelGGL(k_node_update, dim3((c->N + NB - 1) / NB), dim3(NT), sizeof(Smem), s, A, W, last_mode, chi, st,
                        mode == PP_MODE_SDE ? 1 : 0, noise, embed_next, pre0);
     PP_HIP_CHECK(hipGetLastError());
     return PP_OK;
