@@ -93,8 +93,13 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")       # "nccl" IS RCCL on ROCm; gloo only for rehearsals
+        local_rank %= max(torch.cuda.device_count(), 1)                # rehearsal of N ranks on fewer GPUs
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))   # RCCL over xGMI
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))   # RCCL over xGMI
+        else:
+            dist.init_process_group(backend=backend)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
