@@ -73,6 +73,19 @@ def cpu_baseline(batch, init, weights, n_sample_steps):
                       f"scaled x{N_DIFFUSION_STEPS / n_sample_steps:g}"}
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC summary of this same command (tools/profile/run_profiles.sh;
+    counters cannot be read from inside the process).  None when no summary is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return None
+    try:
+        return json.load(open(files[-1]))["kernels"][kernel]["hbm_bytes"]
+    except (KeyError, ValueError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -192,7 +205,10 @@ def main():
                        "residues_per_gpu": residues, "mode": "ode"},
             "roofline": {"bound": "mfma", "kernel": "k_edge_update", "achieved": achieved,
                          "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
-                         "traffic": None, "kernel_ms": t_edge * 1e3,
+                         "traffic": pmc_traffic("k_edge_update") if args.workload == "t1124" else None,
+                         "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate --pmc "
+                                         "passes of this command; profiles/*_pmc_traffic.json)",
+                         "kernel_ms": t_edge * 1e3,
                          "algorithmic_flop_per_launch": EDGE_UPDATE_FLOP_PER_EDGE * n_edges,
                          "node_message_kernel_ms": t_node * 1e3,
                          "node_message_tflops": NODE_MSG_FLOP_PER_EDGE * n_edges / t_node / 1e12},
