@@ -126,6 +126,15 @@ pp_status pp_proximal(pp_ctx *ctx, const float *chi, float lamda, int num_steps,
  * around `iters` launches.  Synchronises the stream. */
 pp_status pp_time_kernel(pp_ctx *ctx, int which, int iters, float *avg_ms, void *stream);
 
+/* Measurement aid, no reference counterpart: in-situ duration of a hot kernel.  After
+ * pp_profile_kernel(ctx, which) (0 node message, 1 edge update, 2 node update) every launch of that
+ * kernel made by pp_score / pp_sample is bracketed by a pair of HIP events on the launch stream;
+ * pp_profile_read waits for the last one, returns the summed intervals (ms) less the measured
+ * interval of an empty event pair per launch, and the number of launches, and switches profiling
+ * off again. */
+pp_status pp_profile_kernel(pp_ctx *ctx, int which);
+pp_status pp_profile_read(pp_ctx *ctx, float *total_ms, int *launches);
+
 #ifdef __cplusplus
 }
 #endif

@@ -211,6 +211,7 @@ extern "C" void pp_ctx_destroy(pp_ctx *c) {
                     c->per_res, c->dchi, c->px, c->pm, c->pv, c->pz, c->pxeff, c->pmask, c->scal, c->dbg};
     for (void *q : ptrs) if (q) hipFree(q);
     if (c->steps_host) hipHostFree(c->steps_host);
+    for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
     delete c;
 }
 
@@ -305,18 +306,43 @@ static void fill_step(StepParams *sp, float t, float dt) {
     sp->c_diff = g * sqrtf(dt);
 }
 
+// RAII-less bracket for pp_profile_kernel: records an event on `s` when kernel class `which` is being profiled.
+static inline void prof_mark(pp_ctx *c, int which, hipStream_t s) {
+    if (c->prof_which != which) return;
+    if (c->prof_n == c->prof_ev.size()) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return;
+        c->prof_ev.push_back(e);
+    }
+    (void)hipEventRecord(c->prof_ev[c->prof_n++], s);
+    c->prof_stream = s;
+    c->prof_stream_valid = true;
+}
+
 static pp_status run_network(pp_ctx *c, hipStream_t s, int step, int last_mode, float *chi, int mode, const float *noise,
                              bool embed_next) {
     pp_status st;
     for (int l = 0; l < 3; l++) {
-        if ((st = pp_launch_node_message(c, l, s)) != PP_OK) return st;
+        prof_mark(c, 0, s);
+        st = pp_launch_node_message(c, l, s);
+        prof_mark(c, 0, s);
+        if (st != PP_OK) return st;
         if (l < 2) {
-            if ((st = pp_launch_node_update(c, l, PP_NU_MID, chi, step, mode, noise, s)) != PP_OK) return st;
-            if ((st = pp_launch_edge_update(c, l, s)) != PP_OK) return st;
+            prof_mark(c, 2, s);
+            st = pp_launch_node_update(c, l, PP_NU_MID, chi, step, mode, noise, s);
+            prof_mark(c, 2, s);
+            if (st != PP_OK) return st;
+            prof_mark(c, 1, s);
+            st = pp_launch_edge_update(c, l, s);
+            prof_mark(c, 1, s);
+            if (st != PP_OK) return st;
         } else {
             int enc = step;
             if (last_mode == PP_NU_STEP && !embed_next) enc = -step - 1;
-            if ((st = pp_launch_node_update(c, l, last_mode, chi, enc, mode, noise, s)) != PP_OK) return st;
+            prof_mark(c, 2, s);
+            st = pp_launch_node_update(c, l, last_mode, chi, enc, mode, noise, s);
+            prof_mark(c, 2, s);
+            if (st != PP_OK) return st;
         }
     }
     return PP_OK;
@@ -417,6 +443,52 @@ extern "C" pp_status pp_time_kernel(pp_ctx *c, int which, int iters, float *avg_
     hipEventDestroy(e1);
     *avg_ms = ms / (float)iters;
     return st;
+}
+
+// Measurement aid (bench.py): in-situ duration of one hot kernel.  After pp_profile_kernel(ctx, which) every launch of
+// that kernel inside pp_score / pp_sample is bracketed by a pair of HIP events on the launch stream;
+// pp_profile_read synchronises, sums the pair intervals, reports (total ms, launches) and switches profiling off.
+extern "C" pp_status pp_profile_kernel(pp_ctx *c, int which) {
+    if (!c || which < 0 || which > 2) FAIL(PP_ERR_INVALID, "pp_profile_kernel: which must be 0 (node message), 1 (edge update) or 2 (node update)");
+    c->prof_which = which;
+    c->prof_n = 0;
+    return PP_OK;
+}
+
+extern "C" pp_status pp_profile_read(pp_ctx *c, float *total_ms, int *launches) {
+    if (!c || !total_ms || !launches) FAIL(PP_ERR_INVALID, "pp_profile_read: null argument");
+    PP_HIP_CHECK(hipSetDevice(c->plan->device));
+    double tot = 0.0;
+    size_t pairs = c->prof_n / 2;
+    if (pairs) PP_HIP_CHECK(hipEventSynchronize(c->prof_ev[2 * pairs - 1]));
+    for (size_t i = 0; i < pairs; i++) {
+        float ms = 0.f;
+        PP_HIP_CHECK(hipEventElapsedTime(&ms, c->prof_ev[2 * i], c->prof_ev[2 * i + 1]));
+        tot += ms;
+    }
+    // the interval of an EMPTY event pair on the same stream is the bracket's own cost: measure and remove it
+    if (pairs && c->prof_stream_valid) {
+        hipEvent_t e[18];
+        int made = 0;
+        for (; made < 18; made++) if (hipEventCreate(&e[made]) != hipSuccess) break;
+        if (made == 18) {
+            for (int i = 0; i < 18; i++) (void)hipEventRecord(e[i], c->prof_stream);
+            (void)hipEventSynchronize(e[17]);
+            double empty = 0.0;
+            for (int i = 1; i < 9; i++) {            // first pair discarded (cold)
+                float ms = 0.f;
+                (void)hipEventElapsedTime(&ms, e[2 * i], e[2 * i + 1]);
+                empty += ms;
+            }
+            tot -= empty / 8.0 * (double)pairs;
+        }
+        for (int i = 0; i < made; i++) (void)hipEventDestroy(e[i]);
+    }
+    *total_ms = (float)tot;
+    *launches = (int)pairs;
+    c->prof_which = -1;
+    c->prof_n = 0;
+    return PP_OK;
 }
 
 // Diagnostic builds (-DPP_X_STAMP, env PP_STAMP=1): copy the s_memtime stamps of the last edge-kernel launch to the host.

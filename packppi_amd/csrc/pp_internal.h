@@ -1,6 +1,7 @@
 // Internal declarations shared by the HIP translation units of libpackppi_hip.so (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <vector>
 #include <stdint.h>
 #include <string>
 
@@ -103,6 +104,12 @@ struct pp_ctx {
     uint8_t *pmask;           // [N]
     float *scal;              // small scalar scratch
     unsigned long long *dbg;  // stamp buffer of PP_X_STAMP diagnostic builds (else unused)
+    // in-situ kernel timing (pp_profile_kernel): event pairs recorded around every launch of one hot kernel
+    int prof_which = -1;       // -1 off, 0 node message, 1 edge update, 2 node update
+    std::vector<hipEvent_t> prof_ev;
+    size_t prof_n = 0;         // events used (2 per launch)
+    hipStream_t prof_stream = nullptr;
+    bool prof_stream_valid = false;
 };
 
 void pp_set_error(const std::string &msg);

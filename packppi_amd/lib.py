@@ -17,7 +17,7 @@ _lib = None
 
 SYMBOLS = ("pp_version", "pp_last_error", "pp_plan_create", "pp_plan_destroy", "pp_plan_set_clash_params",
            "pp_complex_prepare", "pp_ctx_destroy", "pp_ctx_get_graph", "pp_score", "pp_sample", "pp_atom14",
-           "pp_clash", "pp_proximal", "pp_time_kernel")
+           "pp_clash", "pp_proximal", "pp_time_kernel", "pp_profile_kernel", "pp_profile_read")
 
 
 class PPTables(C.Structure):
@@ -59,6 +59,8 @@ def load():
     lib.pp_clash.argtypes = [vp, vp, vp, vp, vp]
     lib.pp_proximal.argtypes = [vp, vp, f, i, vp, vp, vp, vp]
     lib.pp_time_kernel.argtypes = [vp, i, i, C.POINTER(C.c_float), vp]
+    lib.pp_profile_kernel.argtypes = [vp, i]
+    lib.pp_profile_read.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int)]
     _lib = lib
     return lib
 
@@ -220,6 +222,16 @@ class Context:
         _check(load().pp_time_kernel(self.handle, int(which), int(iters), C.byref(ms), _stream(self.plan.device)),
                "pp_time_kernel")
         return float(ms.value)
+
+    def profile_kernel(self, which: int):
+        """Bracket every later launch of kernel `which` (0 node message, 1 edge update, 2 node update) with HIP events."""
+        _check(load().pp_profile_kernel(self.handle, int(which)), "pp_profile_kernel")
+
+    def profile_read(self):
+        """(average ms per launch, launches) since profile_kernel(); switches profiling off."""
+        ms, n = C.c_float(0.0), C.c_int(0)
+        _check(load().pp_profile_read(self.handle, C.byref(ms), C.byref(n)), "pp_profile_read")
+        return (float(ms.value) / max(n.value, 1), int(n.value))
 
     def __del__(self):
         h = getattr(self, "handle", None)
