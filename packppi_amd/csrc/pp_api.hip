@@ -66,13 +66,23 @@ static size_t put_T(std::vector<float> &arena, const float *W, int rows, int ld,
     return at;
 }
 
-// append the [128 rows][ncols] block of W (row stride ld) starting at (row0, col0), row-major contiguous
+// Append one weight chunk = the [128 rows][ncols] block of W (row stride ld) at (row0, col0), packed for the edge
+// kernels' wave-private LDS-DMA pipeline (pp_edge.hip): [wave 4][quad 4][lane 64][4 floats], where lane = (row & 31,
+// half h) of wave row >> 5 holds the A-operand registers of MFMA steps 4q..4q+3:
+//   ncols == 32:  W[row][col0 + 8 q + 4 h + p]                 (k-order F of the accumulator layout)
+//   ncols == 24:  W[row][col0 + 12 h + 4 q + p], quad 3 = 0    (geometry chunks: half h feeds inputs 12 h .. 12 h + 11)
 static void put_chunk(std::vector<float> &arena, const float *W, int ld, int row0, int col0, int ncols) {
     size_t at = arena.size();
-    arena.resize(at + (size_t)128 * ncols);
+    arena.resize(at + (size_t)128 * 32, 0.f);
     float *d = arena.data() + at;
-    for (int r = 0; r < 128; r++)
-        for (int c = 0; c < ncols; c++) d[(size_t)r * ncols + c] = W[(size_t)(row0 + r) * ld + col0 + c];
+    for (int wave = 0; wave < 4; wave++)
+        for (int q = 0; q < (ncols == 32 ? 4 : 3); q++)
+            for (int lane = 0; lane < 64; lane++)
+                for (int pp = 0; pp < 4; pp++) {
+                    int row = 32 * wave + (lane & 31), h = lane >> 5;
+                    int col = ncols == 32 ? 8 * q + 4 * h + pp : 12 * h + 4 * q + pp;
+                    d[((wave * 4 + q) * 64 + lane) * 4 + pp] = W[(size_t)(row0 + row) * ld + col0 + col];
+                }
 }
 // chunk stream of one message MLP: W_in[:,128:256] x4, W_in[:,384:456] x3 (24 cols), W_mid x4 [, W_out x4, FFN blocks]
 static size_t put_stream(std::vector<float> &arena, const float *w, const LayerOff &L, bool edge) {
@@ -89,6 +99,17 @@ static size_t put_stream(std::vector<float> &arena, const float *w, const LayerO
             for (int s = 0; s < 4; s++) put_chunk(arena, w + L.ed_out_w, 512, 0, 128 * c + 32 * s, 32);
         }
     }
+    return at;
+}
+// the edge kernel's small per-layer vectors in one block (staged to LDS once per workgroup):
+// b_mid | b_out | ffn_out_b | g2 | be2 | g3 | be3 | ffn_in_b[512]   (1408 floats)
+static size_t put_edge_params(std::vector<float> &arena, const float *w, const LayerOff &L) {
+    size_t at = (arena.size() + 3) & ~size_t(3);
+    arena.resize(at);
+    auto app = [&](size_t off, int n) { arena.insert(arena.end(), w + off, w + off + n); };
+    app(L.em_mid_b, 128); app(L.em_out_b, 128); app(L.ed_out_b, 128);
+    app(L.norm_g[2], 128); app(L.norm_b[2], 128); app(L.norm_g[3], 128); app(L.norm_b[3], 128);
+    app(L.ed_in_b, 512);
     return at;
 }
 
@@ -130,7 +151,7 @@ extern "C" pp_status pp_plan_create(const float *weights, size_t n_weights, cons
     arena.reserve(3u << 20);
     size_t o_node_emb = put_T(arena, weights + off.node_emb_w, 128, 51, 0, 51);
     size_t o_edge_emb = put_T(arena, weights + off.edge_emb_w, 128, 468, 0, 468);
-    size_t o_l[3][11];
+    size_t o_l[3][12];
     for (int l = 0; l < 3; l++) {
         const LayerOff &L = off.layer[l];
         o_l[l][0] = put_T(arena, weights + L.pts_node_w, 24, 128, 0, 128);
@@ -144,6 +165,7 @@ extern "C" pp_status pp_plan_create(const float *weights, size_t n_weights, cons
         o_l[l][8] = put_T(arena, weights + L.nd_out_w, 128, 512, 0, 512);
         o_l[l][9] = put_stream(arena, weights, L, false);
         o_l[l][10] = put_stream(arena, weights, L, true);
+        o_l[l][11] = put_edge_params(arena, weights, L);
     }
     size_t o_d0i = put_T(arena, weights + off.d0_in_w, 64, 128, 0, 128);
     size_t o_d0o = put_T(arena, weights + off.d0_out_w, 32, 64, 0, 64);
@@ -160,6 +182,7 @@ extern "C" pp_status pp_plan_create(const float *weights, size_t n_weights, cons
         t.nm_out_T = p->wT + o_l[l][6];
         t.nd_in_T = p->wT + o_l[l][7]; t.nd_out_T = p->wT + o_l[l][8];
         t.nm_stream = p->wT + o_l[l][9]; t.em_stream = p->wT + o_l[l][10];
+        t.em_params = p->wT + o_l[l][11];
     }
     p->d0_in_T = p->wT + o_d0i; p->d0_out_T = p->wT + o_d0o;
     p->d2_in_T = p->wT + o_d2i; p->d2_out_T = p->wT + o_d2o;

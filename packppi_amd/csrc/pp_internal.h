@@ -39,6 +39,7 @@ struct LayerT {
     const float *nd_in_T;                            // [128][512]
     const float *nd_out_T;                           // [512][128]
     const float *nm_stream, *em_stream;              // MFMA weight chunks packed in consumption order (pp_edge.hip)
+    const float *em_params;                          // edge kernel small vectors, one block
 };
 
 struct pp_plan {

@@ -26,15 +26,19 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 #define ET 256
-#define CH32 (128 * 32)                 // floats per packed weight chunk (16 KB); a wave's quarter is 1024 floats
+#define WBUF_FLOATS (128 * 36)          // one weight chunk slot, row stride 36 (32 cols) or 28 (24 cols)
 #define XBUF_FLOATS (4 * 4 * 64 * 4)    // exchange buffer: [tile][quad][lane] float4
-#define PARAM_FLOATS 1536               // edge kernel: small per-layer vectors staged once (1408 used)
 
-// Timing-only ablation switch (tools/debug/ablate_edge.py); never defined in a shipped build.
+// Timing-only ablation switches (tools/debug/ablate_edge.py); never defined in a shipped build.
 #ifdef PP_X_NOMFMA
 #define MFMA(a, b, c) ((c) + (a) * (b))
 #else
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+#endif
+#ifdef PP_X_NOBARRIER
+#define STAGE_SYNC() __builtin_amdgcn_sched_barrier(0)
+#else
+#define STAGE_SYNC() __syncthreads()
 #endif
 
 struct EdgeArgs {
@@ -49,43 +53,54 @@ struct EdgeArgs {
     const float *hE_in;        // [N][K][128]
     float *hE_out;             // [N][K][128]   (edge kernel)
     float *S, *msum;           // node kernel outputs
-    const float *wstream;      // this kernel's weight chunks, packed in consumption order (pp_api.hip put_chunk)
-    const float *params;       // edge kernel: b_mid | b_out | ffn_out_b | g2 | be2 | g3 | be3 | ffn_in_b[512]
-    const float *b_mid;        // node kernel (per-lane read)
+    const float *wstream;      // this kernel's weight chunks, packed in consumption order
+    const float *b_mid, *b_out;
+    const float *g2, *be2, *g3, *be3;
+    const float *ffn_in_b, *ffn_out_b;
+    unsigned long long *dbg;   // PP_X_STAMP builds only: [N][4 waves][64 stages][4 stamps]
 };
-enum { P_BMID = 0, P_BOUT = 128, P_FOB = 256, P_G2 = 384, P_BE2 = 512, P_G3 = 640, P_BE3 = 768, P_FIB = 896 };
 
-// ---- weight pipeline: LDS-DMA, private to each wave ------------------------------------------------------------
-// Wave w only ever needs rows 32w..32w+31 of a weight chunk (its output tile), so its quarter of every chunk is
-// packed (pp_plan_create) as [quad q][lane][4 floats] = exactly the A-operand registers of 16 MFMAs: one 4 KB piece,
-// copied global -> LDS by four `global_load_lds_dwordx4` (1 KB each, no VGPRs, no ds_write) into a per-wave ring of S
-// slots and read back lane-linear (conflict-free ds_read_b128).  No other wave touches the slot, so the only
-// ordering needed is this wave's own counted s_waitcnt vmcnt (MI355X_MICROARCH.md, co-residence item 7): the weight
-// stream needs NO workgroup barrier; barriers remain only around the activation exchange buffer.
-// hipcc does not count these loads: between the prologue and the epilogue the kernels issue no ordinary global
-// loads (every small vector is staged to LDS or registers up front), so no compiler-made vmcnt(0) drains the ring.
-__device__ __forceinline__ void dma_chunk(const float *gsrc_lane, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile("s_waitcnt lgkmcnt(0)\n\t"          // this wave's reads of the slot being refilled have returned
-                 "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
-                 "global_load_lds_dwordx4 %1, off\n\t"
-                 "global_load_lds_dwordx4 %1, off offset:1024\n\t"
-                 "global_load_lds_dwordx4 %1, off offset:2048\n\t"
-                 "global_load_lds_dwordx4 %1, off offset:3072\n\t"
-                 "s_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc_lane), "s"(lds_dst) : "memory");
+// one weight chunk in flight through registers: [128 rows][NC cols], NC = 32 (4 float4 per thread) or 24 (3)
+struct WRegs {
+    f32x4v v[4];
+};
+
+// The weight chunks are pre-packed (pp_plan_create) in the order the kernel consumes them, each [128 rows][NC cols]
+// chunk contiguous: a chunk is one linear 16 KB (12 KB) read that spreads over every L2 channel.  (Reading the chunks
+// in place from the [out][in] matrices put all 128 rows of a chunk of the 2 KB-stride FFN matrix on one or two
+// channels and made the kernel L2-bound.)   global chunk -> registers -> LDS (row stride NC + 4)
+template <int NC>
+__device__ __forceinline__ void chunk_load(const float *__restrict__ g, WRegs &r, int tid) {
+    constexpr int PER_ROW = NC / 4, PER_T = (128 * PER_ROW) / ET;
+    static_assert((128 * PER_ROW) % ET == 0 && PER_T <= 4, "chunk shape");
+#ifdef PP_X_NOLOAD
+    for (int m = 0; m < PER_T; m++) r.v[m] = f32x4v{0.001f * tid, 0.f, 0.f, 0.f};
+    return;
+#endif
+#pragma unroll
+    for (int m = 0; m < PER_T; m++) r.v[m] = *reinterpret_cast<const f32x4v *>(g + 4 * (tid + ET * m));
 }
-template <int N>
-__device__ __forceinline__ void wait_vm() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+template <int NC>
+__device__ __forceinline__ void chunk_store(float *lds, const WRegs &r, int tid) {
+    constexpr int PER_ROW = NC / 4, PER_T = (128 * PER_ROW) / ET;
+#ifdef PP_X_NOSTORE
+    return;
+#endif
+#pragma unroll
+    for (int m = 0; m < PER_T; m++) {
+        int idx = tid + ET * m;
+        int row = idx / PER_ROW, c4 = idx - row * PER_ROW;
+        *reinterpret_cast<f32x4v *>(lds + row * (NC + 4) + 4 * c4) = r.v[m];
+    }
 }
 
 // acc += W[32 wave .. +32, chunk cols] * x     (SWAP: acc += x * W^T, edges on rows / features on lanes)
 template <bool SWAP>
-__device__ __forceinline__ void mfma_tile32(const float *wslot, const f32x16 &x, f32x16 &acc, int lane) {
+__device__ __forceinline__ void mfma_tile32(const float *lds, int wave, const f32x16 &x, f32x16 &acc, int lane) {
+    const float *base = lds + (32 * wave + (lane & 31)) * 36 + 4 * (lane >> 5);
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-        f32x4v a = *reinterpret_cast<const f32x4v *>(wslot + (q * 64 + lane) * 4);
+        f32x4v a = *reinterpret_cast<const f32x4v *>(base + 8 * q);
 #pragma unroll
         for (int p = 0; p < 4; p++) {
             if (SWAP) acc = MFMA(x[4 * q + p], a[p], acc);
@@ -94,11 +109,12 @@ __device__ __forceinline__ void mfma_tile32(const float *wslot, const f32x16 &x,
     }
 }
 
-// geometry chunk: 24 inputs = 12 k-steps; lane half h supplies input 12 h + m at step m (quad 3 of the slot is padding)
-__device__ __forceinline__ void mfma_tile24(const float *wslot, const float (&g)[12], f32x16 &acc, int lane) {
+// geometry chunk: 24 inputs = 12 k-steps; lane half h supplies input 12 h + m at step m
+__device__ __forceinline__ void mfma_tile24(const float *lds, int wave, const float (&g)[12], f32x16 &acc, int lane) {
+    const float *base = lds + (32 * wave + (lane & 31)) * 28 + 12 * (lane >> 5);
 #pragma unroll
     for (int q = 0; q < 3; q++) {
-        f32x4v a = *reinterpret_cast<const f32x4v *>(wslot + (q * 64 + lane) * 4);
+        f32x4v a = *reinterpret_cast<const f32x4v *>(base + 4 * q);
 #pragma unroll
         for (int p = 0; p < 4; p++) acc = MFMA(a[p], g[4 * q + p], acc);
     }
@@ -213,72 +229,95 @@ __device__ __forceinline__ void edge_geometry(const float *__restrict__ pts_i, c
         for (int m = 0; m < 12; m++) g[c][m] = h ? geom[24 * c + 12 + m] : geom[24 * c + m];
 }
 
-// Stage k of a kernel with NCH chunks: refill the slot freed by stage k-1 with chunk k+S-1, wait until chunk k has
-// landed (all but the younger chunks' DMAs retired), compute on it.
-#define WSTAGE(k, NCH, BODY)                                                                                   \
-    {                                                                                                          \
-        if constexpr ((k) + S - 1 < (NCH))                                                                     \
-            dma_chunk(wsl + (size_t)((k) + S - 1) * CH32, slot0 + (((k) + S - 1) % S) * 4096u);                \
-        wait_vm<4 * (((NCH) - 1 - (k)) < (S - 1) ? ((NCH) - 1 - (k)) : (S - 1))>();                            \
-        const float *wslot = wl + ((k) % S) * 1024;                                                            \
-        BODY;                                                                                                  \
+// Weight pipeline, prefetch distance 2: at the start of stage k chunk k is visible in LDS slot k&1 and chunk k+1 is in
+// flight into one register set.  The stage issues the loads of chunk k+2 into the other set, computes on chunk k,
+// then publishes chunk k+1 into the other LDS slot (last read one stage ago) and barriers.  A load therefore has two
+// stages of MFMA time to land.  RS / RL name the register sets stored / loaded in this stage (they alternate).
+#ifdef PP_X_STAMP
+#define STAMP(i)                                                                                        \
+    {                                                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                              \
+        unsigned long long _t = __builtin_amdgcn_s_memtime();                                           \
+        if (lane == 0 && stage_no < 64) A.dbg[(((size_t)n * 4 + wave) * 64 + stage_no) * 4 + (i)] = _t; \
+        __builtin_amdgcn_sched_barrier(0);                                                              \
     }
+#define NEXT_STAGE() stage_no++
+#else
+#define STAMP(i)
+#define NEXT_STAGE()
+#endif
+#define STAGE2(COMPUTE, RS, RS_NC, RL, RL_NC, RL_PTR)                      \
+    {                                                                      \
+        STAMP(0)                                                           \
+        chunk_load<RL_NC>((RL_PTR), RL, tid);                              \
+        { COMPUTE; }                                                       \
+        STAMP(1)                                                           \
+        chunk_store<RS_NC>(cur ? wbuf0 : wbuf1, RS, tid);                  \
+        STAMP(2)                                                           \
+        STAGE_SYNC();                                                      \
+        STAMP(3)                                                           \
+        NEXT_STAGE();                                                      \
+        cur ^= 1;                                                          \
+    }
+// last stages of a kernel: nothing further to load
+#define STAGE2_NOLOAD(COMPUTE, RS, RS_NC)                                  \
+    {                                                                      \
+        { COMPUTE; }                                                       \
+        chunk_store<RS_NC>(cur ? wbuf0 : wbuf1, RS, tid);                  \
+        STAGE_SYNC();                                                      \
+        cur ^= 1;                                                          \
+    }
+#define CURBUF (cur ? wbuf1 : wbuf0)
 
-// shared first layer (chunks 0..6 = W_B x4, W_G x3): acc (tile `wave`) = PA_i + PC_j + W_B h_E + W_G geom, ReLU
-#define FIRST_LAYER(NCH)                                                      \
-    WSTAGE(0, NCH, mfma_tile32<false>(wslot, x[0], acc, lane))                \
-    WSTAGE(1, NCH, mfma_tile32<false>(wslot, x[1], acc, lane))                \
-    WSTAGE(2, NCH, mfma_tile32<false>(wslot, x[2], acc, lane))                \
-    WSTAGE(3, NCH, mfma_tile32<false>(wslot, x[3], acc, lane))                \
-    WSTAGE(4, NCH, mfma_tile24(wslot, g[0], acc, lane))                       \
-    WSTAGE(5, NCH, mfma_tile24(wslot, g[1], acc, lane))                       \
-    WSTAGE(6, NCH, mfma_tile24(wslot, g[2], acc, lane))                       \
-    relu_tile(acc);                                                           \
-    xbuf_put(xbuf, wave, lane, acc);                                          \
-    __syncthreads();
+// Stream offsets (floats) of chunk k: chunks 0..3 are 32 columns wide, 4..6 (geometry) 24, the rest 32.
+#define CH32 (128 * 32)
+#define CH24 (128 * 24)
+#define CHUNK_OFF(k) ((k) < 4 ? (k) * CH32 : ((k) < 7 ? 4 * CH32 + ((k) - 4) * CH24 : 4 * CH32 + 3 * CH24 + ((k) - 7) * CH32))
 
-#define PROLOGUE_PIPE()                                                                        \
-    const float *wsl = A.wstream + wave * 1024 + lane * 4;                                     \
-    const float *wl = smem + wave * (S * 1024);                                                \
-    const unsigned slot0 = (unsigned)(size_t)wl;                                               \
-    _Pragma("unroll") for (int pk = 0; pk < S - 1; pk++) dma_chunk(wsl + (size_t)pk * CH32, slot0 + pk * 4096u);
+// shared first layer (chunks 0..6 = W_B x4, W_G x3): acc (tile `wave`) = PA_i + PC_j + W_B h_E + W_G geom, ReLU,
+// published to xbuf.  On exit: chunk 7 visible in LDS, chunk 8 in flight in RA.
+#define FIRST_LAYER()                                                                                     \
+    chunk_load<32>(ws + CHUNK_OFF(0), RA, tid);                                                           \
+    chunk_store<32>(wbuf0, RA, tid);                                                                      \
+    chunk_load<32>(ws + CHUNK_OFF(1), RB, tid);                                                           \
+    __syncthreads();                                                                                      \
+    STAGE2(mfma_tile32<false>(CURBUF, wave, x[0], acc, lane), RB, 32, RA, 32, ws + CHUNK_OFF(2))          \
+    STAGE2(mfma_tile32<false>(CURBUF, wave, x[1], acc, lane), RA, 32, RB, 32, ws + CHUNK_OFF(3))          \
+    STAGE2(mfma_tile32<false>(CURBUF, wave, x[2], acc, lane), RB, 32, RA, 24, ws + CHUNK_OFF(4))          \
+    STAGE2(mfma_tile32<false>(CURBUF, wave, x[3], acc, lane), RA, 24, RB, 24, ws + CHUNK_OFF(5))          \
+    /* x[] is dead from here to the exchange: build the 72 point features in its place */                \
+    edge_geometry(A.pts + (size_t)n * 48, A.frames + (size_t)n * 12, A.pts + (size_t)nbr * 48, h, g);     \
+    STAGE2(mfma_tile24(CURBUF, wave, g[0], acc, lane), RB, 24, RA, 24, ws + CHUNK_OFF(6))                 \
+    STAGE2(mfma_tile24(CURBUF, wave, g[1], acc, lane), RA, 24, RB, 32, ws + CHUNK_OFF(7))                 \
+    STAGE2(mfma_tile24(CURBUF, wave, g[2], acc, lane); relu_tile(acc); xbuf_put(xbuf, wave, lane, acc),   \
+           RB, 32, RA, 32, ws + CHUNK_OFF(8))
 
 // ---------------------------------------------------------------------------------------------
 // node message: S[i] = (1/K) sum_j mask_ij relu(W_mid relu(W_in [..]) + b), msum[i] = (1/K) sum_j mask_ij
 // ---------------------------------------------------------------------------------------------
-template <int S>
 __global__ void __launch_bounds__(ET, 3)
 k_node_message(EdgeArgs A) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *xbuf = smem + 4 * S * 1024;
+    float *wbuf0 = smem, *wbuf1 = smem + WBUF_FLOATS, *xbuf = smem + 2 * WBUF_FLOATS;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, h = lane >> 5;
     const int n = blockIdx.x;
     const int K = A.K;
+    int cur = 0;
+#ifdef PP_X_STAMP
+    int stage_no = 0;
+#endif
     if (A.rmask[n] == 0.f) {              // masked / padded residue: whole workgroup leaves
         if (tid < 128) A.S[(size_t)n * 128 + tid] = 0.f;
         if (tid == 0) A.msum[n] = 0.f;
         return;
     }
-    constexpr int NCH = 11;               // chunks: W_B 0..3, W_G 4..6, W_mid 7..10
-    PROLOGUE_PIPE()
 
     f32x16 x[4], acc;
     float g[3][12];
     const int jj = j < K ? j : K - 1;
     const int nbr = A.eidx[(size_t)n * K + jj];
-    const float bmid = A.b_mid[32 * wave + j];            // SWAP form: feature on the lane
-    float m16[16];
-    {
-        const float *mrow = A.mask_att + (size_t)n * 32;
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            f32x4v mm = *reinterpret_cast<const f32x4v *>(mrow + 8 * q + 4 * h);
-            m16[4 * q] = mm[0]; m16[4 * q + 1] = mm[1]; m16[4 * q + 2] = mm[2]; m16[4 * q + 3] = mm[3];
-        }
-    }
-    edge_geometry(A.pts + (size_t)n * 48, A.frames + (size_t)n * 12, A.pts + (size_t)nbr * 48, h, g);
     {
         const float *hrow = A.hE_in + ((size_t)n * K + jj) * 128;
 #pragma unroll
@@ -286,19 +325,29 @@ k_node_message(EdgeArgs A) {
         load_tile(A.PA + (size_t)n * 128 + 32 * wave, h, acc);
         add_tile(A.PC + (size_t)nbr * 128 + 32 * wave, h, acc);
     }
-    FIRST_LAYER(NCH)
+    const float *ws = A.wstream;          // chunks: W_B 0..3, W_G 4..6, W_mid 7..10
+    WRegs RA, RB;
+    FIRST_LAYER()
     {
 #pragma unroll
         for (int t = 0; t < 4; t++) xbuf_get(xbuf, t, lane, x[t]);
+        const float b = A.b_mid[32 * wave + j];           // SWAP form: feature on the lane
 #pragma unroll
-        for (int r = 0; r < 16; r++) acc[r] = bmid;
+        for (int r = 0; r < 16; r++) acc[r] = b;
     }
-    WSTAGE(7, NCH, mfma_tile32<true>(wslot, x[0], acc, lane))
-    WSTAGE(8, NCH, mfma_tile32<true>(wslot, x[1], acc, lane))
-    WSTAGE(9, NCH, mfma_tile32<true>(wslot, x[2], acc, lane))
-    WSTAGE(10, NCH, mfma_tile32<true>(wslot, x[3], acc, lane))
+    STAGE2(mfma_tile32<true>(CURBUF, wave, x[0], acc, lane), RA, 32, RB, 32, ws + CHUNK_OFF(9))
+    STAGE2(mfma_tile32<true>(CURBUF, wave, x[1], acc, lane), RB, 32, RA, 32, ws + CHUNK_OFF(10))
+    STAGE2_NOLOAD(mfma_tile32<true>(CURBUF, wave, x[2], acc, lane), RA, 32)
     {
+        mfma_tile32<true>(CURBUF, wave, x[3], acc, lane);
         // rows (registers) are edges e = 8 (r>>2) + 4 h + (r&3); mask and reduce over them
+        float m16[16];
+        const float *mrow = A.mask_att + (size_t)n * 32;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            f32x4v mm = *reinterpret_cast<const f32x4v *>(mrow + 8 * q + 4 * h);
+            m16[4 * q] = mm[0]; m16[4 * q + 1] = mm[1]; m16[4 * q + 2] = mm[2]; m16[4 * q + 3] = mm[3];
+        }
         float s = 0.f, ms = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; r++) {
@@ -315,33 +364,20 @@ k_node_message(EdgeArgs A) {
 // ---------------------------------------------------------------------------------------------
 // edge update: h_E <- mask * LN3(x1 + FFN(x1)),  x1 = LN2(h_E + mask * MLP3([..]))
 // ---------------------------------------------------------------------------------------------
-// FFN hidden block c (chunks 15 + 8c ..): W1 s=0..3 -> hidden tile 4c+wave -> exchange -> W2 s'=0..3 accumulate into out
-#define FFN_BLOCK(c)                                                                                         \
-    load_tile(prm + P_FIB + 128 * (c) + 32 * wave, h, acc);                                                  \
-    WSTAGE(15 + 8 * (c) + 0, NCH, mfma_tile32<false>(wslot, x[0], acc, lane))                                \
-    WSTAGE(15 + 8 * (c) + 1, NCH, mfma_tile32<false>(wslot, x[1], acc, lane))                                \
-    WSTAGE(15 + 8 * (c) + 2, NCH, mfma_tile32<false>(wslot, x[2], acc, lane))                                \
-    WSTAGE(15 + 8 * (c) + 3, NCH, mfma_tile32<false>(wslot, x[3], acc, lane))                                \
-    relu_tile(acc);                                                                                          \
-    __syncthreads();          /* every wave is done reading the previous exchange */                        \
-    xbuf_put(xbuf, wave, lane, acc);                                                                         \
-    __syncthreads();                                                                                         \
-    WSTAGE(15 + 8 * (c) + 4, NCH, xbuf_get(xbuf, 0, lane, acc); mfma_tile32<false>(wslot, acc, out, lane))   \
-    WSTAGE(15 + 8 * (c) + 5, NCH, xbuf_get(xbuf, 1, lane, acc); mfma_tile32<false>(wslot, acc, out, lane))   \
-    WSTAGE(15 + 8 * (c) + 6, NCH, xbuf_get(xbuf, 2, lane, acc); mfma_tile32<false>(wslot, acc, out, lane))   \
-    WSTAGE(15 + 8 * (c) + 7, NCH, xbuf_get(xbuf, 3, lane, acc); mfma_tile32<false>(wslot, acc, out, lane))
-
-template <int S>
 __global__ void __launch_bounds__(ET, 2)
 k_edge_update(EdgeArgs A) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *xbuf = smem + 4 * S * 1024, *prm = xbuf + XBUF_FLOATS;
+    float *wbuf0 = smem, *wbuf1 = smem + WBUF_FLOATS, *xbuf = smem + 2 * WBUF_FLOATS;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, h = lane >> 5;
     const int n = blockIdx.x;
     const int K = A.K;
     const int jj = j < K ? j : K - 1;
+    int cur = 0;
+#ifdef PP_X_STAMP
+    int stage_no = 0;
+#endif
     if (A.rmask[n] == 0.f) {              // masked / padded residue: its edges are zero, whole workgroup leaves
         if (j < K) {
             f32x4v z = {0.f, 0.f, 0.f, 0.f};
@@ -351,61 +387,49 @@ k_edge_update(EdgeArgs A) {
         }
         return;
     }
-    // chunks: W_B 0..3, W_G 4..6, W_mid 7..10, W_out 11..14, then per hidden block c: W1 x4, W2 x4
-    constexpr int NCH = 47;
-    PROLOGUE_PIPE()
 
-    f32x16 x[4], acc, out, res;
+    f32x16 x[4], acc, out;
     float g[3][12];
     const float *hrow = A.hE_in + ((size_t)n * K + jj) * 128;
     const int nbr = A.eidx[(size_t)n * K + jj];
     const float me = A.mask_att[(size_t)n * 32 + j];
-    // the small per-layer vectors go to LDS once (published by the first exchange barrier)
-    for (int i = tid; i < 1408 / 4; i += ET)
-        *reinterpret_cast<f32x4v *>(prm + 4 * i) = *reinterpret_cast<const f32x4v *>(A.params + 4 * i);
-    edge_geometry(A.pts + (size_t)n * 48, A.frames + (size_t)n * 12, A.pts + (size_t)nbr * 48, h, g);
     {
 #pragma unroll
         for (int t = 0; t < 4; t++) load_tile(hrow + 32 * t, h, x[t]);
         load_tile(A.PA + (size_t)n * 128 + 32 * wave, h, acc);
         add_tile(A.PC + (size_t)nbr * 128 + 32 * wave, h, acc);
     }
-    // residual input of the first LayerNorm: this wave's tile of h_E (wave is scalar: uniform branches, static indices)
-    if (wave == 0) res = x[0];
-    else if (wave == 1) res = x[1];
-    else if (wave == 2) res = x[2];
-    else res = x[3];
-    FIRST_LAYER(NCH)
+    const float *ws = A.wstream;   // chunks: W_B 0..3, W_G 4..6, W_mid 7..10, W_out 11..14, then per c: W1 x4, W2 x4
+    WRegs RA, RB;
+    FIRST_LAYER()
     // ---- second layer (chunks 7..10) -------------------------------------------------------------
     {
 #pragma unroll
         for (int t = 0; t < 4; t++) xbuf_get(xbuf, t, lane, x[t]);
-        load_tile(prm + P_BMID + 32 * wave, h, acc);
+        load_tile(A.b_mid + 32 * wave, h, acc);
     }
-    WSTAGE(7, NCH, mfma_tile32<false>(wslot, x[0], acc, lane))
-    WSTAGE(8, NCH, mfma_tile32<false>(wslot, x[1], acc, lane))
-    WSTAGE(9, NCH, mfma_tile32<false>(wslot, x[2], acc, lane))
-    WSTAGE(10, NCH, mfma_tile32<false>(wslot, x[3], acc, lane))
-    relu_tile(acc);
-    __syncthreads();
-    xbuf_put(xbuf, wave, lane, acc);
-    __syncthreads();
+    STAGE2(mfma_tile32<false>(CURBUF, wave, x[0], acc, lane), RA, 32, RB, 32, ws + CHUNK_OFF(9))
+    STAGE2(mfma_tile32<false>(CURBUF, wave, x[1], acc, lane), RB, 32, RA, 32, ws + CHUNK_OFF(10))
+    STAGE2(mfma_tile32<false>(CURBUF, wave, x[2], acc, lane), RA, 32, RB, 32, ws + CHUNK_OFF(11))
+    STAGE2(mfma_tile32<false>(CURBUF, wave, x[3], acc, lane); relu_tile(acc); xbuf_put(xbuf, wave, lane, acc),
+           RB, 32, RA, 32, ws + CHUNK_OFF(12))
     // ---- third layer (chunks 11..14) --------------------------------------------------------------
     {
 #pragma unroll
         for (int t = 0; t < 4; t++) xbuf_get(xbuf, t, lane, x[t]);
-        load_tile(prm + P_BOUT + 32 * wave, h, acc);
+        load_tile(A.b_out + 32 * wave, h, acc);
     }
-    WSTAGE(11, NCH, mfma_tile32<false>(wslot, x[0], acc, lane))
-    WSTAGE(12, NCH, mfma_tile32<false>(wslot, x[1], acc, lane))
-    WSTAGE(13, NCH, mfma_tile32<false>(wslot, x[2], acc, lane))
-    WSTAGE(14, NCH, mfma_tile32<false>(wslot, x[3], acc, lane))
-    // publish v = h_E + mask * m for the first LayerNorm
-#pragma unroll
-    for (int r = 0; r < 16; r++) res[r] = fmaf(acc[r], me, res[r]);
-    __syncthreads();
-    xbuf_put(xbuf, wave, lane, res);
-    __syncthreads();
+    STAGE2(mfma_tile32<false>(CURBUF, wave, x[0], acc, lane), RA, 32, RB, 32, ws + CHUNK_OFF(13))
+    STAGE2(mfma_tile32<false>(CURBUF, wave, x[1], acc, lane), RB, 32, RA, 32, ws + CHUNK_OFF(14))
+    STAGE2(mfma_tile32<false>(CURBUF, wave, x[2], acc, lane), RA, 32, RB, 32, ws + CHUNK_OFF(15))
+    // last chunk; then publish v = h_E + mask * m for the first LayerNorm
+    STAGE2(mfma_tile32<false>(CURBUF, wave, x[3], acc, lane); {
+               f32x16 v;
+               load_tile(hrow + 32 * wave, h, v);
+               _Pragma("unroll") for (int r = 0; r < 16; r++) v[r] = fmaf(acc[r], me, v[r]);
+               xbuf_put(xbuf, wave, lane, v);
+           },
+           RB, 32, RA, 32, ws + CHUNK_OFF(16))
     {
         // x1 = LN2(v): every wave normalises the full vector (it needs all of x1 as B operands)
 #pragma unroll
@@ -413,20 +437,39 @@ k_edge_update(EdgeArgs A) {
         float mean;
         const float rstd = ln_center(x, mean);
 #pragma unroll
-        for (int t = 0; t < 4; t++) ln_affine_tile(x[t], rstd, prm + P_G2 + 32 * t, prm + P_BE2 + 32 * t, h);
-        load_tile(prm + P_FOB + 32 * wave, h, out);
+        for (int t = 0; t < 4; t++) ln_affine_tile(x[t], rstd, A.g2 + 32 * t, A.be2 + 32 * t, h);
+        load_tile(A.ffn_out_b + 32 * wave, h, out);
     }
-    // ---- FFN 128 -> 512 -> 128 in four hidden blocks of 128 ------------------------------------------
-    FFN_BLOCK(0)
-    FFN_BLOCK(1)
-    FFN_BLOCK(2)
-    FFN_BLOCK(3)
+    // ---- FFN 128 -> 512 -> 128 in four hidden blocks of 128 (chunks 15 + 8c ..) ------------------------
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const float *wc = ws + CHUNK_OFF(15 + 8 * c);             // this block's 8 chunks: W1 s=0..3, W2 s'=0..3
+        load_tile(A.ffn_in_b + 128 * c + 32 * wave, h, acc);
+        STAGE2(mfma_tile32<false>(CURBUF, wave, x[0], acc, lane), RA, 32, RB, 32, wc + 2 * CH32)
+        STAGE2(mfma_tile32<false>(CURBUF, wave, x[1], acc, lane), RB, 32, RA, 32, wc + 3 * CH32)
+        STAGE2(mfma_tile32<false>(CURBUF, wave, x[2], acc, lane), RA, 32, RB, 32, wc + 4 * CH32)
+        STAGE2(mfma_tile32<false>(CURBUF, wave, x[3], acc, lane); relu_tile(acc); xbuf_put(xbuf, wave, lane, acc),
+               RB, 32, RA, 32, wc + 5 * CH32)
+        // second FFN layer over this hidden block: B operands come tile by tile from the exchange buffer
+        STAGE2(xbuf_get(xbuf, 0, lane, acc); mfma_tile32<false>(CURBUF, wave, acc, out, lane), RA, 32, RB, 32, wc + 6 * CH32)
+        STAGE2(xbuf_get(xbuf, 1, lane, acc); mfma_tile32<false>(CURBUF, wave, acc, out, lane), RB, 32, RA, 32, wc + 7 * CH32)
+        if (c < 3) {
+            STAGE2(xbuf_get(xbuf, 2, lane, acc); mfma_tile32<false>(CURBUF, wave, acc, out, lane), RA, 32, RB, 32, wc + 8 * CH32)
+            STAGE2(xbuf_get(xbuf, 3, lane, acc); mfma_tile32<false>(CURBUF, wave, acc, out, lane), RB, 32, RA, 32,
+                   wc + 9 * CH32)
+        } else {
+            STAGE2_NOLOAD(xbuf_get(xbuf, 2, lane, acc); mfma_tile32<false>(CURBUF, wave, acc, out, lane), RA, 32)
+            xbuf_get(xbuf, 3, lane, acc);
+            mfma_tile32<false>(CURBUF, wave, acc, out, lane);
+            __syncthreads();          // every wave is done reading the hidden tiles before they are overwritten
+        }
+    }
     // ---- h_E = mask * LN3(x1 + ffn) ---------------------------------------------------------------------
+    // residual: this wave's tile of x1 (wave is scalar: four uniform branches, static register indices)
     if (wave == 0) { _Pragma("unroll") for (int r = 0; r < 16; r++) out[r] += x[0][r]; }
     else if (wave == 1) { _Pragma("unroll") for (int r = 0; r < 16; r++) out[r] += x[1][r]; }
     else if (wave == 2) { _Pragma("unroll") for (int r = 0; r < 16; r++) out[r] += x[2][r]; }
     else { _Pragma("unroll") for (int r = 0; r < 16; r++) out[r] += x[3][r]; }
-    __syncthreads();
     xbuf_put(xbuf, wave, lane, out);
     __syncthreads();
 #pragma unroll
@@ -435,20 +478,13 @@ k_edge_update(EdgeArgs A) {
     const float rstd = ln_center(x, mean3);
 #pragma unroll
     for (int r = 0; r < 16; r++) out[r] -= mean3;
-    ln_affine_tile(out, rstd, prm + P_G3 + 32 * wave, prm + P_BE3 + 32 * wave, h);
+    ln_affine_tile(out, rstd, A.g3 + 32 * wave, A.be3 + 32 * wave, h);
 #pragma unroll
     for (int r = 0; r < 16; r++) out[r] *= me;
     if (j < K) store_tile(A.hE_out + ((size_t)n * K + j) * 128 + 32 * wave, h, out);
 }
 
 // ---------------------------------------------------------------------------------------------
-#ifndef PP_NM_SLOTS
-#define PP_NM_SLOTS 3
-#endif
-#ifndef PP_EU_SLOTS
-#define PP_EU_SLOTS 3
-#endif
-
 static EdgeArgs edge_args(pp_ctx *c, int layer, bool edge) {
     const pp_plan *p = c->plan;
     const LayerOff &o = p->off.layer[layer];
@@ -462,46 +498,36 @@ static EdgeArgs edge_args(pp_ctx *c, int layer, bool edge) {
     A.hE_in = layer == 0 ? c->hE0 : c->hE;
     A.hE_out = c->hE;
     A.S = c->S; A.msum = c->msum;
+    const float *w = p->w;
     A.wstream = edge ? p->lt[layer].em_stream : p->lt[layer].nm_stream;
-    A.params = p->lt[layer].em_params;
-    A.b_mid = p->w + o.nm_mid_b;
+    A.b_mid = w + (edge ? o.em_mid_b : o.nm_mid_b);
+    A.b_out = w + (edge ? o.em_out_b : o.nm_out_b);
+    A.g2 = w + o.norm_g[2]; A.be2 = w + o.norm_b[2];
+    A.g3 = w + o.norm_g[3]; A.be3 = w + o.norm_b[3];
+    A.ffn_in_b = w + o.ed_in_b;
+    A.ffn_out_b = w + o.ed_out_b;
+    A.dbg = c->dbg;
     return A;
 }
 
-static const size_t NM_SMEM = (4 * PP_NM_SLOTS * 1024 + XBUF_FLOATS) * sizeof(float);
-static const size_t EU_SMEM = (4 * PP_EU_SLOTS * 1024 + XBUF_FLOATS + PARAM_FLOATS) * sizeof(float);
-
-static bool edge_attrs() {
-    static bool done = false, ok = false;
-    if (!done) {
-        done = true;
-        ok = hipFuncSetAttribute(reinterpret_cast<const void *>(k_node_message<PP_NM_SLOTS>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)NM_SMEM) == hipSuccess &&
-             hipFuncSetAttribute(reinterpret_cast<const void *>(k_edge_update<PP_EU_SLOTS>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)EU_SMEM) == hipSuccess;
-    }
-    return ok;
-}
+static const size_t EDGE_SMEM = (2 * WBUF_FLOATS + XBUF_FLOATS) * sizeof(float);
 
 // resident workgroups per CU the runtime predicts for the two kernels (measurement aid)
 void pp_edge_occupancy(int *node_msg, int *edge_upd) {
-    edge_attrs();
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(node_msg, reinterpret_cast<const void *>(k_node_message<PP_NM_SLOTS>), ET, NM_SMEM);
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(edge_upd, reinterpret_cast<const void *>(k_edge_update<PP_EU_SLOTS>), ET, EU_SMEM);
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(node_msg, reinterpret_cast<const void *>(k_node_message), ET, EDGE_SMEM);
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(edge_upd, reinterpret_cast<const void *>(k_edge_update), ET, EDGE_SMEM);
 }
 
 pp_status pp_launch_node_message(pp_ctx *c, int layer, hipStream_t s) {
-    if (!edge_attrs()) { pp_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for the edge kernels"); return PP_ERR_HIP; }
     EdgeArgs A = edge_args(c, layer, false);
-    hipLaunchKernelGGL(k_node_message<PP_NM_SLOTS>, dim3(c->N), dim3(ET), NM_SMEM, s, A);
+    hipLaunchKernelGGL(k_node_message, dim3(c->N), dim3(ET), EDGE_SMEM, s, A);
     PP_HIP_CHECK(hipGetLastError());
     return PP_OK;
 }
 
 pp_status pp_launch_edge_update(pp_ctx *c, int layer, hipStream_t s) {
-    if (!edge_attrs()) { pp_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for the edge kernels"); return PP_ERR_HIP; }
     EdgeArgs A = edge_args(c, layer, true);
-    hipLaunchKernelGGL(k_edge_update<PP_EU_SLOTS>, dim3(c->N), dim3(ET), EU_SMEM, s, A);
+    hipLaunchKernelGGL(k_edge_update, dim3(c->N), dim3(ET), EDGE_SMEM, s, A);
     PP_HIP_CHECK(hipGetLastError());
     return PP_OK;
 }
