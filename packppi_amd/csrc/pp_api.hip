@@ -102,13 +102,13 @@ static size_t put_stream(std::vector<float> &arena, const float *w, const LayerO
     return at;
 }
 // the edge kernel's small per-layer vectors in one block (staged to LDS once per workgroup):
-// b_mid | b_out | ffn_out_b | g2 | be2 | g3 | be3 | ffn_in_b[512]   (1408 floats)
+// b_mid | b_out | ffn_out_b | g2 | be2 | ffn_in_b[512]   (1152 floats)
 static size_t put_edge_params(std::vector<float> &arena, const float *w, const LayerOff &L) {
     size_t at = (arena.size() + 3) & ~size_t(3);
     arena.resize(at);
     auto app = [&](size_t off, int n) { arena.insert(arena.end(), w + off, w + off + n); };
     app(L.em_mid_b, 128); app(L.em_out_b, 128); app(L.ed_out_b, 128);
-    app(L.norm_g[2], 128); app(L.norm_b[2], 128); app(L.norm_g[3], 128); app(L.norm_b[3], 128);
+    app(L.norm_g[2], 128); app(L.norm_b[2], 128);
     app(L.ed_in_b, 512);
     return at;
 }

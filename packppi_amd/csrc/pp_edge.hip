@@ -28,7 +28,7 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 #define ET 256
 #define CH32 (128 * 32)                 // floats per packed weight chunk (16 KB); a wave's quarter is 1024 floats
 #define XBUF_FLOATS (4 * 4 * 64 * 4)    // exchange buffer: [tile][quad][lane] float4
-#define PARAM_FLOATS 1536               // edge kernel: small per-layer vectors staged once (1408 used)
+#define PARAM_FLOATS 1152               // edge kernel: small per-layer vectors staged once
 
 // Timing-only ablation switch (tools/debug/ablate_edge.py); never defined in a shipped build.
 #ifdef PP_X_NOMFMA
@@ -50,10 +50,11 @@ struct EdgeArgs {
     float *hE_out;             // [N][K][128]   (edge kernel)
     float *S, *msum;           // node kernel outputs
     const float *wstream;      // this kernel's weight chunks, packed in consumption order (pp_api.hip put_chunk)
-    const float *params;       // edge kernel: b_mid | b_out | ffn_out_b | g2 | be2 | g3 | be3 | ffn_in_b[512]
+    const float *params;       // edge kernel: b_mid | b_out | ffn_out_b | g2 | be2 | ffn_in_b[512]
+    const float *g3, *be3;     // edge kernel: last LayerNorm (read in the epilogue)
     const float *b_mid;        // node kernel (per-lane read)
 };
-enum { P_BMID = 0, P_BOUT = 128, P_FOB = 256, P_G2 = 384, P_BE2 = 512, P_G3 = 640, P_BE3 = 768, P_FIB = 896 };
+enum { P_BMID = 0, P_BOUT = 128, P_FOB = 256, P_G2 = 384, P_BE2 = 512, P_FIB = 640 };
 
 // ---- weight pipeline: LDS-DMA, private to each wave ------------------------------------------------------------
 // Wave w only ever needs rows 32w..32w+31 of a weight chunk (its output tile), so its quarter of every chunk is
@@ -74,6 +75,23 @@ __device__ __forceinline__ void dma_chunk(const float *gsrc_lane, unsigned lds_d
                  "global_load_lds_dwordx4 %1, off offset:3072\n\t"
                  "s_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc_lane), "s"(lds_dst) : "memory");
+}
+// one tile of a row-major [.][128] row set, gathered per lane (row pointer row32 = this lane's row + 32 tile) into the
+// [quad][lane][4] register image at lds_dst: quad q is the float4 at row32 + 8 q + 4 h.  The instruction offset moves
+// the global AND the LDS address, hence the 1024 - 32 stride on M0.
+__device__ __forceinline__ void dma_tile(const float *row32_h, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\t"
+                 "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, off\n\t"
+                 "s_add_u32 m0, m0, 992\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, off offset:32\n\t"
+                 "s_add_u32 m0, m0, 992\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, off offset:64\n\t"
+                 "s_add_u32 m0, m0, 992\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, off offset:96\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(row32_h), "s"(lds_dst) : "memory", "scc");
 }
 template <int N>
 __device__ __forceinline__ void wait_vm() {
@@ -246,6 +264,16 @@ __device__ __forceinline__ void edge_geometry(const float *__restrict__ pts_i, c
 // ---------------------------------------------------------------------------------------------
 // node message: S[i] = (1/K) sum_j mask_ij relu(W_mid relu(W_in [..]) + b), msum[i] = (1/K) sum_j mask_ij
 // ---------------------------------------------------------------------------------------------
+#ifndef PP_NM_SLOTS
+#define PP_NM_SLOTS 2
+#endif
+#ifndef PP_EU_SLOTS
+#define PP_EU_SLOTS 2
+#endif
+#ifndef PP_EU_WGS
+#define PP_EU_WGS 3
+#endif
+
 template <int S>
 __global__ void __launch_bounds__(ET, 3)
 k_node_message(EdgeArgs A) {
@@ -332,10 +360,14 @@ k_node_message(EdgeArgs A) {
     WSTAGE(15 + 8 * (c) + 7, NCH, xbuf_get(xbuf, 3, lane, acc); mfma_tile32<false>(wslot, acc, out, lane))
 
 template <int S>
-__global__ void __launch_bounds__(ET, 2)
+__global__ void __launch_bounds__(ET, PP_EU_WGS)
 k_edge_update(EdgeArgs A) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+#ifdef PP_X_PRM_ALIAS          // timing only: params alias the exchange buffer (wrong results) to test an 80 KB footprint
+    float *xbuf = smem + 4 * S * 1024, *prm = xbuf;
+#else
     float *xbuf = smem + 4 * S * 1024, *prm = xbuf + XBUF_FLOATS;
+#endif
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, h = lane >> 5;
@@ -355,26 +387,22 @@ k_edge_update(EdgeArgs A) {
     constexpr int NCH = 47;
     PROLOGUE_PIPE()
 
-    f32x16 x[4], acc, out, res;
+    f32x16 x[4], acc, out;
     float g[3][12];
     const float *hrow = A.hE_in + ((size_t)n * K + jj) * 128;
     const int nbr = A.eidx[(size_t)n * K + jj];
     const float me = A.mask_att[(size_t)n * 32 + j];
     // the small per-layer vectors go to LDS once (published by the first exchange barrier)
-    for (int i = tid; i < 1408 / 4; i += ET)
+    for (int i = tid; i < PARAM_FLOATS / 4; i += ET)
         *reinterpret_cast<f32x4v *>(prm + 4 * i) = *reinterpret_cast<const f32x4v *>(A.params + 4 * i);
     edge_geometry(A.pts + (size_t)n * 48, A.frames + (size_t)n * 12, A.pts + (size_t)nbr * 48, h, g);
+    __builtin_amdgcn_sched_barrier(0);        // geometry temporaries die before the activation tiles are loaded
     {
 #pragma unroll
         for (int t = 0; t < 4; t++) load_tile(hrow + 32 * t, h, x[t]);
         load_tile(A.PA + (size_t)n * 128 + 32 * wave, h, acc);
         add_tile(A.PC + (size_t)nbr * 128 + 32 * wave, h, acc);
     }
-    // residual input of the first LayerNorm: this wave's tile of h_E (wave is scalar: uniform branches, static indices)
-    if (wave == 0) res = x[0];
-    else if (wave == 1) res = x[1];
-    else if (wave == 2) res = x[2];
-    else res = x[3];
     FIRST_LAYER(NCH)
     // ---- second layer (chunks 7..10) -------------------------------------------------------------
     {
@@ -396,24 +424,35 @@ k_edge_update(EdgeArgs A) {
         for (int t = 0; t < 4; t++) xbuf_get(xbuf, t, lane, x[t]);
         load_tile(prm + P_BOUT + 32 * wave, h, acc);
     }
+    // The exchange buffer is idle during this layer: once every wave has its B operands (barrier), each wave parks
+    // the residual input of the first LayerNorm -- its own tile of h_E -- in its own exchange tile by LDS-DMA.  The copy
+    // is older than the weight chunks issued below, so the vmcnt wait of stage 14 covers it.
+    __syncthreads();
+    dma_tile(hrow + 32 * wave + 4 * h, (unsigned)(size_t)(xbuf + wave * 1024));
     WSTAGE(11, NCH, mfma_tile32<false>(wslot, x[0], acc, lane))
     WSTAGE(12, NCH, mfma_tile32<false>(wslot, x[1], acc, lane))
     WSTAGE(13, NCH, mfma_tile32<false>(wslot, x[2], acc, lane))
     WSTAGE(14, NCH, mfma_tile32<false>(wslot, x[3], acc, lane))
-    // publish v = h_E + mask * m for the first LayerNorm
+    // publish v = h_E + mask * m for the first LayerNorm (own tile: read, then overwritten in place)
+    xbuf_get(xbuf, wave, lane, out);
 #pragma unroll
-    for (int r = 0; r < 16; r++) res[r] = fmaf(acc[r], me, res[r]);
-    __syncthreads();
-    xbuf_put(xbuf, wave, lane, res);
+    for (int r = 0; r < 16; r++) out[r] = fmaf(acc[r], me, out[r]);
+    xbuf_put(xbuf, wave, lane, out);
     __syncthreads();
     {
         // x1 = LN2(v): every wave normalises the full vector (it needs all of x1 as B operands)
 #pragma unroll
         for (int t = 0; t < 4; t++) xbuf_get(xbuf, t, lane, x[t]);
         float mean;
-        const float rstd = ln_center(x, mean);
+        float rstd = ln_center(x, mean);
 #pragma unroll
-        for (int t = 0; t < 4; t++) ln_affine_tile(x[t], rstd, prm + P_G2 + 32 * t, prm + P_BE2 + 32 * t, h);
+        for (int t = 0; t < 4; t++) {
+            // compiler fence tied to the data flow: the gamma / beta reads of tile t are issued only once rstd (and the
+            // previous tile) exist, so one tile's worth of them is live at a time (168-VGPR budget)
+            if (t == 0) asm volatile("" : "+v"(rstd) : : "memory");
+            else asm volatile("" : "+v"(x[t > 0 ? t - 1 : 0][15]) : : "memory");
+            ln_affine_tile(x[t], rstd, prm + P_G2 + 32 * t, prm + P_BE2 + 32 * t, h);
+        }
         load_tile(prm + P_FOB + 32 * wave, h, out);
     }
     // ---- FFN 128 -> 512 -> 128 in four hidden blocks of 128 ------------------------------------------
@@ -435,20 +474,13 @@ k_edge_update(EdgeArgs A) {
     const float rstd = ln_center(x, mean3);
 #pragma unroll
     for (int r = 0; r < 16; r++) out[r] -= mean3;
-    ln_affine_tile(out, rstd, prm + P_G3 + 32 * wave, prm + P_BE3 + 32 * wave, h);
+    ln_affine_tile(out, rstd, A.g3 + 32 * wave, A.be3 + 32 * wave, h);
 #pragma unroll
     for (int r = 0; r < 16; r++) out[r] *= me;
     if (j < K) store_tile(A.hE_out + ((size_t)n * K + j) * 128 + 32 * wave, h, out);
 }
 
 // ---------------------------------------------------------------------------------------------
-#ifndef PP_NM_SLOTS
-#define PP_NM_SLOTS 3
-#endif
-#ifndef PP_EU_SLOTS
-#define PP_EU_SLOTS 3
-#endif
-
 static EdgeArgs edge_args(pp_ctx *c, int layer, bool edge) {
     const pp_plan *p = c->plan;
     const LayerOff &o = p->off.layer[layer];
@@ -464,12 +496,17 @@ static EdgeArgs edge_args(pp_ctx *c, int layer, bool edge) {
     A.S = c->S; A.msum = c->msum;
     A.wstream = edge ? p->lt[layer].em_stream : p->lt[layer].nm_stream;
     A.params = p->lt[layer].em_params;
+    A.g3 = p->w + o.norm_g[3]; A.be3 = p->w + o.norm_b[3];
     A.b_mid = p->w + o.nm_mid_b;
     return A;
 }
 
 static const size_t NM_SMEM = (4 * PP_NM_SLOTS * 1024 + XBUF_FLOATS) * sizeof(float);
+#ifdef PP_X_PRM_ALIAS
+static const size_t EU_SMEM = (4 * PP_EU_SLOTS * 1024 + XBUF_FLOATS) * sizeof(float);
+#else
 static const size_t EU_SMEM = (4 * PP_EU_SLOTS * 1024 + XBUF_FLOATS + PARAM_FLOATS) * sizeof(float);
+#endif
 
 static bool edge_attrs() {
     static bool done = false, ok = false;
