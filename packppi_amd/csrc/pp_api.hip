@@ -66,6 +66,18 @@ static size_t put_T(std::vector<float> &arena, const float *W, int rows, int ld,
     return at;
 }
 
+// k-quad interleaved transpose for the node kernels (pp_node.hip): dst[in / 4][out][in % 4], so that a thread owning
+// output column `out` reads four consecutive reduction inputs with one 16-byte load (cols % 4 == 0)
+static size_t put_T4(std::vector<float> &arena, const float *W, int rows, int ld, int c0, int cols) {
+    size_t at = arena.size();
+    at = (at + 3) & ~size_t(3);
+    arena.resize(at + (size_t)rows * cols);
+    float *d = arena.data() + at;
+    for (int r = 0; r < rows; r++)
+        for (int c = 0; c < cols; c++) d[((size_t)(c >> 2) * rows + r) * 4 + (c & 3)] = W[(size_t)r * ld + c0 + c];
+    return at;
+}
+
 // Append one weight chunk = the [128 rows][ncols] block of W (row stride ld) at (row0, col0), packed for the edge
 // kernels' wave-private LDS-DMA pipeline (pp_edge.hip): [wave 4][quad 4][lane 64][4 floats], where lane = (row & 31,
 // half h) of wave row >> 5 holds the A-operand registers of MFMA steps 4q..4q+3:
@@ -154,23 +166,23 @@ extern "C" pp_status pp_plan_create(const float *weights, size_t n_weights, cons
     size_t o_l[3][12];
     for (int l = 0; l < 3; l++) {
         const LayerOff &L = off.layer[l];
-        o_l[l][0] = put_T(arena, weights + L.pts_node_w, 24, 128, 0, 128);
-        o_l[l][1] = put_T(arena, weights + L.pts_edge_w, 24, 128, 0, 128);
-        o_l[l][2] = put_T(arena, weights + L.nm_in_w, 128, 456, 0, 128);
-        o_l[l][3] = put_T(arena, weights + L.nm_in_w, 128, 456, 256, 128);
-        o_l[l][4] = put_T(arena, weights + L.em_in_w, 128, 456, 0, 128);
-        o_l[l][5] = put_T(arena, weights + L.em_in_w, 128, 456, 256, 128);
-        o_l[l][6] = put_T(arena, weights + L.nm_out_w, 128, 128, 0, 128);
-        o_l[l][7] = put_T(arena, weights + L.nd_in_w, 512, 128, 0, 128);
-        o_l[l][8] = put_T(arena, weights + L.nd_out_w, 128, 512, 0, 512);
+        o_l[l][0] = put_T4(arena, weights + L.pts_node_w, 24, 128, 0, 128);
+        o_l[l][1] = put_T4(arena, weights + L.pts_edge_w, 24, 128, 0, 128);
+        o_l[l][2] = put_T4(arena, weights + L.nm_in_w, 128, 456, 0, 128);
+        o_l[l][3] = put_T4(arena, weights + L.nm_in_w, 128, 456, 256, 128);
+        o_l[l][4] = put_T4(arena, weights + L.em_in_w, 128, 456, 0, 128);
+        o_l[l][5] = put_T4(arena, weights + L.em_in_w, 128, 456, 256, 128);
+        o_l[l][6] = put_T4(arena, weights + L.nm_out_w, 128, 128, 0, 128);
+        o_l[l][7] = put_T4(arena, weights + L.nd_in_w, 512, 128, 0, 128);
+        o_l[l][8] = put_T4(arena, weights + L.nd_out_w, 128, 512, 0, 512);
         o_l[l][9] = put_stream(arena, weights, L, false);
         o_l[l][10] = put_stream(arena, weights, L, true);
         o_l[l][11] = put_edge_params(arena, weights, L);
     }
-    size_t o_d0i = put_T(arena, weights + off.d0_in_w, 64, 128, 0, 128);
-    size_t o_d0o = put_T(arena, weights + off.d0_out_w, 32, 64, 0, 64);
-    size_t o_d2i = put_T(arena, weights + off.d2_in_w, 16, 32, 0, 32);
-    size_t o_d2o = put_T(arena, weights + off.d2_out_w, 4, 16, 0, 16);
+    size_t o_d0i = put_T4(arena, weights + off.d0_in_w, 64, 128, 0, 128);
+    size_t o_d0o = put_T4(arena, weights + off.d0_out_w, 32, 64, 0, 64);
+    size_t o_d2i = put_T4(arena, weights + off.d2_in_w, 16, 32, 0, 32);
+    size_t o_d2o = put_T4(arena, weights + off.d2_out_w, 4, 16, 0, 16);
     if ((st = upload(&p->wT, arena.data(), arena.size())) != PP_OK) return st;
     p->node_emb_T = p->wT + o_node_emb;
     p->edge_emb_T = p->wT + o_edge_emb;

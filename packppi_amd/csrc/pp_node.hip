@@ -11,8 +11,8 @@
 // latency: a block of 512 threads owns NB = 4 NG consecutive residues; thread (f = tid & 127, ks = tid >> 7) owns
 // output feature f for all of them over the ks-th quarter of the reduction dimension; the four partial sums meet
 // in LDS.  Weights are read from transposed copies ([in][out]) so a wave's loads are contiguous; activations
-// sit in LDS as float4 groups (one component per residue).  The kernel is bound by the L2 round trip of each
-// dependent dense phase, not by bytes: NG = 1 (185 blocks at T1124) runs in 27 us, NG = 2 (93 blocks) in 74 us.
+// sit in LDS as float4 groups (one component per residue).  The kernel is bound by one block's dependent chain, not by
+// bytes (same time for 16 and 256 blocks), so k_node_update fetches every phase's weights a phase or two ahead.
 // The cheap epilogues (LayerNorm, bias, ReLU) are replicated in the four ks-groups to keep control flow uniform.
 #include "pp_internal.h"
 
@@ -96,15 +96,21 @@ __device__ __forceinline__ VN vrelu(VN a) {
 }
 __device__ __forceinline__ float vcomp(const VN &v, int i) { return comp(v.g[i >> 2], i & 3); }   // i: residue in block
 
-// partial sum over the ks-th quarter of the reduction dimension
+// partial sum over the ks-th quarter of the reduction dimension; WT is k-quad interleaved [in / 4][ldo][4] (put_T4)
 template <int KIN>
 __device__ __forceinline__ VN dense_slice(const float *__restrict__ WT, int ldo, int col, const VN *act, int ks) {
     constexpr int KL = KIN / 4;
-    const float *w = WT + (size_t)(ks * KL) * ldo + col;
+    const float4 *w = reinterpret_cast<const float4 *>(WT) + (size_t)(ks * (KL / 4)) * ldo + col;
     const VN *a = act + ks * KL;
     VN acc = vn(0.f);
-#pragma unroll 16
-    for (int i = 0; i < KL; i++) acc = vfma(w[(size_t)i * ldo], a[i], acc);
+#pragma unroll 4
+    for (int i = 0; i < KL / 4; i++) {
+        const float4 q = w[(size_t)i * ldo];
+        acc = vfma(q.x, a[4 * i], acc);
+        acc = vfma(q.y, a[4 * i + 1], acc);
+        acc = vfma(q.z, a[4 * i + 2], acc);
+        acc = vfma(q.w, a[4 * i + 3], acc);
+    }
     return acc;
 }
 
@@ -269,6 +275,88 @@ __device__ __forceinline__ VN dense_small(Smem &sm, int &flip, const float *WT, 
     return f < width ? vadd(r, vn(bias[f])) : vn(0.f);
 }
 
+// ---- k_node_update: the same arithmetic as the helpers above, software-pipelined -------------------------------
+// Measured (tools/debug/time_vs_n.py): the kernel takes the same 24 us for 16 and for 256 blocks -- it is one block's
+// dependent chain of ~30 L2 round trips (every dense phase used to fetch its 32-128 weights per thread right before
+// using them).  Weights do not depend on activations, so here every phase's weights are fetched into registers one or
+// two phases ahead (five register sets of 32), and the per-feature vectors (biases, LayerNorm gains) at kernel start.
+struct WSet {
+    float v[32];
+};
+// rows k0 .. k0+KL of column col of a transposed weight [in][ldo]
+// `after`: a value the previous user of this register set produced.  The weights are read-only kernel arguments, so
+// the compiler would otherwise hoist every fetch of the kernel to its top (and spill ~1900 registers); making the
+// offset opaque behind an empty asm that consumes `after` pins the fetch between that value and its first use.
+template <int KL, int DST0 = 0>
+__device__ __forceinline__ void wload(WSet &w, const float *__restrict__ WT, int ldo, int col, int k0, float after) {
+    int off = (k0 >> 2) * ldo + col;          // in float4 units of the k-quad interleaved layout (put_T4)
+    asm volatile("" : "+v"(off) : "v"(after));
+    const float4 *w4 = reinterpret_cast<const float4 *>(WT);
+#pragma unroll
+    for (int i = 0; i < KL / 4; i++) {
+        const float4 q = w4[off + i * ldo];
+        w.v[DST0 + 4 * i] = q.x; w.v[DST0 + 4 * i + 1] = q.y; w.v[DST0 + 4 * i + 2] = q.z; w.v[DST0 + 4 * i + 3] = q.w;
+    }
+}
+template <int KL, int SRC0 = 0>
+__device__ __forceinline__ VN wdot(const WSet &w, const VN *act, VN acc) {
+#pragma unroll
+    for (int i = 0; i < KL; i++) {
+#ifdef PP_X_NOACT             // timing-only ablation: no activation reads from LDS
+        acc = vfma(w.v[SRC0 + i], acc, acc);
+#else
+        acc = vfma(w.v[SRC0 + i], act[i], acc);
+#endif
+        // keep the scheduler from running the x/y chains of a whole slice ahead of the z/w chains (it then parks
+        // half of every activation read in scratch)
+        if ((i & 7) == 7) VN_FOR asm volatile("" : "+v"(acc.g[gi].x), "+v"(acc.g[gi].y), "+v"(acc.g[gi].z), "+v"(acc.g[gi].w));
+    }
+    return acc;
+}
+
+// message_inputs with the weights already in registers (wA, wC: this thread's K-quarter of column f; wP: of column f < 24).
+// refill_ptsT, if not null: the point weights of the NEXT call, fetched into wP as soon as it has been consumed.
+__device__ __forceinline__ void message_inputs_pre(Smem &sm, int &flip, const WSet &wA, const WSet &wC, WSet &wP,
+                                                   const float *refill_ptsT, float in_b, float pts_b, const float *frames,
+                                                   int n0, int N, float *pts, float *PA, float *PC) {
+    const int f = threadIdx.x & 127, ks = threadIdx.x >> 7;
+    const VN *h = sm.h + ks * 32;
+    VN *buf = sm.part[flip];
+    flip ^= 1;
+    buf[ks * 384 + f] = wdot<32>(wA, h, vn(0.f));
+    buf[ks * 384 + 128 + f] = wdot<32>(wC, h, vn(0.f));
+    if (f < 24) {
+        const VN up = wdot<32>(wP, h, vn(0.f));
+        buf[ks * 384 + 256 + f] = up;
+        if (refill_ptsT) wload<32>(wP, refill_ptsT, 24, f, ks * 32, up.g[0].x);
+    }
+    __syncthreads();
+    if (ks == 0) {
+        VN a = vadd(vadd(buf[f], buf[384 + f]), vadd(buf[768 + f], buf[1152 + f]));
+        store_rows(PA, 128, n0, N, f, vadd(a, vn(in_b)));
+    } else if (ks == 1) {
+        VN c = vadd(vadd(buf[128 + f], buf[512 + f]), vadd(buf[896 + f], buf[1280 + f]));
+        store_rows(PC, 128, n0, N, f, c);
+    } else if (ks == 2 && f < 24) {
+        VN p = vadd(vadd(buf[256 + f], buf[640 + f]), vadd(buf[1024 + f], buf[1408 + f]));
+        p = vadd(p, vn(pts_b));
+        sm.p[f] = p;
+        store_rows(pts, 48, n0, N, f, p);
+    }
+    __syncthreads();
+    if (threadIdx.x < 8 * NB) {            // (point q, residue i): p_glob = R p_loc + t
+        int q = threadIdx.x / NB, i = threadIdx.x % NB;
+        int n = n0 + i;
+        if (n < N) {
+            const float *fr = frames + (size_t)n * 12;
+            float x = vcomp(sm.p[3 * q], i), y = vcomp(sm.p[3 * q + 1], i), z = vcomp(sm.p[3 * q + 2], i);
+            for (int r = 0; r < 3; r++)
+                pts[(size_t)n * 48 + 24 + 3 * q + r] = (fr[3 * r] * x + fr[3 * r + 1] * y + fr[3 * r + 2] * z) + fr[9 + r];
+        }
+    }
+    __syncthreads();
+}
+
 __global__ void __launch_bounds__(NT)
 k_node_update(NodeArgs A, UpdW W, int last_mode, float *chi, int step, int sde, const float *noise, int embed_next,
               PreW pre0) {
@@ -276,56 +364,140 @@ k_node_update(NodeArgs A, UpdW W, int last_mode, float *chi, int step, int sde, 
     Smem &sm = *reinterpret_cast<Smem *>(smem_raw);
     int flip = 0, rflip = 0;
     const int t = threadIdx.x, f = t & 127, ks = t >> 7, n0 = blockIdx.x * NB, N = A.N;
+    const int kq = ks * 32;                  // this thread's quarter of a 128-deep reduction
+    const bool mid = last_mode == PP_NU_MID;
+    WSet wa, wb, wc, wd, we;
+    wload<32>(wa, W.outT, 128, f, kq, 0.f);
+    wload<32>(wb, W.ffn_inT, 512, f, kq, 0.f);            // FFN-in, half 0: units f and f + 128
+    wload<32>(wc, W.ffn_inT, 512, f + 128, kq, 0.f);
+    // per-feature vectors and row inputs, all up front
+    const float out_b = W.out_b[f], g0 = W.g0[f], b0 = W.b0[f], g1 = W.g1[f], b1 = W.b1[f], ffn_out_b = W.ffn_out_b[f];
+    const float fib0 = W.ffn_in_b[t & 255], fib1 = W.ffn_in_b[256 + (t & 255)];
+    const VN ms = load_rows(A.msum, 1, n0, N, 0);
+    const VN hv = load_rows(A.hV, 128, n0, N, f);
+    const VN rm = load_rows(A.rmask, 1, n0, N, 0);
     if (ks == 0) sm.a[f] = load_rows(A.S, 128, n0, N, f);
     __syncthreads();
-    const VN ms = load_rows(A.msum, 1, n0, N, 0);
     // mean_j mask_j (W_out y_j + b) = W_out mean_j(mask_j y_j) + b mean_j(mask_j)
-    VN m = meet(sm, flip, dense_slice<128>(W.outT, 128, f, sm.a, ks), 128, f, ks);
-    m = vadd(m, vscale(ms, W.out_b[f]));
-    VN h1 = layernorm(sm, rflip, vadd(load_rows(A.hV, 128, n0, N, f), m), W.g0[f], W.b0[f]);
+    VN part = wdot<32>(wa, sm.a + kq, vn(0.f));
+    wload<32>(wa, W.ffn_inT, 512, 256 + f, kq, part.g[0].x);           // FFN-in, half 1
+    wload<32>(wd, W.ffn_inT, 512, 256 + f + 128, kq, part.g[0].x);
+    VN m = meet(sm, flip, part, 128, f, ks);
+    m = vadd(m, vscale(ms, out_b));
+    VN h1 = layernorm(sm, rflip, vadd(hv, m), g0, b0);
     if (ks == 0) sm.h[f] = h1;
     __syncthreads();
     // FFN 128 -> 512 in two halves of 256 hidden units: thread (f, ks) builds the ks-th K-quarter of units f and
     // f + 128 of the half, then threads 0..255 own one unit each
-#pragma unroll
-    for (int half = 0; half < 2; half++) {
+    {
         VN *buf = sm.part[flip];
         flip ^= 1;
-#pragma unroll
-        for (int jx = 0; jx < 2; jx++)
-            buf[ks * 256 + f + 128 * jx] = dense_slice<128>(W.ffn_inT, 512, 256 * half + f + 128 * jx, sm.h, ks);
+        const VN u0 = wdot<32>(wb, sm.h + kq, vn(0.f)), u1 = wdot<32>(wc, sm.h + kq, vn(0.f));
+        buf[ks * 256 + f] = u0;
+        buf[ks * 256 + f + 128] = u1;
+        wload<32>(wb, W.ffn_outT, 128, f, ks * 128, u0.g[0].x);       // FFN-out: this thread's 128 inputs in four sets
+        wload<32>(wc, W.ffn_outT, 128, f, ks * 128 + 32, u1.g[0].x);
         __syncthreads();
         if (t < 256) {
             VN hd = vadd(vadd(buf[t], buf[256 + t]), vadd(buf[512 + t], buf[768 + t]));
-            sm.a[256 * half + t] = vrelu(vadd(hd, vn(W.ffn_in_b[256 * half + t])));
+            sm.a[t] = vrelu(vadd(hd, vn(fib0)));
+        }
+    }
+    {
+        VN *buf = sm.part[flip];
+        flip ^= 1;
+        const VN u0 = wdot<32>(wa, sm.h + kq, vn(0.f)), u1 = wdot<32>(wd, sm.h + kq, vn(0.f));
+        buf[ks * 256 + f] = u0;
+        buf[ks * 256 + f + 128] = u1;
+        wload<32>(wa, W.ffn_outT, 128, f, ks * 128 + 64, u0.g[0].x);
+        wload<32>(wd, W.ffn_outT, 128, f, ks * 128 + 96, u1.g[0].x);
+        __syncthreads();
+        if (t < 256) {
+            VN hd = vadd(vadd(buf[t], buf[256 + t]), vadd(buf[512 + t], buf[768 + t]));
+            sm.a[256 + t] = vrelu(vadd(hd, vn(fib1)));
         }
     }
     __syncthreads();
-    VN o = meet(sm, flip, dense_slice<512>(W.ffn_outT, 128, f, sm.a, ks), 128, f, ks);
-    o = vadd(o, vn(W.ffn_out_b[f]));
-    VN h2 = layernorm(sm, rflip, vadd(h1, o), W.g1[f], W.b1[f]);
-    h2 = vmul(h2, load_rows(A.rmask, 1, n0, N, 0));
+    part = wdot<32>(wb, sm.a + ks * 128, vn(0.f));
+    part = wdot<32>(wc, sm.a + ks * 128 + 32, part);
+    part = wdot<32>(wa, sm.a + ks * 128 + 64, part);
+    part = wdot<32>(wd, sm.a + ks * 128 + 96, part);
+    // next phase's weights: the two message functions (middle layers) / decoder + next embedding (last layer)
+    float in_b_1, pts_b_1 = 0.f, in_b_2 = 0.f, pts_b_2 = 0.f;
+    float db0 = 0.f, db1 = 0.f, db2 = 0.f, db3 = 0.f;
+    if (mid) {
+        const float tk = part.g[0].x;
+        wload<32>(wb, W.pre_edge.AT, 128, f, kq, tk);
+        wload<32>(wc, W.pre_edge.CT, 128, f, kq, tk);
+        if (f < 24) { wload<32>(we, W.pre_edge.ptsT, 24, f, kq, tk); pts_b_1 = W.pre_edge.pts_b[f]; pts_b_2 = W.pre_next.pts_b[f]; }
+        wload<32>(wa, W.pre_next.AT, 128, f, kq, tk);
+        wload<32>(wd, W.pre_next.CT, 128, f, kq, tk);
+        in_b_1 = W.pre_edge.in_b[f];
+        in_b_2 = W.pre_next.in_b[f];
+    } else {
+        // decoder 128 -> 64 -> 32 -> 16 -> 4: K-quarters of 32 / 16 / 8 / 4 inputs
+        const float tk = part.g[0].x;
+        if (f < 64) { wload<32>(wb, W.d0_inT, 64, f, kq, tk); db0 = W.d0_in_b[f]; }
+        if (f < 32) { wload<16, 0>(wc, W.d0_outT, 32, f, ks * 16, tk); db1 = W.d0_out_b[f]; }
+        if (f < 16) { wload<8, 16>(wc, W.d2_inT, 16, f, ks * 8, tk); db2 = W.d2_in_b[f]; }
+        if (f < 4) { wload<4, 24>(wc, W.d2_outT, 4, f, ks * 4, tk); db3 = W.d2_out_b[f]; }
+        wload<32>(wa, pre0.AT, 128, f, kq, tk);
+        wload<32>(wd, pre0.CT, 128, f, kq, tk);
+        if (f < 24) { wload<32>(we, pre0.ptsT, 24, f, kq, tk); pts_b_1 = pre0.pts_b[f]; }
+        in_b_1 = pre0.in_b[f];
+    }
+    VN o = meet(sm, flip, part, 128, f, ks);
+    o = vadd(o, vn(ffn_out_b));
+    VN h2 = layernorm(sm, rflip, vadd(h1, o), g1, b1);
+    h2 = vmul(h2, rm);
     if (ks == 0) {
         store_rows(A.hV, 128, n0, N, f, h2);
         sm.h[f] = h2;
     }
     __syncthreads();
-    if (last_mode == PP_NU_MID) {
-        message_inputs(sm, flip, W.pre_edge, A.frames, n0, N, A.ptsE, A.PAe, A.PCe);
-        message_inputs(sm, flip, W.pre_next, A.frames, n0, N, A.ptsN, A.PAn, A.PCn);
+    if (mid) {
+        // inputs of this layer's edge message, then of the next layer's node message (whose point weights are
+        // fetched as soon as the first call has consumed `we`)
+        message_inputs_pre(sm, flip, wb, wc, we, W.pre_next.ptsT, in_b_1, pts_b_1, A.frames, n0, N, A.ptsE, A.PAe, A.PCe);
+        message_inputs_pre(sm, flip, wa, wd, we, nullptr, in_b_2, pts_b_2, A.frames, n0, N, A.ptsN, A.PAn, A.PCn);
         return;
     }
-    // decoder: 128 -> 64 -> 32 -> relu -> 16 -> 4
-    VN v = vrelu(dense_small<128>(sm, flip, W.d0_inT, 64, sm.h, W.d0_in_b));
+    // decoder: 128 -> 64 -> 32 -> relu -> 16 -> 4 (weights in wb / wc)
+    VN v;
+    {
+        VN pp = f < 64 ? wdot<32>(wb, sm.h + kq, vn(0.f)) : vn(0.f);
+        // wb is free: the next embedding's 30 dense rows (14 angle features + 16 time features)
+        if (embed_next) {
+            int off = 21 * 128 + f;
+            asm volatile("" : "+v"(off) : "v"(pp.g[0].x));
+#pragma unroll
+            for (int i = 0; i < 30; i++) wb.v[i] = A.embT[off + i * 128];
+            wb.v[30] = A.emb_b[f];
+        }
+        VN r = meet(sm, flip, pp, 128, f, ks);
+        v = f < 64 ? vrelu(vadd(r, vn(db0))) : vn(0.f);
+    }
     if (ks == 0 && f < 64) sm.a[f] = v;
     __syncthreads();
-    v = vrelu(dense_small<64>(sm, flip, W.d0_outT, 32, sm.a, W.d0_out_b));
+    {
+        VN pp = f < 32 ? wdot<16, 0>(wc, sm.a + ks * 16, vn(0.f)) : vn(0.f);
+        VN r = meet(sm, flip, pp, 128, f, ks);
+        v = f < 32 ? vrelu(vadd(r, vn(db1))) : vn(0.f);
+    }
     if (ks == 0 && f < 32) sm.a[64 + f] = v;
     __syncthreads();
-    v = vrelu(dense_small<32>(sm, flip, W.d2_inT, 16, sm.a + 64, W.d2_in_b));
+    {
+        VN pp = f < 16 ? wdot<8, 16>(wc, sm.a + 64 + ks * 8, vn(0.f)) : vn(0.f);
+        VN r = meet(sm, flip, pp, 128, f, ks);
+        v = f < 16 ? vrelu(vadd(r, vn(db2))) : vn(0.f);
+    }
     if (ks == 0 && f < 16) sm.a[96 + f] = v;
     __syncthreads();
-    v = dense_small<16>(sm, flip, W.d2_outT, 4, sm.a + 96, W.d2_out_b);
+    {
+        VN pp = f < 4 ? wdot<4, 24>(wc, sm.a + 96 + ks * 4, vn(0.f)) : vn(0.f);
+        VN r = meet(sm, flip, pp, 128, f, ks);
+        v = f < 4 ? vadd(r, vn(db3)) : vn(0.f);
+    }
     if (ks == 0 && f < 4) {
         sm.a[112 + f] = v;
         store_rows(A.score, 4, n0, N, f, v);
@@ -355,14 +527,40 @@ k_node_update(NodeArgs A, UpdW W, int last_mode, float *chi, int step, int sde, 
     }
     __syncthreads();
     if (!embed_next) return;
-    VN e = embed_pre(sm, A, chi, step + 1, n0);
-    VN h = layernorm(sm, rflip, e, A.emb_g[f], A.emb_beta[f]);
-    if (ks == 0) {
-        store_rows(A.hV, 128, n0, N, f, h);
-        sm.h[f] = h;
+    // next step's node embedding (embed_pre with the dense rows already in wb)
+    {
+        if (t < 6) sm.p[t] = load_rows(A.bb_sincos, 6, n0, N, t);
+        else if (t < 14) {
+            int k = (t - 6) >> 1, sc = (t - 6) & 1;
+            VN x = load_rows(chi, 4, n0, N, k), mk = load_rows(A.sc_mask, 4, n0, N, k), sv;
+            VN_FOR sv.g[gi] = sc ? make_float4(cosf(x.g[gi].x), cosf(x.g[gi].y), cosf(x.g[gi].z), cosf(x.g[gi].w))
+                                 : make_float4(sinf(x.g[gi].x), sinf(x.g[gi].y), sinf(x.g[gi].z), sinf(x.g[gi].w));
+            sm.p[t] = vmul(sv, mk);
+        }
+        VN acc = vn(wb.v[30]);
+        VN_FOR {
+            const int b = n0 + 4 * gi;
+            const int t0 = b + 0 < N ? (int)A.rtype[b + 0] : 0, t1 = b + 1 < N ? (int)A.rtype[b + 1] : 0;
+            const int t2 = b + 2 < N ? (int)A.rtype[b + 2] : 0, t3 = b + 3 < N ? (int)A.rtype[b + 3] : 0;
+            acc.g[gi].x += A.embT[t0 * 128 + f]; acc.g[gi].y += A.embT[t1 * 128 + f];
+            acc.g[gi].z += A.embT[t2 * 128 + f]; acc.g[gi].w += A.embT[t3 * 128 + f];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 14; k++) acc = vfma(wb.v[k], sm.p[k], acc);
+        const float *te = A.steps[step + 1].temb;
+        float tacc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; k++) tacc = fmaf(wb.v[14 + k], te[k], tacc);
+        VN e = vadd(acc, vn(tacc));
+        VN h = layernorm(sm, rflip, e, A.emb_g[f], A.emb_beta[f]);
+        if (ks == 0) {
+            store_rows(A.hV, 128, n0, N, f, h);
+            sm.h[f] = h;
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    message_inputs(sm, flip, pre0, A.frames, n0, N, A.ptsN, A.PAn, A.PCn);
+    message_inputs_pre(sm, flip, wa, wd, we, nullptr, in_b_1, pts_b_1, A.frames, n0, N, A.ptsN, A.PAn, A.PCn);
 }
 
 // ---------------------------------------------------------------------------------------------

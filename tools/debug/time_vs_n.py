@@ -11,5 +11,9 @@ for L in Ls:
     b = protein_to_batch(synth.make_complex(L, 77)).to("cuda:0")
     ctx = m._context(b)
     chi = ctx.sample(b.SC_D, torch.linspace(1, 0, 3))
-    ctx.time_kernel(1, 10); ctx.time_kernel(0, 10)
-    print("L=%d  edge %.1f us  node_msg %.1f us" % (L, ctx.time_kernel(1, 30) * 1e3, ctx.time_kernel(0, 30) * 1e3), flush=True)
+    sched = torch.linspace(1, 0, 21)
+    ctx.sample(b.SC_D, sched)
+    r = []
+    for which in (1, 0, 2):
+        ctx.profile_kernel(which); ctx.sample(b.SC_D, sched); r.append(ctx.profile_read()[0] * 1e3)
+    print("L=%d  edge %.1f us  node_msg %.1f us  node_upd %.1f us (in situ)" % (L, r[0], r[1], r[2]), flush=True)
