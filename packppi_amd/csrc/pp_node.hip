@@ -51,47 +51,47 @@ struct UpdW {
     const float *d0_inT, *d0_in_b, *d0_outT, *d0_out_b, *d2_inT, *d2_in_b, *d2_outT, *d2_out_b;
 };
 
-// one feature's values for the NB residues of the block
+// one feature's values for the NB residues of the block (ext vector: fma on it selects v_pk_fma_f32)
+typedef float f4v __attribute__((ext_vector_type(4)));
 struct VN {
-    float4 g[NG];
+    f4v g[NG];
 };
 
 struct Smem {
-    VN part[2][4 * 384];       // ping-pong partial sums (4 K-slices x up to 384 columns)
+    VN part[2][4 * 576];       // ping-pong partial sums (4 K-slices x up to 576 columns)
     VN a[512];                 // wide activation vector (FFN hidden, decoder scratch)
     VN h[128];                 // current node vector
-    VN p[24];                  // local points / small inputs
+    VN p[48];                  // local points / small inputs
     VN red[2][8];              // LayerNorm partials, ping-pong
 };
 
-__device__ __forceinline__ float4 f4(float v) { return make_float4(v, v, v, v); }
-__device__ __forceinline__ float comp(float4 v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w)); }
+__device__ __forceinline__ f4v f4(float v) { return f4v{v, v, v, v}; }
+__device__ __forceinline__ float comp(f4v v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w)); }
 
 #define VN_FOR _Pragma("unroll") for (int gi = 0; gi < NG; gi++)
 __device__ __forceinline__ VN vn(float v) { VN r; VN_FOR r.g[gi] = f4(v); return r; }
 __device__ __forceinline__ VN vfma(float w, const VN &a, VN c) {
-    VN_FOR c.g[gi] = make_float4(fmaf(w, a.g[gi].x, c.g[gi].x), fmaf(w, a.g[gi].y, c.g[gi].y), fmaf(w, a.g[gi].z, c.g[gi].z),
-                                 fmaf(w, a.g[gi].w, c.g[gi].w));
+    VN_FOR c.g[gi] = __builtin_elementwise_fma(f4(w), a.g[gi], c.g[gi]);
     return c;
 }
 __device__ __forceinline__ VN vadd(VN a, const VN &b) {
-    VN_FOR a.g[gi] = make_float4(a.g[gi].x + b.g[gi].x, a.g[gi].y + b.g[gi].y, a.g[gi].z + b.g[gi].z, a.g[gi].w + b.g[gi].w);
+    VN_FOR a.g[gi] = a.g[gi] + b.g[gi];
     return a;
 }
 __device__ __forceinline__ VN vsub(VN a, const VN &b) {
-    VN_FOR a.g[gi] = make_float4(a.g[gi].x - b.g[gi].x, a.g[gi].y - b.g[gi].y, a.g[gi].z - b.g[gi].z, a.g[gi].w - b.g[gi].w);
+    VN_FOR a.g[gi] = a.g[gi] - b.g[gi];
     return a;
 }
 __device__ __forceinline__ VN vmul(VN a, const VN &b) {
-    VN_FOR a.g[gi] = make_float4(a.g[gi].x * b.g[gi].x, a.g[gi].y * b.g[gi].y, a.g[gi].z * b.g[gi].z, a.g[gi].w * b.g[gi].w);
+    VN_FOR a.g[gi] = a.g[gi] * b.g[gi];
     return a;
 }
 __device__ __forceinline__ VN vscale(VN a, float s) {
-    VN_FOR a.g[gi] = make_float4(a.g[gi].x * s, a.g[gi].y * s, a.g[gi].z * s, a.g[gi].w * s);
+    VN_FOR a.g[gi] = a.g[gi] * s;
     return a;
 }
 __device__ __forceinline__ VN vrelu(VN a) {
-    VN_FOR a.g[gi] = make_float4(fmaxf(a.g[gi].x, 0.f), fmaxf(a.g[gi].y, 0.f), fmaxf(a.g[gi].z, 0.f), fmaxf(a.g[gi].w, 0.f));
+    VN_FOR a.g[gi] = f4v{fmaxf(a.g[gi].x, 0.f), fmaxf(a.g[gi].y, 0.f), fmaxf(a.g[gi].z, 0.f), fmaxf(a.g[gi].w, 0.f)};
     return a;
 }
 __device__ __forceinline__ float vcomp(const VN &v, int i) { return comp(v.g[i >> 2], i & 3); }   // i: residue in block
@@ -123,13 +123,22 @@ __device__ __forceinline__ VN meet(Smem &sm, int &flip, const VN &partial, int s
     return vadd(vadd(buf[col], buf[stride + col]), vadd(buf[2 * stride + col], buf[3 * stride + col]));
 }
 
+// all-lanes sum over a wave: four DPP butterfly steps inside each row of 16 lanes (VALU speed), then the four row
+// totals through SGPRs -- no LDS-pipeline permutes (ds_bpermute x 6 levels was ~0.4 us per call)
+__device__ __forceinline__ float wave_sum1(float x) {
+    x += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+    x += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+    x += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x141, 0xF, 0xF, true));  // row_half_mirror
+    x += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x140, 0xF, 0xF, true));  // row_mirror
+    const int xi = __builtin_bit_cast(int, x);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 32));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 48));
+    return (r0 + r1) + (r2 + r3);
+}
 __device__ __forceinline__ VN wave_sum(VN v) {
-    for (int o = 32; o > 0; o >>= 1) {
-        VN_FOR {
-            v.g[gi].x += __shfl_xor(v.g[gi].x, o); v.g[gi].y += __shfl_xor(v.g[gi].y, o);
-            v.g[gi].z += __shfl_xor(v.g[gi].z, o); v.g[gi].w += __shfl_xor(v.g[gi].w, o);
-        }
-    }
+    VN_FOR v.g[gi] = f4v{wave_sum1(v.g[gi].x), wave_sum1(v.g[gi].y), wave_sum1(v.g[gi].z), wave_sum1(v.g[gi].w)};
     return v;
 }
 
@@ -150,10 +159,10 @@ __device__ __forceinline__ VN layernorm(Smem &sm, int &rflip, const VN &v, float
     __syncthreads();
     const VN var = vscale(vadd(r[grp], r[grp + 1]), 1.f / 128.f);
     VN o;
-    VN_FOR o.g[gi] = make_float4(d.g[gi].x * (1.f / sqrtf(var.g[gi].x + 1e-5f)) * g + b,
+    VN_FOR o.g[gi] = f4v{d.g[gi].x * (1.f / sqrtf(var.g[gi].x + 1e-5f)) * g + b,
                                  d.g[gi].y * (1.f / sqrtf(var.g[gi].y + 1e-5f)) * g + b,
                                  d.g[gi].z * (1.f / sqrtf(var.g[gi].z + 1e-5f)) * g + b,
-                                 d.g[gi].w * (1.f / sqrtf(var.g[gi].w + 1e-5f)) * g + b);
+                                 d.g[gi].w * (1.f / sqrtf(var.g[gi].w + 1e-5f)) * g + b};
     return o;
 }
 
@@ -166,8 +175,8 @@ __device__ __forceinline__ VN load_rows(const float *src, int ld, int n0, int N,
     VN v;
     VN_FOR {
         const int b = n0 + 4 * gi;
-        v.g[gi] = make_float4(b + 0 < N ? src[(size_t)(b + 0) * ld + col] : 0.f, b + 1 < N ? src[(size_t)(b + 1) * ld + col] : 0.f,
-                              b + 2 < N ? src[(size_t)(b + 2) * ld + col] : 0.f, b + 3 < N ? src[(size_t)(b + 3) * ld + col] : 0.f);
+        v.g[gi] = f4v{b + 0 < N ? src[(size_t)(b + 0) * ld + col] : 0.f, b + 1 < N ? src[(size_t)(b + 1) * ld + col] : 0.f,
+                              b + 2 < N ? src[(size_t)(b + 2) * ld + col] : 0.f, b + 3 < N ? src[(size_t)(b + 3) * ld + col] : 0.f};
     }
     return v;
 }
@@ -218,8 +227,8 @@ __device__ __forceinline__ VN embed_pre(Smem &sm, const NodeArgs &A, const float
     else if (t < 14) {
         int k = (t - 6) >> 1, sc = (t - 6) & 1;
         VN x = load_rows(chi, 4, n0, A.N, k), m = load_rows(A.sc_mask, 4, n0, A.N, k), v;
-        VN_FOR v.g[gi] = sc ? make_float4(cosf(x.g[gi].x), cosf(x.g[gi].y), cosf(x.g[gi].z), cosf(x.g[gi].w))
-                            : make_float4(sinf(x.g[gi].x), sinf(x.g[gi].y), sinf(x.g[gi].z), sinf(x.g[gi].w));
+        VN_FOR v.g[gi] = sc ? f4v{cosf(x.g[gi].x), cosf(x.g[gi].y), cosf(x.g[gi].z), cosf(x.g[gi].w)}
+                            : f4v{sinf(x.g[gi].x), sinf(x.g[gi].y), sinf(x.g[gi].z), sinf(x.g[gi].w)};
         sm.p[t] = vmul(v, m);
     }
     __syncthreads();
@@ -314,6 +323,21 @@ __device__ __forceinline__ VN wdot(const WSet &w, const VN *act, VN acc) {
     return acc;
 }
 
+// four dot products over the same activation slice in one pass (one LDS read feeds four outputs)
+#define ACC_PIN(a) VN_FOR asm volatile("" : "+v"(a.g[gi].x), "+v"(a.g[gi].y), "+v"(a.g[gi].z), "+v"(a.g[gi].w))
+__device__ __forceinline__ void wdot4(const WSet &w0, const WSet &w1, const WSet &w2, const WSet &w3, const VN *act,
+                                      VN &a0, VN &a1, VN &a2, VN &a3) {
+#pragma unroll
+    for (int i = 0; i < 32; i++) {
+        const VN x = act[i];
+        a0 = vfma(w0.v[i], x, a0);
+        a1 = vfma(w1.v[i], x, a1);
+        a2 = vfma(w2.v[i], x, a2);
+        a3 = vfma(w3.v[i], x, a3);
+        if ((i & 3) == 3) { ACC_PIN(a0); ACC_PIN(a1); ACC_PIN(a2); ACC_PIN(a3); }
+    }
+}
+
 // message_inputs with the weights already in registers (wA, wC: this thread's K-quarter of column f; wP: of column f < 24).
 // refill_ptsT, if not null: the point weights of the NEXT call, fetched into wP as soon as it has been consumed.
 __device__ __forceinline__ void message_inputs_pre(Smem &sm, int &flip, const WSet &wA, const WSet &wC, WSet &wP,
@@ -372,7 +396,7 @@ k_node_update(NodeArgs A, UpdW W, int last_mode, float *chi, int step, int sde, 
     wload<32>(wc, W.ffn_inT, 512, f + 128, kq, 0.f);
     // per-feature vectors and row inputs, all up front
     const float out_b = W.out_b[f], g0 = W.g0[f], b0 = W.b0[f], g1 = W.g1[f], b1 = W.b1[f], ffn_out_b = W.ffn_out_b[f];
-    const float fib0 = W.ffn_in_b[t & 255], fib1 = W.ffn_in_b[256 + (t & 255)];
+    const float fib = W.ffn_in_b[t];
     const VN ms = load_rows(A.msum, 1, n0, N, 0);
     const VN hv = load_rows(A.hV, 128, n0, N, f);
     const VN rm = load_rows(A.rmask, 1, n0, N, 0);
@@ -380,42 +404,31 @@ k_node_update(NodeArgs A, UpdW W, int last_mode, float *chi, int step, int sde, 
     __syncthreads();
     // mean_j mask_j (W_out y_j + b) = W_out mean_j(mask_j y_j) + b mean_j(mask_j)
     VN part = wdot<32>(wa, sm.a + kq, vn(0.f));
-    wload<32>(wa, W.ffn_inT, 512, 256 + f, kq, part.g[0].x);           // FFN-in, half 1
+    wload<32>(wa, W.ffn_inT, 512, 256 + f, kq, part.g[0].x);           // FFN-in, units f + 256, f + 384
     wload<32>(wd, W.ffn_inT, 512, 256 + f + 128, kq, part.g[0].x);
     VN m = meet(sm, flip, part, 128, f, ks);
     m = vadd(m, vscale(ms, out_b));
     VN h1 = layernorm(sm, rflip, vadd(hv, m), g0, b0);
     if (ks == 0) sm.h[f] = h1;
     __syncthreads();
-    // FFN 128 -> 512 in two halves of 256 hidden units: thread (f, ks) builds the ks-th K-quarter of units f and
-    // f + 128 of the half, then threads 0..255 own one unit each
+    // FFN 128 -> 512: thread (f, ks) builds the ks-th K-quarter of hidden units f, f+128, f+256, f+384 in one pass
+    // over h1, then every thread owns one hidden unit
     {
         VN *buf = sm.part[flip];
         flip ^= 1;
-        const VN u0 = wdot<32>(wb, sm.h + kq, vn(0.f)), u1 = wdot<32>(wc, sm.h + kq, vn(0.f));
-        buf[ks * 256 + f] = u0;
-        buf[ks * 256 + f + 128] = u1;
+        VN u0 = vn(0.f), u1 = vn(0.f), u2 = vn(0.f), u3 = vn(0.f);
+        wdot4(wb, wc, wa, wd, sm.h + kq, u0, u1, u2, u3);
+        buf[ks * 512 + f] = u0;
+        buf[ks * 512 + f + 128] = u1;
+        buf[ks * 512 + f + 256] = u2;
+        buf[ks * 512 + f + 384] = u3;
         wload<32>(wb, W.ffn_outT, 128, f, ks * 128, u0.g[0].x);       // FFN-out: this thread's 128 inputs in four sets
         wload<32>(wc, W.ffn_outT, 128, f, ks * 128 + 32, u1.g[0].x);
+        wload<32>(wa, W.ffn_outT, 128, f, ks * 128 + 64, u2.g[0].x);
+        wload<32>(wd, W.ffn_outT, 128, f, ks * 128 + 96, u3.g[0].x);
         __syncthreads();
-        if (t < 256) {
-            VN hd = vadd(vadd(buf[t], buf[256 + t]), vadd(buf[512 + t], buf[768 + t]));
-            sm.a[t] = vrelu(vadd(hd, vn(fib0)));
-        }
-    }
-    {
-        VN *buf = sm.part[flip];
-        flip ^= 1;
-        const VN u0 = wdot<32>(wa, sm.h + kq, vn(0.f)), u1 = wdot<32>(wd, sm.h + kq, vn(0.f));
-        buf[ks * 256 + f] = u0;
-        buf[ks * 256 + f + 128] = u1;
-        wload<32>(wa, W.ffn_outT, 128, f, ks * 128 + 64, u0.g[0].x);
-        wload<32>(wd, W.ffn_outT, 128, f, ks * 128 + 96, u1.g[0].x);
-        __syncthreads();
-        if (t < 256) {
-            VN hd = vadd(vadd(buf[t], buf[256 + t]), vadd(buf[512 + t], buf[768 + t]));
-            sm.a[256 + t] = vrelu(vadd(hd, vn(fib1)));
-        }
+        VN hd = vadd(vadd(buf[t], buf[512 + t]), vadd(buf[1024 + t], buf[1536 + t]));
+        sm.a[t] = vrelu(vadd(hd, vn(fib)));
     }
     __syncthreads();
     part = wdot<32>(wb, sm.a + ks * 128, vn(0.f));
@@ -456,10 +469,51 @@ k_node_update(NodeArgs A, UpdW W, int last_mode, float *chi, int step, int sde, 
     }
     __syncthreads();
     if (mid) {
-        // inputs of this layer's edge message, then of the next layer's node message (whose point weights are
-        // fetched as soon as the first call has consumed `we`)
-        message_inputs_pre(sm, flip, wb, wc, we, W.pre_next.ptsT, in_b_1, pts_b_1, A.frames, n0, N, A.ptsE, A.PAe, A.PCe);
-        message_inputs_pre(sm, flip, wa, wd, we, nullptr, in_b_2, pts_b_2, A.frames, n0, N, A.ptsN, A.PAn, A.PCn);
+        // inputs of this layer's edge message and of the next layer's node message in one pass over h2:
+        // columns PAe 0..127 | PCe 128..255 | PAn 256..383 | PCn 384..511 | ptsE 512..535 | ptsN 536..559
+        VN *buf = sm.part[flip];
+        flip ^= 1;
+        VN u0 = vn(0.f), u1 = vn(0.f), u2 = vn(0.f), u3 = vn(0.f);
+        wdot4(wb, wc, wa, wd, sm.h + kq, u0, u1, u2, u3);
+        buf[ks * 576 + f] = u0;
+        buf[ks * 576 + 128 + f] = u1;
+        buf[ks * 576 + 256 + f] = u2;
+        buf[ks * 576 + 384 + f] = u3;
+        if (f < 24) {
+            const VN up = wdot<32>(we, sm.h + kq, vn(0.f));
+            buf[ks * 576 + 512 + f] = up;
+            wload<32>(we, W.pre_next.ptsT, 24, f, kq, up.g[0].x);
+            buf[ks * 576 + 536 + f] = wdot<32>(we, sm.h + kq, vn(0.f));
+        }
+        __syncthreads();
+        {
+            const int c = ks * 128 + f;           // ks-group 0: PAe, 1: PCe, 2: PAn, 3: PCn
+            VN a = vadd(vadd(buf[c], buf[576 + c]), vadd(buf[1152 + c], buf[1728 + c]));
+            if (ks == 0) store_rows(A.PAe, 128, n0, N, f, vadd(a, vn(in_b_1)));
+            else if (ks == 1) store_rows(A.PCe, 128, n0, N, f, a);
+            else if (ks == 2) store_rows(A.PAn, 128, n0, N, f, vadd(a, vn(in_b_2)));
+            else store_rows(A.PCn, 128, n0, N, f, a);
+            if (ks < 2 && f < 24) {               // local points: ks-group 0 -> edge message, 1 -> next node message
+                const int pc = 512 + 24 * ks + f;
+                VN pl = vadd(vadd(buf[pc], buf[576 + pc]), vadd(buf[1152 + pc], buf[1728 + pc]));
+                pl = vadd(pl, vn(ks == 0 ? pts_b_1 : pts_b_2));
+                sm.p[24 * ks + f] = pl;
+                store_rows(ks == 0 ? A.ptsE : A.ptsN, 48, n0, N, f, pl);
+            }
+        }
+        __syncthreads();
+        if (t < 16 * NB) {                        // (message m, point q, residue i): p_glob = R p_loc + t
+            const int mm = t / (8 * NB), q = (t / NB) & 7, i = t % NB;
+            const int n = n0 + i;
+            if (n < N) {
+                float *pts = mm == 0 ? A.ptsE : A.ptsN;
+                const float *fr = A.frames + (size_t)n * 12;
+                const float x = vcomp(sm.p[24 * mm + 3 * q], i), y = vcomp(sm.p[24 * mm + 3 * q + 1], i),
+                            z = vcomp(sm.p[24 * mm + 3 * q + 2], i);
+                for (int r = 0; r < 3; r++)
+                    pts[(size_t)n * 48 + 24 + 3 * q + r] = (fr[3 * r] * x + fr[3 * r + 1] * y + fr[3 * r + 2] * z) + fr[9 + r];
+            }
+        }
         return;
     }
     // decoder: 128 -> 64 -> 32 -> relu -> 16 -> 4 (weights in wb / wc)
@@ -533,8 +587,8 @@ k_node_update(NodeArgs A, UpdW W, int last_mode, float *chi, int step, int sde, 
         else if (t < 14) {
             int k = (t - 6) >> 1, sc = (t - 6) & 1;
             VN x = load_rows(chi, 4, n0, N, k), mk = load_rows(A.sc_mask, 4, n0, N, k), sv;
-            VN_FOR sv.g[gi] = sc ? make_float4(cosf(x.g[gi].x), cosf(x.g[gi].y), cosf(x.g[gi].z), cosf(x.g[gi].w))
-                                 : make_float4(sinf(x.g[gi].x), sinf(x.g[gi].y), sinf(x.g[gi].z), sinf(x.g[gi].w));
+            VN_FOR sv.g[gi] = sc ? f4v{cosf(x.g[gi].x), cosf(x.g[gi].y), cosf(x.g[gi].z), cosf(x.g[gi].w)}
+                                 : f4v{sinf(x.g[gi].x), sinf(x.g[gi].y), sinf(x.g[gi].z), sinf(x.g[gi].w)};
             sm.p[t] = vmul(sv, mk);
         }
         VN acc = vn(wb.v[30]);
