@@ -408,9 +408,15 @@ k_node_update(NodeArgs A, UpdW W, int last_mode, float *chi, int step, int sde, 
     wload<32>(wd, W.ffn_inT, 512, 256 + f + 128, kq, part.g[0].x);
     VN m = meet(sm, flip, part, 128, f, ks);
     m = vadd(m, vscale(ms, out_b));
+#if defined(PP_X_NU_STOP) && PP_X_NU_STOP == 1
+    return;
+#endif
     VN h1 = layernorm(sm, rflip, vadd(hv, m), g0, b0);
     if (ks == 0) sm.h[f] = h1;
     __syncthreads();
+#if defined(PP_X_NU_STOP) && PP_X_NU_STOP == 2
+    return;
+#endif
     // FFN 128 -> 512: thread (f, ks) builds the ks-th K-quarter of hidden units f, f+128, f+256, f+384 in one pass
     // over h1, then every thread owns one hidden unit
     {
@@ -431,6 +437,9 @@ k_node_update(NodeArgs A, UpdW W, int last_mode, float *chi, int step, int sde, 
         sm.a[t] = vrelu(vadd(hd, vn(fib)));
     }
     __syncthreads();
+#if defined(PP_X_NU_STOP) && PP_X_NU_STOP == 3
+    return;
+#endif
     part = wdot<32>(wb, sm.a + ks * 128, vn(0.f));
     part = wdot<32>(wc, sm.a + ks * 128 + 32, part);
     part = wdot<32>(wa, sm.a + ks * 128 + 64, part);
@@ -461,6 +470,9 @@ k_node_update(NodeArgs A, UpdW W, int last_mode, float *chi, int step, int sde, 
     }
     VN o = meet(sm, flip, part, 128, f, ks);
     o = vadd(o, vn(ffn_out_b));
+#if defined(PP_X_NU_STOP) && PP_X_NU_STOP == 4
+    return;
+#endif
     VN h2 = layernorm(sm, rflip, vadd(h1, o), g1, b1);
     h2 = vmul(h2, rm);
     if (ks == 0) {
@@ -468,6 +480,12 @@ k_node_update(NodeArgs A, UpdW W, int last_mode, float *chi, int step, int sde, 
         sm.h[f] = h2;
     }
     __syncthreads();
+#if defined(PP_X_NU_STOP) && PP_X_NU_STOP == 5
+    return;
+#endif
+#if defined(PP_X_NU_STOP) && PP_X_NU_STOP == 6
+    if (!mid) return;
+#endif
     if (mid) {
         // inputs of this layer's edge message and of the next layer's node message in one pass over h2:
         // columns PAe 0..127 | PCe 128..255 | PAn 256..383 | PCn 384..511 | ptsE 512..535 | ptsN 536..559
