@@ -96,12 +96,14 @@ static void put_chunk(std::vector<float> &arena, const float *W, int ld, int row
                     d[((wave * 4 + q) * 64 + lane) * 4 + pp] = W[(size_t)(row0 + row) * ld + col0 + col];
                 }
 }
-// chunk stream of one message MLP: W_in[:,128:256] x4, W_in[:,384:456] x3 (24 cols), W_mid x4 [, W_out x4, FFN blocks]
-static size_t put_stream(std::vector<float> &arena, const float *w, const LayerOff &L, bool edge) {
+// chunk stream of one message MLP: [W_in[:,128:256] x4 unless `skip_wb`,] W_in[:,384:456] x3 (24 cols), W_mid x4
+// [, W_out x4, FFN blocks].  Layer 0 skips the W_B chunks: its W_B h_E0 is precomputed once per complex (k_edge_static).
+static size_t put_stream(std::vector<float> &arena, const float *w, const LayerOff &L, bool edge, bool skip_wb) {
     size_t at = (arena.size() + 3) & ~size_t(3);
     arena.resize(at);
     const float *win = w + (edge ? L.em_in_w : L.nm_in_w), *wmid = w + (edge ? L.em_mid_w : L.nm_mid_w);
-    for (int s = 0; s < 4; s++) put_chunk(arena, win, 456, 0, 128 + 32 * s, 32);
+    if (!skip_wb)
+        for (int s = 0; s < 4; s++) put_chunk(arena, win, 456, 0, 128 + 32 * s, 32);
     for (int g = 0; g < 3; g++) put_chunk(arena, win, 456, 0, 384 + 24 * g, 24);
     for (int s = 0; s < 4; s++) put_chunk(arena, wmid, 128, 0, 32 * s, 32);
     if (edge) {
@@ -111,6 +113,14 @@ static size_t put_stream(std::vector<float> &arena, const float *w, const LayerO
             for (int s = 0; s < 4; s++) put_chunk(arena, w + L.ed_out_w, 512, 0, 128 * c + 32 * s, 32);
         }
     }
+    return at;
+}
+// k_edge_static's stream: the W_B chunks of layer 0's node message, then of its edge message
+static size_t put_static_stream(std::vector<float> &arena, const float *w, const LayerOff &L) {
+    size_t at = (arena.size() + 3) & ~size_t(3);
+    arena.resize(at);
+    for (int s = 0; s < 4; s++) put_chunk(arena, w + L.nm_in_w, 456, 0, 128 + 32 * s, 32);
+    for (int s = 0; s < 4; s++) put_chunk(arena, w + L.em_in_w, 456, 0, 128 + 32 * s, 32);
     return at;
 }
 // the edge kernel's small per-layer vectors in one block (staged to LDS once per workgroup):
@@ -175,10 +185,11 @@ extern "C" pp_status pp_plan_create(const float *weights, size_t n_weights, cons
         o_l[l][6] = put_T4(arena, weights + L.nm_out_w, 128, 128, 0, 128);
         o_l[l][7] = put_T4(arena, weights + L.nd_in_w, 512, 128, 0, 128);
         o_l[l][8] = put_T4(arena, weights + L.nd_out_w, 128, 512, 0, 512);
-        o_l[l][9] = put_stream(arena, weights, L, false);
-        o_l[l][10] = put_stream(arena, weights, L, true);
+        o_l[l][9] = put_stream(arena, weights, L, false, l == 0);
+        o_l[l][10] = put_stream(arena, weights, L, true, l == 0);
         o_l[l][11] = put_edge_params(arena, weights, L);
     }
+    size_t o_static = put_static_stream(arena, weights, off.layer[0]);
     size_t o_d0i = put_T4(arena, weights + off.d0_in_w, 64, 128, 0, 128);
     size_t o_d0o = put_T4(arena, weights + off.d0_out_w, 32, 64, 0, 64);
     size_t o_d2i = put_T4(arena, weights + off.d2_in_w, 16, 32, 0, 32);
@@ -196,6 +207,7 @@ extern "C" pp_status pp_plan_create(const float *weights, size_t n_weights, cons
         t.nm_stream = p->wT + o_l[l][9]; t.em_stream = p->wT + o_l[l][10];
         t.em_params = p->wT + o_l[l][11];
     }
+    p->static_stream = p->wT + o_static;
     p->d0_in_T = p->wT + o_d0i; p->d0_out_T = p->wT + o_d0o;
     p->d2_in_T = p->wT + o_d2i; p->d2_out_T = p->wT + o_d2o;
     }
@@ -241,7 +253,7 @@ static pp_status dalloc(T **p, size_t n) {
 
 extern "C" void pp_ctx_destroy(pp_ctx *c) {
     if (!c) return;
-    void *ptrs[] = {c->eidx, c->mask_att, c->frames, c->bbpos, c->hE0, c->hE, c->hV, c->S, c->msum, c->ptsN, c->PAn,
+    void *ptrs[] = {c->Znm, c->Zem, c->eidx, c->mask_att, c->frames, c->bbpos, c->hE0, c->hE, c->hV, c->S, c->msum, c->ptsN, c->PAn,
                     c->PCn, c->ptsE, c->PAe, c->PCe, c->score, c->chi_tmp, c->steps, c->xyz, c->axes, c->brad,
                     c->per_res, c->dchi, c->px, c->pm, c->pv, c->pz, c->pxeff, c->pmask, c->scal, c->dbg};
     for (void *q : ptrs) if (q) hipFree(q);
@@ -273,7 +285,7 @@ extern "C" pp_status pp_complex_prepare(pp_plan *plan, const pp_batch *b, void *
 #define ALLOC(field, n) if (st == PP_OK) st = dalloc(&c->field, (n))
     if (net) {
     ALLOC(eidx, N * K); ALLOC(mask_att, N * 32); ALLOC(frames, N * 12); ALLOC(bbpos, N * 15);
-    ALLOC(hE0, N * K * 128); ALLOC(hE, N * K * 128); ALLOC(hV, N * 128); ALLOC(S, N * 128); ALLOC(msum, N);
+    ALLOC(hE0, N * K * 128); ALLOC(hE, N * K * 128); ALLOC(Znm, N * K * 128); ALLOC(Zem, N * K * 128); ALLOC(hV, N * 128); ALLOC(S, N * 128); ALLOC(msum, N);
     ALLOC(ptsN, N * 48); ALLOC(PAn, N * 128); ALLOC(PCn, N * 128);
     ALLOC(ptsE, N * 48); ALLOC(PAe, N * 128); ALLOC(PCe, N * 128);
     ALLOC(score, N * 4); ALLOC(chi_tmp, N * 4);
@@ -290,6 +302,7 @@ extern "C" pp_status pp_complex_prepare(pp_plan *plan, const pp_batch *b, void *
         st = PP_ERR_HIP;
     }
     if (net && st == PP_OK) st = pp_launch_prepare(c, static_cast<hipStream_t>(stream));
+    if (net && st == PP_OK) st = pp_launch_edge_static(c, static_cast<hipStream_t>(stream));
     if (st != PP_OK) { pp_ctx_destroy(c); return st; }
     *out = c;
     return PP_OK;

@@ -53,6 +53,8 @@ struct EdgeArgs {
     const float *params;       // edge kernel: b_mid | b_out | ffn_out_b | g2 | be2 | ffn_in_b[512]
     const float *g3, *be3;     // edge kernel: last LayerNorm (read in the epilogue)
     const float *b_mid;        // node kernel (per-lane read)
+    const float *Z;            // layer 0: precomputed W_B h_E0 of this message function [N][K][128]
+    float *Znm, *Zem;          // k_edge_static outputs
 };
 enum { P_BMID = 0, P_BOUT = 128, P_FOB = 256, P_G2 = 384, P_BE2 = 512, P_FIB = 640 };
 
@@ -242,17 +244,20 @@ __device__ __forceinline__ void edge_geometry(const float *__restrict__ pts_i, c
         BODY;                                                                                                  \
     }
 
-// shared first layer (chunks 0..6 = W_B x4, W_G x3): acc (tile `wave`) = PA_i + PC_j + W_B h_E + W_G geom, ReLU
-#define FIRST_LAYER(NCH)                                                      \
-    WSTAGE(0, NCH, mfma_tile32<false>(wslot, x[0], acc, lane))                \
-    WSTAGE(1, NCH, mfma_tile32<false>(wslot, x[1], acc, lane))                \
-    WSTAGE(2, NCH, mfma_tile32<false>(wslot, x[2], acc, lane))                \
-    WSTAGE(3, NCH, mfma_tile32<false>(wslot, x[3], acc, lane))                \
-    WSTAGE(4, NCH, mfma_tile24(wslot, g[0], acc, lane))                       \
-    WSTAGE(5, NCH, mfma_tile24(wslot, g[1], acc, lane))                       \
-    WSTAGE(6, NCH, mfma_tile24(wslot, g[2], acc, lane))                       \
-    relu_tile(acc);                                                           \
-    xbuf_put(xbuf, wave, lane, acc);                                          \
+// shared first layer: acc (tile `wave`) = PA_i + PC_j + W_B h_E + W_G geom, ReLU.  Chunks W_B x4 (absent when ST0:
+// layer 0's W_B h_E0 is timestep-invariant and arrives precomputed in acc), then W_G x3.  C0 = number of W_B chunks.
+#define FIRST_LAYER(NCH)                                                          \
+    if constexpr (!ST0) {                                                         \
+        WSTAGE(0, NCH, mfma_tile32<false>(wslot, x[0], acc, lane))                \
+        WSTAGE(1, NCH, mfma_tile32<false>(wslot, x[1], acc, lane))                \
+        WSTAGE(2, NCH, mfma_tile32<false>(wslot, x[2], acc, lane))                \
+        WSTAGE(3, NCH, mfma_tile32<false>(wslot, x[3], acc, lane))                \
+    }                                                                             \
+    WSTAGE(C0 + 0, NCH, mfma_tile24(wslot, g[0], acc, lane))                      \
+    WSTAGE(C0 + 1, NCH, mfma_tile24(wslot, g[1], acc, lane))                      \
+    WSTAGE(C0 + 2, NCH, mfma_tile24(wslot, g[2], acc, lane))                      \
+    relu_tile(acc);                                                               \
+    xbuf_put(xbuf, wave, lane, acc);                                              \
     __syncthreads();
 
 #define PROLOGUE_PIPE()                                                                        \
@@ -274,7 +279,7 @@ __device__ __forceinline__ void edge_geometry(const float *__restrict__ pts_i, c
 #define PP_EU_WGS 3
 #endif
 
-template <int S>
+template <int S, bool ST0>
 __global__ void __launch_bounds__(ET, 3)
 k_node_message(EdgeArgs A) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -289,7 +294,8 @@ k_node_message(EdgeArgs A) {
         if (tid == 0) A.msum[n] = 0.f;
         return;
     }
-    constexpr int NCH = 11;               // chunks: W_B 0..3, W_G 4..6, W_mid 7..10
+    constexpr int C0 = ST0 ? 0 : 4;
+    constexpr int NCH = C0 + 7;           // chunks: [W_B x4,] W_G x3, W_mid x4
     PROLOGUE_PIPE()
 
     f32x16 x[4], acc;
@@ -309,10 +315,13 @@ k_node_message(EdgeArgs A) {
     edge_geometry(A.pts + (size_t)n * 48, A.frames + (size_t)n * 12, A.pts + (size_t)nbr * 48, h, g);
     {
         const float *hrow = A.hE_in + ((size_t)n * K + jj) * 128;
+        if constexpr (!ST0) {
 #pragma unroll
-        for (int t = 0; t < 4; t++) load_tile(hrow + 32 * t, h, x[t]);
+            for (int t = 0; t < 4; t++) load_tile(hrow + 32 * t, h, x[t]);
+        }
         load_tile(A.PA + (size_t)n * 128 + 32 * wave, h, acc);
         add_tile(A.PC + (size_t)nbr * 128 + 32 * wave, h, acc);
+        if constexpr (ST0) add_tile(A.Z + ((size_t)n * K + jj) * 128 + 32 * wave, h, acc);
     }
     FIRST_LAYER(NCH)
     {
@@ -321,10 +330,10 @@ k_node_message(EdgeArgs A) {
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[r] = bmid;
     }
-    WSTAGE(7, NCH, mfma_tile32<true>(wslot, x[0], acc, lane))
-    WSTAGE(8, NCH, mfma_tile32<true>(wslot, x[1], acc, lane))
-    WSTAGE(9, NCH, mfma_tile32<true>(wslot, x[2], acc, lane))
-    WSTAGE(10, NCH, mfma_tile32<true>(wslot, x[3], acc, lane))
+    WSTAGE(C0 + 3, NCH, mfma_tile32<true>(wslot, x[0], acc, lane))
+    WSTAGE(C0 + 4, NCH, mfma_tile32<true>(wslot, x[1], acc, lane))
+    WSTAGE(C0 + 5, NCH, mfma_tile32<true>(wslot, x[2], acc, lane))
+    WSTAGE(C0 + 6, NCH, mfma_tile32<true>(wslot, x[3], acc, lane))
     {
         // rows (registers) are edges e = 8 (r>>2) + 4 h + (r&3); mask and reduce over them
         float s = 0.f, ms = 0.f;
@@ -346,20 +355,20 @@ k_node_message(EdgeArgs A) {
 // FFN hidden block c (chunks 15 + 8c ..): W1 s=0..3 -> hidden tile 4c+wave -> exchange -> W2 s'=0..3 accumulate into out
 #define FFN_BLOCK(c)                                                                                         \
     load_tile(prm + P_FIB + 128 * (c) + 32 * wave, h, acc);                                                  \
-    WSTAGE(15 + 8 * (c) + 0, NCH, mfma_tile32<false>(wslot, x[0], acc, lane))                                \
-    WSTAGE(15 + 8 * (c) + 1, NCH, mfma_tile32<false>(wslot, x[1], acc, lane))                                \
-    WSTAGE(15 + 8 * (c) + 2, NCH, mfma_tile32<false>(wslot, x[2], acc, lane))                                \
-    WSTAGE(15 + 8 * (c) + 3, NCH, mfma_tile32<false>(wslot, x[3], acc, lane))                                \
+    WSTAGE(C0 + 11 + 8 * (c) + 0, NCH, mfma_tile32<false>(wslot, x[0], acc, lane))                                \
+    WSTAGE(C0 + 11 + 8 * (c) + 1, NCH, mfma_tile32<false>(wslot, x[1], acc, lane))                                \
+    WSTAGE(C0 + 11 + 8 * (c) + 2, NCH, mfma_tile32<false>(wslot, x[2], acc, lane))                                \
+    WSTAGE(C0 + 11 + 8 * (c) + 3, NCH, mfma_tile32<false>(wslot, x[3], acc, lane))                                \
     relu_tile(acc);                                                                                          \
     __syncthreads();          /* every wave is done reading the previous exchange */                        \
     xbuf_put(xbuf, wave, lane, acc);                                                                         \
     __syncthreads();                                                                                         \
-    WSTAGE(15 + 8 * (c) + 4, NCH, xbuf_get(xbuf, 0, lane, acc); mfma_tile32<false>(wslot, acc, out, lane))   \
-    WSTAGE(15 + 8 * (c) + 5, NCH, xbuf_get(xbuf, 1, lane, acc); mfma_tile32<false>(wslot, acc, out, lane))   \
-    WSTAGE(15 + 8 * (c) + 6, NCH, xbuf_get(xbuf, 2, lane, acc); mfma_tile32<false>(wslot, acc, out, lane))   \
-    WSTAGE(15 + 8 * (c) + 7, NCH, xbuf_get(xbuf, 3, lane, acc); mfma_tile32<false>(wslot, acc, out, lane))
+    WSTAGE(C0 + 11 + 8 * (c) + 4, NCH, xbuf_get(xbuf, 0, lane, acc); mfma_tile32<false>(wslot, acc, out, lane))   \
+    WSTAGE(C0 + 11 + 8 * (c) + 5, NCH, xbuf_get(xbuf, 1, lane, acc); mfma_tile32<false>(wslot, acc, out, lane))   \
+    WSTAGE(C0 + 11 + 8 * (c) + 6, NCH, xbuf_get(xbuf, 2, lane, acc); mfma_tile32<false>(wslot, acc, out, lane))   \
+    WSTAGE(C0 + 11 + 8 * (c) + 7, NCH, xbuf_get(xbuf, 3, lane, acc); mfma_tile32<false>(wslot, acc, out, lane))
 
-template <int S>
+template <int S, bool ST0>
 __global__ void __launch_bounds__(ET, PP_EU_WGS)
 k_edge_update(EdgeArgs A) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -383,8 +392,9 @@ k_edge_update(EdgeArgs A) {
         }
         return;
     }
-    // chunks: W_B 0..3, W_G 4..6, W_mid 7..10, W_out 11..14, then per hidden block c: W1 x4, W2 x4
-    constexpr int NCH = 47;
+    // chunks: [W_B x4,] W_G x3, W_mid x4, W_out x4, then per hidden block c: W1 x4, W2 x4
+    constexpr int C0 = ST0 ? 0 : 4;
+    constexpr int NCH = C0 + 43;
     PROLOGUE_PIPE()
 
     f32x16 x[4], acc, out;
@@ -398,10 +408,13 @@ k_edge_update(EdgeArgs A) {
     edge_geometry(A.pts + (size_t)n * 48, A.frames + (size_t)n * 12, A.pts + (size_t)nbr * 48, h, g);
     __builtin_amdgcn_sched_barrier(0);        // geometry temporaries die before the activation tiles are loaded
     {
+        if constexpr (!ST0) {
 #pragma unroll
-        for (int t = 0; t < 4; t++) load_tile(hrow + 32 * t, h, x[t]);
+            for (int t = 0; t < 4; t++) load_tile(hrow + 32 * t, h, x[t]);
+        }
         load_tile(A.PA + (size_t)n * 128 + 32 * wave, h, acc);
         add_tile(A.PC + (size_t)nbr * 128 + 32 * wave, h, acc);
+        if constexpr (ST0) add_tile(A.Z + ((size_t)n * K + jj) * 128 + 32 * wave, h, acc);
     }
     FIRST_LAYER(NCH)
     // ---- second layer (chunks 7..10) -------------------------------------------------------------
@@ -410,10 +423,10 @@ k_edge_update(EdgeArgs A) {
         for (int t = 0; t < 4; t++) xbuf_get(xbuf, t, lane, x[t]);
         load_tile(prm + P_BMID + 32 * wave, h, acc);
     }
-    WSTAGE(7, NCH, mfma_tile32<false>(wslot, x[0], acc, lane))
-    WSTAGE(8, NCH, mfma_tile32<false>(wslot, x[1], acc, lane))
-    WSTAGE(9, NCH, mfma_tile32<false>(wslot, x[2], acc, lane))
-    WSTAGE(10, NCH, mfma_tile32<false>(wslot, x[3], acc, lane))
+    WSTAGE(C0 + 3, NCH, mfma_tile32<false>(wslot, x[0], acc, lane))
+    WSTAGE(C0 + 4, NCH, mfma_tile32<false>(wslot, x[1], acc, lane))
+    WSTAGE(C0 + 5, NCH, mfma_tile32<false>(wslot, x[2], acc, lane))
+    WSTAGE(C0 + 6, NCH, mfma_tile32<false>(wslot, x[3], acc, lane))
     relu_tile(acc);
     __syncthreads();
     xbuf_put(xbuf, wave, lane, acc);
@@ -426,13 +439,13 @@ k_edge_update(EdgeArgs A) {
     }
     // The exchange buffer is idle during this layer: once every wave has its B operands (barrier), each wave parks
     // the residual input of the first LayerNorm -- its own tile of h_E -- in its own exchange tile by LDS-DMA.  The copy
-    // is older than the weight chunks issued below, so the vmcnt wait of stage 14 covers it.
+    // is older than the weight chunks issued below, so the vmcnt wait of the layer's last stage covers it.
     __syncthreads();
     dma_tile(hrow + 32 * wave + 4 * h, (unsigned)(size_t)(xbuf + wave * 1024));
-    WSTAGE(11, NCH, mfma_tile32<false>(wslot, x[0], acc, lane))
-    WSTAGE(12, NCH, mfma_tile32<false>(wslot, x[1], acc, lane))
-    WSTAGE(13, NCH, mfma_tile32<false>(wslot, x[2], acc, lane))
-    WSTAGE(14, NCH, mfma_tile32<false>(wslot, x[3], acc, lane))
+    WSTAGE(C0 + 7, NCH, mfma_tile32<false>(wslot, x[0], acc, lane))
+    WSTAGE(C0 + 8, NCH, mfma_tile32<false>(wslot, x[1], acc, lane))
+    WSTAGE(C0 + 9, NCH, mfma_tile32<false>(wslot, x[2], acc, lane))
+    WSTAGE(C0 + 10, NCH, mfma_tile32<false>(wslot, x[3], acc, lane))
     // publish v = h_E + mask * m for the first LayerNorm (own tile: read, then overwritten in place)
     xbuf_get(xbuf, wave, lane, out);
 #pragma unroll
@@ -481,6 +494,43 @@ k_edge_update(EdgeArgs A) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------------
+// once per complex: Z_nm = W_B(node message, layer 0) h_E0 and Z_em = W_B(edge message, layer 0) h_E0.  h_E0 never
+// changes during sampling, so the layer-0 kernels skip four of their stages and start from these tiles.
+// ---------------------------------------------------------------------------------------------
+template <int S>
+__global__ void __launch_bounds__(ET, 3)
+k_edge_static(EdgeArgs A) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    const int n = blockIdx.x;
+    const int K = A.K;
+    if (A.rmask[n] == 0.f) return;        // never read: the layer kernels leave masked residues early as well
+    constexpr int NCH = 8;                // chunks: W_B(node message) x4, W_B(edge message) x4
+    PROLOGUE_PIPE()
+    f32x16 x[4], acc;
+    const int jj = j < K ? j : K - 1;
+    const float *hrow = A.hE_in + ((size_t)n * K + jj) * 128;
+#pragma unroll
+    for (int t = 0; t < 4; t++) load_tile(hrow + 32 * t, h, x[t]);
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = 0.f;
+    WSTAGE(0, NCH, mfma_tile32<false>(wslot, x[0], acc, lane))
+    WSTAGE(1, NCH, mfma_tile32<false>(wslot, x[1], acc, lane))
+    WSTAGE(2, NCH, mfma_tile32<false>(wslot, x[2], acc, lane))
+    WSTAGE(3, NCH, mfma_tile32<false>(wslot, x[3], acc, lane))
+    if (j < K) store_tile(A.Znm + ((size_t)n * K + j) * 128 + 32 * wave, h, acc);
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = 0.f;
+    WSTAGE(4, NCH, mfma_tile32<false>(wslot, x[0], acc, lane))
+    WSTAGE(5, NCH, mfma_tile32<false>(wslot, x[1], acc, lane))
+    WSTAGE(6, NCH, mfma_tile32<false>(wslot, x[2], acc, lane))
+    WSTAGE(7, NCH, mfma_tile32<false>(wslot, x[3], acc, lane))
+    if (j < K) store_tile(A.Zem + ((size_t)n * K + j) * 128 + 32 * wave, h, acc);
+}
+
 static EdgeArgs edge_args(pp_ctx *c, int layer, bool edge) {
     const pp_plan *p = c->plan;
     const LayerOff &o = p->off.layer[layer];
@@ -498,6 +548,8 @@ static EdgeArgs edge_args(pp_ctx *c, int layer, bool edge) {
     A.params = p->lt[layer].em_params;
     A.g3 = p->w + o.norm_g[3]; A.be3 = p->w + o.norm_b[3];
     A.b_mid = p->w + o.nm_mid_b;
+    A.Z = edge ? c->Zem : c->Znm;
+    A.Znm = c->Znm; A.Zem = c->Zem;
     return A;
 }
 
@@ -507,15 +559,19 @@ static const size_t EU_SMEM = (4 * PP_EU_SLOTS * 1024 + XBUF_FLOATS) * sizeof(fl
 #else
 static const size_t EU_SMEM = (4 * PP_EU_SLOTS * 1024 + XBUF_FLOATS + PARAM_FLOATS) * sizeof(float);
 #endif
+static const size_t ST_SMEM = (4 * 2 * 1024) * sizeof(float);
 
 static bool edge_attrs() {
     static bool done = false, ok = false;
     if (!done) {
         done = true;
-        ok = hipFuncSetAttribute(reinterpret_cast<const void *>(k_node_message<PP_NM_SLOTS>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)NM_SMEM) == hipSuccess &&
-             hipFuncSetAttribute(reinterpret_cast<const void *>(k_edge_update<PP_EU_SLOTS>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)EU_SMEM) == hipSuccess;
+        auto set = [](const void *f, size_t bytes) {
+            return hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess;
+        };
+        ok = set(reinterpret_cast<const void *>(k_node_message<PP_NM_SLOTS, false>), NM_SMEM) &&
+             set(reinterpret_cast<const void *>(k_node_message<PP_NM_SLOTS, true>), NM_SMEM) &&
+             set(reinterpret_cast<const void *>(k_edge_update<PP_EU_SLOTS, false>), EU_SMEM) &&
+             set(reinterpret_cast<const void *>(k_edge_update<PP_EU_SLOTS, true>), EU_SMEM);
     }
     return ok;
 }
@@ -523,22 +579,39 @@ static bool edge_attrs() {
 // resident workgroups per CU the runtime predicts for the two kernels (measurement aid)
 void pp_edge_occupancy(int *node_msg, int *edge_upd) {
     edge_attrs();
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(node_msg, reinterpret_cast<const void *>(k_node_message<PP_NM_SLOTS>), ET, NM_SMEM);
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(edge_upd, reinterpret_cast<const void *>(k_edge_update<PP_EU_SLOTS>), ET, EU_SMEM);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(node_msg, reinterpret_cast<const void *>(k_node_message<PP_NM_SLOTS, false>), ET, NM_SMEM);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(edge_upd, reinterpret_cast<const void *>(k_edge_update<PP_EU_SLOTS, false>), ET, EU_SMEM);
+}
+
+#define EDGE_ATTR_CHECK()                                                                                   \
+    if (!edge_attrs()) {                                                                                    \
+        pp_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for the edge kernels");        \
+        return PP_ERR_HIP;                                                                                  \
+    }
+
+pp_status pp_launch_edge_static(pp_ctx *c, hipStream_t s) {
+    EDGE_ATTR_CHECK()
+    EdgeArgs A = edge_args(c, 0, false);
+    A.wstream = c->plan->static_stream;
+    hipLaunchKernelGGL(k_edge_static<2>, dim3(c->N), dim3(ET), ST_SMEM, s, A);
+    PP_HIP_CHECK(hipGetLastError());
+    return PP_OK;
 }
 
 pp_status pp_launch_node_message(pp_ctx *c, int layer, hipStream_t s) {
-    if (!edge_attrs()) { pp_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for the edge kernels"); return PP_ERR_HIP; }
+    EDGE_ATTR_CHECK()
     EdgeArgs A = edge_args(c, layer, false);
-    hipLaunchKernelGGL(k_node_message<PP_NM_SLOTS>, dim3(c->N), dim3(ET), NM_SMEM, s, A);
+    if (layer == 0) hipLaunchKernelGGL((k_node_message<PP_NM_SLOTS, true>), dim3(c->N), dim3(ET), NM_SMEM, s, A);
+    else hipLaunchKernelGGL((k_node_message<PP_NM_SLOTS, false>), dim3(c->N), dim3(ET), NM_SMEM, s, A);
     PP_HIP_CHECK(hipGetLastError());
     return PP_OK;
 }
 
 pp_status pp_launch_edge_update(pp_ctx *c, int layer, hipStream_t s) {
-    if (!edge_attrs()) { pp_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for the edge kernels"); return PP_ERR_HIP; }
+    EDGE_ATTR_CHECK()
     EdgeArgs A = edge_args(c, layer, true);
-    hipLaunchKernelGGL(k_edge_update<PP_EU_SLOTS>, dim3(c->N), dim3(ET), EU_SMEM, s, A);
+    if (layer == 0) hipLaunchKernelGGL((k_edge_update<PP_EU_SLOTS, true>), dim3(c->N), dim3(ET), EU_SMEM, s, A);
+    else hipLaunchKernelGGL((k_edge_update<PP_EU_SLOTS, false>), dim3(c->N), dim3(ET), EU_SMEM, s, A);
     PP_HIP_CHECK(hipGetLastError());
     return PP_OK;
 }

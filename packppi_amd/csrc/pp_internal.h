@@ -52,6 +52,7 @@ struct pp_plan {
     const float *node_emb_T;  // [51][128]
     const float *edge_emb_T;  // [468][128]
     const float *d0_in_T, *d0_out_T, *d2_in_T, *d2_out_T;   // [128][64] [64][32] [32][16] [16][4]
+    const float *static_stream;                             // k_edge_static: W_B chunks of layer 0 (node, edge message)
     // chemistry tables (device)
     float *default_frames;    // [21][8][16]
     int32_t *atom14_to_group; // [21][14]
@@ -83,6 +84,7 @@ struct pp_ctx {
     float *frames;            // [N][12]  R (row-major 9) | t (3)
     float *bbpos;             // [N][5][3] N CA C O CB*
     float *hE0;               // [N][K][128]
+    float *Znm, *Zem;         // [N][K][128] W_B h_E0 of layer 0's node / edge message (k_edge_static)
     // per-evaluation state
     float *hE;                // [N][K][128]
     float *hV;                // [N][128]
@@ -128,6 +130,7 @@ pp_status pp_launch_prepare(pp_ctx *c, hipStream_t s);
 pp_status pp_launch_node_embed(pp_ctx *c, const float *chi, int step, hipStream_t s);
 pp_status pp_launch_node_update(pp_ctx *c, int layer, int last_mode, float *chi, int step, int mode,
                                 const float *noise, hipStream_t s);
+pp_status pp_launch_edge_static(pp_ctx *c, hipStream_t s);
 pp_status pp_launch_node_message(pp_ctx *c, int layer, hipStream_t s);
 pp_status pp_launch_edge_update(pp_ctx *c, int layer, hipStream_t s);
 pp_status pp_launch_atom14(pp_ctx *c, const float *chi, float *xyz, hipStream_t s);
