@@ -187,6 +187,7 @@ extern "C" pp_status pp_plan_create(const float *weights, size_t n_weights, cons
         o_l[l][8] = put_T4(arena, weights + L.nd_out_w, 128, 512, 0, 512);
         o_l[l][9] = put_stream(arena, weights, L, false, l == 0);
         o_l[l][10] = put_stream(arena, weights, L, true, l == 0);
+        if (l < 2) put_stream(arena, weights, off.layer[l + 1], false, false);   // fused kernel: next layer's node message follows
         o_l[l][11] = put_edge_params(arena, weights, L);
     }
     size_t o_static = put_static_stream(arena, weights, off.layer[0]);
@@ -371,10 +372,12 @@ static pp_status run_network(pp_ctx *c, hipStream_t s, int step, int last_mode, 
                              bool embed_next) {
     pp_status st;
     for (int l = 0; l < 3; l++) {
-        prof_mark(c, 0, s);
-        st = pp_launch_node_message(c, l, s);
-        prof_mark(c, 0, s);
-        if (st != PP_OK) return st;
+        if (l == 0) {                 // layers 1 and 2: computed by the tail of the previous layer's edge update
+            prof_mark(c, 0, s);
+            st = pp_launch_node_message(c, 0, s);
+            prof_mark(c, 0, s);
+            if (st != PP_OK) return st;
+        }
         if (l < 2) {
             prof_mark(c, 2, s);
             st = pp_launch_node_update(c, l, PP_NU_MID, chi, step, mode, noise, s);
@@ -480,9 +483,9 @@ extern "C" pp_status pp_time_kernel(pp_ctx *c, int which, int iters, float *avg_
     PP_HIP_CHECK(hipEventCreate(&e0));
     PP_HIP_CHECK(hipEventCreate(&e1));
     pp_status st = PP_OK;
-    for (int w = 0; w < 2 && st == PP_OK; w++) st = which == 0 ? pp_launch_node_message(c, 1, s) : pp_launch_edge_update(c, 1, s);
+    for (int w = 0; w < 2 && st == PP_OK; w++) st = which == 0 ? pp_launch_node_message(c, 0, s) : pp_launch_edge_update(c, 1, s);
     PP_HIP_CHECK(hipEventRecord(e0, s));
-    for (int i = 0; i < iters && st == PP_OK; i++) st = which == 0 ? pp_launch_node_message(c, 1, s) : pp_launch_edge_update(c, 1, s);
+    for (int i = 0; i < iters && st == PP_OK; i++) st = which == 0 ? pp_launch_node_message(c, 0, s) : pp_launch_edge_update(c, 1, s);
     PP_HIP_CHECK(hipEventRecord(e1, s));
     PP_HIP_CHECK(hipEventSynchronize(e1));
     float ms = 0.f;

@@ -54,6 +54,7 @@ struct EdgeArgs {
     const float *g3, *be3;     // edge kernel: last LayerNorm (read in the epilogue)
     const float *b_mid;        // node kernel (per-lane read)
     const float *Z;            // layer 0: precomputed W_B h_E0 of this message function [N][K][128]
+    const float *pts2, *PA2, *PC2, *b_mid2;   // fused edge update: node-level inputs / bias of the NEXT node message
     float *Znm, *Zem;          // k_edge_static outputs
 };
 enum { P_BMID = 0, P_BOUT = 128, P_FOB = 256, P_G2 = 384, P_BE2 = 512, P_FIB = 640 };
@@ -368,7 +369,10 @@ k_node_message(EdgeArgs A) {
     WSTAGE(C0 + 11 + 8 * (c) + 6, NCH, xbuf_get(xbuf, 2, lane, acc); mfma_tile32<false>(wslot, acc, out, lane))   \
     WSTAGE(C0 + 11 + 8 * (c) + 7, NCH, xbuf_get(xbuf, 3, lane, acc); mfma_tile32<false>(wslot, acc, out, lane))
 
-template <int S, bool ST0>
+// FUSE: the workgroup goes straight on to the NEXT layer's node message of its residue (same 32 edges, whose new
+// h_E it holds; the node-level inputs PA2 / PC2 / pts2 were written by the node update that ran before this kernel):
+// one launch, one prologue and one read of h_E less per layer.
+template <int S, bool ST0, bool FUSE>
 __global__ void __launch_bounds__(ET, PP_EU_WGS)
 k_edge_update(EdgeArgs A) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -390,11 +394,16 @@ k_edge_update(EdgeArgs A) {
 #pragma unroll
             for (int q = 0; q < 4; q++) *reinterpret_cast<f32x4v *>(orow + 8 * q + 4 * h) = z;
         }
+        if constexpr (FUSE) {
+            if (tid < 128) A.S[(size_t)n * 128 + tid] = 0.f;
+            if (tid == 0) A.msum[n] = 0.f;
+        }
         return;
     }
     // chunks: [W_B x4,] W_G x3, W_mid x4, W_out x4, then per hidden block c: W1 x4, W2 x4
     constexpr int C0 = ST0 ? 0 : 4;
-    constexpr int NCH = C0 + 43;
+    constexpr int NEU = C0 + 43;                       // chunks of the edge update itself
+    constexpr int NCH = NEU + (FUSE ? 11 : 0);         // + W_B x4, W_G x3, W_mid x4 of the next node message
     PROLOGUE_PIPE()
 
     f32x16 x[4], acc, out;
@@ -491,6 +500,58 @@ k_edge_update(EdgeArgs A) {
 #pragma unroll
     for (int r = 0; r < 16; r++) out[r] *= me;
     if (j < K) store_tile(A.hE_out + ((size_t)n * K + j) * 128 + 32 * wave, h, out);
+    if constexpr (FUSE) {
+        // ---- next layer's node message on the fresh edges ------------------------------------------------
+        // its inputs are fetched here and not earlier: offsets made opaque behind `out` (scalar ones stay scalar)
+        int o_pts = n * 48, o_fr = n * 12, o_pa = n * 128;
+        int o_ptsj = nbr * 48, o_pc = nbr * 128;
+        asm volatile("" : "+s"(o_pts), "+s"(o_fr), "+s"(o_pa), "+v"(o_ptsj), "+v"(o_pc) : "v"(out[0]));
+        edge_geometry(A.pts2 + o_pts, A.frames + o_fr, A.pts2 + o_ptsj, h, g);
+        load_tile(A.PA2 + o_pa + 32 * wave, h, acc);
+        add_tile(A.PC2 + o_pc + 32 * wave, h, acc);
+        const float bmid = A.b_mid2[32 * wave + j];           // SWAP form: feature on the lane
+        __syncthreads();                                      // every wave has read the LayerNorm exchange
+        xbuf_put(xbuf, wave, lane, out);
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 4; t++) xbuf_get(xbuf, t, lane, x[t]);
+        WSTAGE(NEU + 0, NCH, mfma_tile32<false>(wslot, x[0], acc, lane))
+        WSTAGE(NEU + 1, NCH, mfma_tile32<false>(wslot, x[1], acc, lane))
+        WSTAGE(NEU + 2, NCH, mfma_tile32<false>(wslot, x[2], acc, lane))
+        WSTAGE(NEU + 3, NCH, mfma_tile32<false>(wslot, x[3], acc, lane))
+        WSTAGE(NEU + 4, NCH, mfma_tile24(wslot, g[0], acc, lane))
+        WSTAGE(NEU + 5, NCH, mfma_tile24(wslot, g[1], acc, lane))
+        WSTAGE(NEU + 6, NCH, mfma_tile24(wslot, g[2], acc, lane))
+        relu_tile(acc);
+        __syncthreads();
+        xbuf_put(xbuf, wave, lane, acc);
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 4; t++) xbuf_get(xbuf, t, lane, x[t]);
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[r] = bmid;
+        WSTAGE(NEU + 7, NCH, mfma_tile32<true>(wslot, x[0], acc, lane))
+        WSTAGE(NEU + 8, NCH, mfma_tile32<true>(wslot, x[1], acc, lane))
+        WSTAGE(NEU + 9, NCH, mfma_tile32<true>(wslot, x[2], acc, lane))
+        WSTAGE(NEU + 10, NCH, mfma_tile32<true>(wslot, x[3], acc, lane))
+        // rows (registers) are edges e = 8 (r>>2) + 4 h + (r&3); mask and reduce over them
+        int o_m = n * 32 + 4 * h;
+        asm volatile("" : "+v"(o_m) : "v"(acc[0]));
+        float sacc = 0.f, ms = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const f32x4v mm = *reinterpret_cast<const f32x4v *>(A.mask_att + o_m + 8 * q);
+#pragma unroll
+            for (int pq = 0; pq < 4; pq++) {
+                sacc = fmaf(fmaxf(acc[4 * q + pq], 0.f), mm[pq], sacc);
+                ms += mm[pq];
+            }
+        }
+        sacc += __shfl_xor(sacc, 32);
+        ms += __shfl_xor(ms, 32);
+        if (h == 0) A.S[(size_t)n * 128 + 32 * wave + j] = sacc * A.inv_K;
+        if (tid == 0) A.msum[n] = ms * A.inv_K;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -550,6 +611,8 @@ static EdgeArgs edge_args(pp_ctx *c, int layer, bool edge) {
     A.b_mid = p->w + o.nm_mid_b;
     A.Z = edge ? c->Zem : c->Znm;
     A.Znm = c->Znm; A.Zem = c->Zem;
+    A.pts2 = c->ptsN; A.PA2 = c->PAn; A.PC2 = c->PCn;
+    A.b_mid2 = p->w + p->off.layer[layer < 2 ? layer + 1 : 2].nm_mid_b;
     return A;
 }
 
@@ -570,8 +633,8 @@ static bool edge_attrs() {
         };
         ok = set(reinterpret_cast<const void *>(k_node_message<PP_NM_SLOTS, false>), NM_SMEM) &&
              set(reinterpret_cast<const void *>(k_node_message<PP_NM_SLOTS, true>), NM_SMEM) &&
-             set(reinterpret_cast<const void *>(k_edge_update<PP_EU_SLOTS, false>), EU_SMEM) &&
-             set(reinterpret_cast<const void *>(k_edge_update<PP_EU_SLOTS, true>), EU_SMEM);
+             set(reinterpret_cast<const void *>(k_edge_update<PP_EU_SLOTS, false, true>), EU_SMEM) &&
+             set(reinterpret_cast<const void *>(k_edge_update<PP_EU_SLOTS, true, true>), EU_SMEM);
     }
     return ok;
 }
@@ -580,7 +643,7 @@ static bool edge_attrs() {
 void pp_edge_occupancy(int *node_msg, int *edge_upd) {
     edge_attrs();
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(node_msg, reinterpret_cast<const void *>(k_node_message<PP_NM_SLOTS, false>), ET, NM_SMEM);
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(edge_upd, reinterpret_cast<const void *>(k_edge_update<PP_EU_SLOTS, false>), ET, EU_SMEM);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(edge_upd, reinterpret_cast<const void *>(k_edge_update<PP_EU_SLOTS, false, true>), ET, EU_SMEM);
 }
 
 #define EDGE_ATTR_CHECK()                                                                                   \
@@ -607,11 +670,13 @@ pp_status pp_launch_node_message(pp_ctx *c, int layer, hipStream_t s) {
     return PP_OK;
 }
 
+// layers 0 and 1 only (the reference's layer-2 edge update is dead code); also produces S / msum of layer + 1
 pp_status pp_launch_edge_update(pp_ctx *c, int layer, hipStream_t s) {
     EDGE_ATTR_CHECK()
+    if (layer < 0 || layer > 1) { pp_set_error("pp_launch_edge_update: layer must be 0 or 1"); return PP_ERR_INVALID; }
     EdgeArgs A = edge_args(c, layer, true);
-    if (layer == 0) hipLaunchKernelGGL((k_edge_update<PP_EU_SLOTS, true>), dim3(c->N), dim3(ET), EU_SMEM, s, A);
-    else hipLaunchKernelGGL((k_edge_update<PP_EU_SLOTS, false>), dim3(c->N), dim3(ET), EU_SMEM, s, A);
+    if (layer == 0) hipLaunchKernelGGL((k_edge_update<PP_EU_SLOTS, true, true>), dim3(c->N), dim3(ET), EU_SMEM, s, A);
+    else hipLaunchKernelGGL((k_edge_update<PP_EU_SLOTS, false, true>), dim3(c->N), dim3(ET), EU_SMEM, s, A);
     PP_HIP_CHECK(hipGetLastError());
     return PP_OK;
 }
