@@ -197,7 +197,12 @@ def main():
     t_node = insitu["k_node_message"][0] * 1e-3
     t_edge_b2b = ctx.time_kernel(1, 20) * 1e-3
     n_edges = residues * ctx.K
-    achieved = EDGE_UPDATE_FLOP_PER_EDGE * n_edges / t_edge / 1e12
+    # k_edge_update(l) also computes the node message of layer l + 1 (fused): its algorithmic work is both MLP chains
+    # of the reference (layers.py:119-148), 2 FLOP per MAC of the dense layers, per edge.  Executed MFMA work is lower:
+    # layer 0's W_B h_E0 products are timestep-invariant and computed once per complex.
+    fused_flop_per_edge = EDGE_UPDATE_FLOP_PER_EDGE + NODE_MSG_FLOP_PER_EDGE
+    achieved = fused_flop_per_edge * n_edges / t_edge / 1e12
+    executed_mfma = (2960 + 656 - 128) * 4096.0 * residues        # average of the layer-0 and layer-1 launches
 
     if rank == 0:
         out = {
@@ -217,12 +222,19 @@ def main():
                          "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate --pmc "
                                          "passes of this command; profiles/*_pmc_traffic.json)",
                          "kernel_ms": t_edge * 1e3,
-                         "algorithmic_flop_per_launch": EDGE_UPDATE_FLOP_PER_EDGE * n_edges,
+                         "kernel_does": "edge update of layer l + node message of layer l+1, one launch",
+                         "algorithmic_flop_per_launch": fused_flop_per_edge * n_edges,
+                         "executed_mfma_tflops": executed_mfma / t_edge / 1e12,
+                         # whole pass against SURVEY 8(d): 46 792 576 algorithmic FLOP per residue per network evaluation
+                         "whole_pass_algorithmic_tflops": 46792576.0 * total_res * N_DIFFUSION_STEPS * args.steps / elapsed / 1e12
+                                                          / max(args.gpus, 1),
+                         "whole_pass_frac_of_peak": 46792576.0 * total_res * N_DIFFUSION_STEPS * args.steps / elapsed / 1e12
+                                                    / max(args.gpus, 1) / FP32_MFMA_PEAK_TFLOPS,
                          "kernel_launches_timed": insitu["k_edge_update"][1],
                          "kernel_ms_back_to_back": t_edge_b2b * 1e3,
                          "node_update_kernel_ms": insitu["k_node_update"][0],
                          "node_message_kernel_ms": t_node * 1e3,
-                         "node_message_tflops": NODE_MSG_FLOP_PER_EDGE * n_edges / t_node / 1e12},
+                         "node_message_layer0_tflops": NODE_MSG_FLOP_PER_EDGE * n_edges / t_node / 1e12},
             "parity": {"max_abs_dchi_vs_reference_rad": max_dchi, "atom_rmsd": float(m["atom_rmsd"])},
             "metrics_rows_gathered": len(rows),
         }

@@ -297,6 +297,10 @@ k_node_message(EdgeArgs A) {
     }
     constexpr int C0 = ST0 ? 0 : 4;
     constexpr int NCH = C0 + 7;           // chunks: [W_B x4,] W_G x3, W_mid x4
+#ifdef PP_X_NM_SCRATCH        // timing experiment: give this kernel a private segment like its neighbours
+    volatile float dummy_scratch[4];
+    dummy_scratch[lane & 3] = 1.f;
+#endif
     PROLOGUE_PIPE()
 
     f32x16 x[4], acc;
@@ -505,13 +509,16 @@ k_edge_update(EdgeArgs A) {
         // its inputs are fetched here and not earlier: offsets made opaque behind `out` (scalar ones stay scalar)
         int o_pts = n * 48, o_fr = n * 12, o_pa = n * 128;
         int o_ptsj = nbr * 48, o_pc = nbr * 128;
-        asm volatile("" : "+s"(o_pts), "+s"(o_fr), "+s"(o_pa), "+v"(o_ptsj), "+v"(o_pc) : "v"(out[0]));
+        __syncthreads();                                      // every wave has read the LayerNorm exchange
+        xbuf_put(xbuf, wave, lane, out);
+        // `out` is dead from here; the fence keeps the input fetches below it (they would otherwise be hoisted to the
+        // top of the kernel), and the geometry arithmetic fills the wait for the other waves' tiles
+        asm volatile("" : "+s"(o_pts), "+s"(o_fr), "+s"(o_pa), "+v"(o_ptsj), "+v"(o_pc) : : "memory");
         edge_geometry(A.pts2 + o_pts, A.frames + o_fr, A.pts2 + o_ptsj, h, g);
         load_tile(A.PA2 + o_pa + 32 * wave, h, acc);
         add_tile(A.PC2 + o_pc + 32 * wave, h, acc);
         const float bmid = A.b_mid2[32 * wave + j];           // SWAP form: feature on the lane
-        __syncthreads();                                      // every wave has read the LayerNorm exchange
-        xbuf_put(xbuf, wave, lane, out);
+        __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
 #pragma unroll
         for (int t = 0; t < 4; t++) xbuf_get(xbuf, t, lane, x[t]);
@@ -616,7 +623,11 @@ static EdgeArgs edge_args(pp_ctx *c, int layer, bool edge) {
     return A;
 }
 
+#ifdef PP_X_NM_SMEM_EQ       // timing experiment: same LDS request as the edge-update kernel
+static const size_t NM_SMEM = (4 * PP_EU_SLOTS * 1024 + XBUF_FLOATS + PARAM_FLOATS) * sizeof(float);
+#else
 static const size_t NM_SMEM = (4 * PP_NM_SLOTS * 1024 + XBUF_FLOATS) * sizeof(float);
+#endif
 #ifdef PP_X_PRM_ALIAS
 static const size_t EU_SMEM = (4 * PP_EU_SLOTS * 1024 + XBUF_FLOATS) * sizeof(float);
 #else

@@ -381,15 +381,18 @@ __device__ __forceinline__ void message_inputs_pre(Smem &sm, int &flip, const WS
     __syncthreads();
 }
 
+// LAST_MODE is a template parameter so that the middle-layer variant (two of three launches) gets its own register
+// allocation: as one function the decoder / step / embedding tail cost it ~30 spilled registers.
+template <int LAST_MODE>
 __global__ void __launch_bounds__(NT)
-k_node_update(NodeArgs A, UpdW W, int last_mode, float *chi, int step, int sde, const float *noise, int embed_next,
-              PreW pre0) {
+k_node_update(NodeArgs A, UpdW W, float *chi, int step, int sde, const float *noise, int embed_next, PreW pre0) {
+    constexpr int last_mode = LAST_MODE;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     Smem &sm = *reinterpret_cast<Smem *>(smem_raw);
     int flip = 0, rflip = 0;
     const int t = threadIdx.x, f = t & 127, ks = t >> 7, n0 = blockIdx.x * NB, N = A.N;
     const int kq = ks * 32;                  // this thread's quarter of a 128-deep reduction
-    const bool mid = last_mode == PP_NU_MID;
+    constexpr bool mid = last_mode == PP_NU_MID;
     WSet wa, wb, wc, wd, we;
     wload<32>(wa, W.outT, 128, f, kq, 0.f);
     wload<32>(wb, W.ffn_inT, 512, f, kq, 0.f);            // FFN-in, half 0: units f and f + 128
@@ -447,7 +450,7 @@ k_node_update(NodeArgs A, UpdW W, int last_mode, float *chi, int step, int sde, 
     // next phase's weights: the two message functions (middle layers) / decoder + next embedding (last layer)
     float in_b_1, pts_b_1 = 0.f, in_b_2 = 0.f, pts_b_2 = 0.f;
     float db0 = 0.f, db1 = 0.f, db2 = 0.f, db3 = 0.f;
-    if (mid) {
+    if constexpr (mid) {
         const float tk = part.g[0].x;
         wload<32>(wb, W.pre_edge.AT, 128, f, kq, tk);
         wload<32>(wc, W.pre_edge.CT, 128, f, kq, tk);
@@ -486,7 +489,7 @@ k_node_update(NodeArgs A, UpdW W, int last_mode, float *chi, int step, int sde, 
 #if defined(PP_X_NU_STOP) && PP_X_NU_STOP == 6
     if (!mid) return;
 #endif
-    if (mid) {
+    if constexpr (mid) {
         // inputs of this layer's edge message and of the next layer's node message in one pass over h2:
         // columns PAe 0..127 | PCe 128..255 | PAn 256..383 | PCn 384..511 | ptsE 512..535 | ptsN 536..559
         VN *buf = sm.part[flip];
@@ -575,7 +578,7 @@ k_node_update(NodeArgs A, UpdW W, int last_mode, float *chi, int step, int sde, 
         store_rows(A.score, 4, n0, N, f, v);
     }
     __syncthreads();
-    if (last_mode != PP_NU_STEP) return;
+    if constexpr (last_mode != PP_NU_STEP) return;
     // reverse step on (residue i, chi k) = 4 NB threads
     if (t < 4 * NB) {
         int i = t >> 2, k = t & 3, n = n0 + i;
@@ -675,7 +678,11 @@ static pp_status node_attrs() {
     if (!done) {
         PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_node_embed),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Smem)));
-        PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_node_update),
+        PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_node_update<PP_NU_MID>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Smem)));
+        PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_node_update<PP_NU_STEP>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Smem)));
+        PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_node_update<PP_NU_SCORE>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Smem)));
         done = true;
     }
@@ -717,8 +724,14 @@ pp_status pp_launch_node_update(pp_ctx *c, int layer, int last_mode, float *chi,
     int embed_next = (last_mode == PP_NU_STEP && step >= 0) ? 1 : 0;
     int st = step;
     if (last_mode == PP_NU_STEP && step < 0) { st = -step - 1; embed_next = 0; }
-    hipLaunchKernelGGL(k_node_update, dim3((c->N + NB - 1) / NB), dim3(NT), sizeof(Smem), s, A, W, last_mode, chi, st,
-                       mode == PP_MODE_SDE ? 1 : 0, noise, embed_next, pre0);
+    const dim3 grid((c->N + NB - 1) / NB), block(NT);
+    const int sde = mode == PP_MODE_SDE ? 1 : 0;
+    if (last_mode == PP_NU_MID)
+        hipLaunchKernelGGL(k_node_update<PP_NU_MID>, grid, block, sizeof(Smem), s, A, W, chi, st, sde, noise, embed_next, pre0);
+    else if (last_mode == PP_NU_STEP)
+        hipLaunchKernelGGL(k_node_update<PP_NU_STEP>, grid, block, sizeof(Smem), s, A, W, chi, st, sde, noise, embed_next, pre0);
+    else
+        hipLaunchKernelGGL(k_node_update<PP_NU_SCORE>, grid, block, sizeof(Smem), s, A, W, chi, st, sde, noise, embed_next, pre0);
     PP_HIP_CHECK(hipGetLastError());
     return PP_OK;
 }

@@ -16,7 +16,10 @@ ROUND = os.environ.get("GRAFT_ROUND", "r01")
 
 
 def short(name):
-    name = name.split("(")[0]
+    name = name.split("(")[0].strip()
+    if name.startswith("void "):
+        name = name[5:]
+    name = name.split("<")[0]
     return name.split("::")[-1].strip()
 
 
