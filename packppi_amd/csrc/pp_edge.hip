@@ -297,10 +297,6 @@ k_node_message(EdgeArgs A) {
     }
     constexpr int C0 = ST0 ? 0 : 4;
     constexpr int NCH = C0 + 7;           // chunks: [W_B x4,] W_G x3, W_mid x4
-#ifdef PP_X_NM_SCRATCH        // timing experiment: give this kernel a private segment like its neighbours
-    volatile float dummy_scratch[4];
-    dummy_scratch[lane & 3] = 1.f;
-#endif
     PROLOGUE_PIPE()
 
     f32x16 x[4], acc;
@@ -623,11 +619,7 @@ static EdgeArgs edge_args(pp_ctx *c, int layer, bool edge) {
     return A;
 }
 
-#ifdef PP_X_NM_SMEM_EQ       // timing experiment: same LDS request as the edge-update kernel
-static const size_t NM_SMEM = (4 * PP_EU_SLOTS * 1024 + XBUF_FLOATS + PARAM_FLOATS) * sizeof(float);
-#else
 static const size_t NM_SMEM = (4 * PP_NM_SLOTS * 1024 + XBUF_FLOATS) * sizeof(float);
-#endif
 #ifdef PP_X_PRM_ALIAS
 static const size_t EU_SMEM = (4 * PP_EU_SLOTS * 1024 + XBUF_FLOATS) * sizeof(float);
 #else
