@@ -257,7 +257,7 @@ extern "C" void pp_ctx_destroy(pp_ctx *c) {
     if (!c) return;
     void *ptrs[] = {c->Znm, c->Zem, c->eidx, c->mask_att, c->frames, c->bbpos, c->hE0, c->hE, c->hV, c->S, c->msum, c->ptsN, c->PAn,
                     c->PCn, c->ptsE, c->PAe, c->PCe, c->score, c->chi_tmp, c->steps, c->xyz, c->axes, c->brad,
-                    c->per_res, c->dchi, c->px, c->pm, c->pv, c->pz, c->pxeff, c->pmask, c->scal, c->dbg};
+                    c->per_res, c->dchi, c->px, c->pm, c->pv, c->pz, c->pxeff, c->pmask, c->scal};
     for (void *q : ptrs) if (q) hipFree(q);
     if (c->steps_host) hipHostFree(c->steps_host);
     for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
@@ -294,7 +294,6 @@ extern "C" pp_status pp_complex_prepare(pp_plan *plan, const pp_batch *b, void *
     ALLOC(xyz, N * 42); ALLOC(axes, N * 24); ALLOC(brad, N); ALLOC(per_res, N); ALLOC(dchi, N * 4);
     ALLOC(px, N * 4); ALLOC(pm, N * 4); ALLOC(pv, N * 4); ALLOC(pz, N * 4); ALLOC(pxeff, N * 4); ALLOC(pmask, N);
     ALLOC(scal, 64);
-    if (getenv("PP_STAMP")) { ALLOC(dbg, N * 4 * 64 * 4); }
     c->max_steps = 1024;
     if (net) { ALLOC(steps, (size_t)c->max_steps); }
 #undef ALLOC
@@ -550,10 +549,3 @@ extern "C" pp_status pp_profile_read(pp_ctx *c, float *total_ms, int *launches) 
     return PP_OK;
 }
 
-// Diagnostic builds (-DPP_X_STAMP, env PP_STAMP=1): copy the s_memtime stamps of the last edge-kernel launch to the host.
-extern "C" pp_status pp_debug_stamps(pp_ctx *c, unsigned long long *host, size_t n_words) {
-    if (!c || !c->dbg) FAIL(PP_ERR_INVALID, "pp_debug_stamps: no stamp buffer (set PP_STAMP=1)");
-    PP_HIP_CHECK(hipDeviceSynchronize());
-    PP_HIP_CHECK(hipMemcpy(host, c->dbg, n_words * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    return PP_OK;
-}

@@ -106,7 +106,6 @@ struct pp_ctx {
     float *px, *pm, *pv, *pz, *pxeff;   // proximal: param, Adam moments, anchor, effective chi  [N][4]
     uint8_t *pmask;           // [N]
     float *scal;              // small scalar scratch
-    unsigned long long *dbg;  // stamp buffer of PP_X_STAMP diagnostic builds (else unused)
     // in-situ kernel timing (pp_profile_kernel): event pairs recorded around every launch of one hot kernel
     int prof_which = -1;       // -1 off, 0 node message, 1 edge update, 2 node update
     std::vector<hipEvent_t> prof_ev;
