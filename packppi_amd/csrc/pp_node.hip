@@ -454,7 +454,10 @@ k_node_update(NodeArgs A, UpdW W, float *chi, int step, int sde, const float *no
         const float tk = part.g[0].x;
         wload<32>(wb, W.pre_edge.AT, 128, f, kq, tk);
         wload<32>(wc, W.pre_edge.CT, 128, f, kq, tk);
+        // point weights: threads f < 24 take the edge message's column f, threads 32 <= f < 56 the next node message's
+        // column f - 32, so one register set serves both and nothing is fetched between the two dot products
         if (f < 24) { wload<32>(we, W.pre_edge.ptsT, 24, f, kq, tk); pts_b_1 = W.pre_edge.pts_b[f]; pts_b_2 = W.pre_next.pts_b[f]; }
+        else if (f >= 32 && f < 56) wload<32>(we, W.pre_next.ptsT, 24, f - 32, kq, tk);
         wload<32>(wa, W.pre_next.AT, 128, f, kq, tk);
         wload<32>(wd, W.pre_next.CT, 128, f, kq, tk);
         in_b_1 = W.pre_edge.in_b[f];
@@ -500,12 +503,8 @@ k_node_update(NodeArgs A, UpdW W, float *chi, int step, int sde, const float *no
         buf[ks * 576 + 128 + f] = u1;
         buf[ks * 576 + 256 + f] = u2;
         buf[ks * 576 + 384 + f] = u3;
-        if (f < 24) {
-            const VN up = wdot<32>(we, sm.h + kq, vn(0.f));
-            buf[ks * 576 + 512 + f] = up;
-            wload<32>(we, W.pre_next.ptsT, 24, f, kq, up.g[0].x);
-            buf[ks * 576 + 536 + f] = wdot<32>(we, sm.h + kq, vn(0.f));
-        }
+        if (f < 24) buf[ks * 576 + 512 + f] = wdot<32>(we, sm.h + kq, vn(0.f));
+        else if (f >= 32 && f < 56) buf[ks * 576 + 536 + (f - 32)] = wdot<32>(we, sm.h + kq, vn(0.f));
         __syncthreads();
         {
             const int c = ks * 128 + f;           // ks-group 0: PAe, 1: PCe, 2: PAn, 3: PCn
