@@ -74,8 +74,10 @@ __device__ __forceinline__ void dma_chunk(const float *gsrc_lane, unsigned lds_d
                  "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
                  "global_load_lds_dwordx4 %1, off\n\t"
                  "global_load_lds_dwordx4 %1, off offset:1024\n\t"
+#ifndef PP_X_HALFDMA         // (timing experiment: half the weight traffic, wrong results)
                  "global_load_lds_dwordx4 %1, off offset:2048\n\t"
                  "global_load_lds_dwordx4 %1, off offset:3072\n\t"
+#endif
                  "s_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc_lane), "s"(lds_dst) : "memory");
 }
@@ -234,13 +236,18 @@ __device__ __forceinline__ void edge_geometry(const float *__restrict__ pts_i, c
         for (int m = 0; m < 12; m++) g[c][m] = h ? geom[24 * c + 12 + m] : geom[24 * c + m];
 }
 
+#ifdef PP_X_HALFDMA
+#define DMA_PER_CHUNK 2
+#else
+#define DMA_PER_CHUNK 4
+#endif
 // Stage k of a kernel with NCH chunks: refill the slot freed by stage k-1 with chunk k+S-1, wait until chunk k has
 // landed (all but the younger chunks' DMAs retired), compute on it.
 #define WSTAGE(k, NCH, BODY)                                                                                   \
     {                                                                                                          \
         if constexpr ((k) + S - 1 < (NCH))                                                                     \
             dma_chunk(wsl + (size_t)((k) + S - 1) * CH32, slot0 + (((k) + S - 1) % S) * 4096u);                \
-        wait_vm<4 * (((NCH) - 1 - (k)) < (S - 1) ? ((NCH) - 1 - (k)) : (S - 1))>();                            \
+        wait_vm<DMA_PER_CHUNK * (((NCH) - 1 - (k)) < (S - 1) ? ((NCH) - 1 - (k)) : (S - 1))>();                            \
         const float *wslot = wl + ((k) % S) * 1024;                                                            \
         BODY;                                                                                                  \
     }
