@@ -255,7 +255,7 @@ static pp_status dalloc(T **p, size_t n) {
 
 extern "C" void pp_ctx_destroy(pp_ctx *c) {
     if (!c) return;
-    void *ptrs[] = {c->Znm, c->Zem, c->eidx, c->mask_att, c->frames, c->bbpos, c->hE0, c->hE, c->hV, c->S, c->msum, c->ptsN, c->PAn,
+    void *ptrs[] = {c->rec, c->Znm, c->Zem, c->eidx, c->mask_att, c->frames, c->bbpos, c->hE0, c->hE, c->hV, c->S, c->msum, c->ptsN, c->PAn,
                     c->PCn, c->ptsE, c->PAe, c->PCe, c->score, c->chi_tmp, c->steps, c->xyz, c->axes, c->brad,
                     c->per_res, c->dchi, c->px, c->pm, c->pv, c->pz, c->pxeff, c->pmask, c->scal};
     for (void *q : ptrs) if (q) hipFree(q);
@@ -291,7 +291,7 @@ extern "C" pp_status pp_complex_prepare(pp_plan *plan, const pp_batch *b, void *
     ALLOC(ptsE, N * 48); ALLOC(PAe, N * 128); ALLOC(PCe, N * 128);
     ALLOC(score, N * 4); ALLOC(chi_tmp, N * 4);
     }
-    ALLOC(xyz, N * 42); ALLOC(axes, N * 24); ALLOC(brad, N); ALLOC(per_res, N); ALLOC(dchi, N * 4);
+    ALLOC(xyz, N * 42); ALLOC(rec, N * 64); ALLOC(axes, N * 24); ALLOC(brad, N); ALLOC(per_res, N); ALLOC(dchi, N * 4);
     ALLOC(px, N * 4); ALLOC(pm, N * 4); ALLOC(pv, N * 4); ALLOC(pz, N * 4); ALLOC(pxeff, N * 4); ALLOC(pmask, N);
     ALLOC(scal, 64);
     c->max_steps = 1024;

@@ -37,101 +37,146 @@ __device__ __forceinline__ Rig compose(const Rig &a, const Rig &b) {
     return o;
 }
 
-// one thread per residue
-__global__ void k_atom14(int N, const float *__restrict__ X, const int64_t *__restrict__ rtype,
-                         const float *__restrict__ BB_D, const float *__restrict__ chi,
-                         const float *__restrict__ default_frames, const int32_t *__restrict__ a2g,
-                         const float *__restrict__ amask14, const float *__restrict__ lit,
-                         const float *__restrict__ atom_exists,
-                         float *__restrict__ xyz, float *__restrict__ axes, float *__restrict__ brad) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
+// default frame g of residue type S composed with the torsion rotation about x:  D_g * Rx(sin, cos)
+__device__ __forceinline__ Rig torsion_frame(const float *__restrict__ df, int g, float sn, float cs) {
+    Rig D, o;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+#pragma unroll
+        for (int jx = 0; jx < 3; jx++) D.R.m[3 * i + jx] = df[g * 16 + 4 * i + jx];
+        D.t[i] = df[g * 16 + 4 * i + 3];
+    }
+    const M3 Rx = {{1.f, 0.f, 0.f, 0.f, cs, -sn, 0.f, sn, cs}};
+    o.R = mul33(D.R, Rx);
+#pragma unroll
+    for (int i = 0; i < 3; i++) o.t[i] = D.t[i];
+    return o;
+}
+__device__ __forceinline__ float sel8(const float (&v)[8], int g) {
+    float r = v[0];
+#pragma unroll
+    for (int k = 1; k < 8; k++) r = g == k ? v[k] : r;
+    return r;
+}
+
+// 16 lanes per residue: lane a < 14 builds atom a (its own rigid-group frame: the chain chi1 .. chi_g is composed by
+// every lane up to its group), lane 14 walks the whole chain and emits the four chi axes, and the per-residue
+// reductions (bounding spheres, side-chain atom count) are 16-lane butterflies.  (One thread per residue took 26 us
+// at T1124 -- a 3000-instruction dependent chain on 12 waves; this layout takes ~5.)
+__global__ void __launch_bounds__(256)
+k_atom14(int N, const float *__restrict__ X, const int64_t *__restrict__ rtype,
+         const float *__restrict__ BB_D, const float *__restrict__ chi,
+         const float *__restrict__ default_frames, const int32_t *__restrict__ a2g,
+         const float *__restrict__ amask14, const float *__restrict__ lit,
+         const float *__restrict__ atom_exists, const float *__restrict__ between_radius,
+         const int64_t *__restrict__ rindex,
+         float *__restrict__ xyz, float *__restrict__ axes, float *__restrict__ brad,
+         float4 *__restrict__ rec) {
+    const int a = threadIdx.x & 15;
+    const int nraw = blockIdx.x * 16 + (threadIdx.x >> 4);
+    const bool live = nraw < N;
+    const int n = live ? nraw : N - 1;           // out-of-range groups mirror the last residue and store nothing
     const int S = (int)rtype[n];
     const float *x = X + (size_t)n * 42;
     // backbone frame (same construction as k_frames)
-    float a[3], b[3], ca[3];
+    float av[3], bv[3], ca[3];
 #pragma unroll
-    for (int k = 0; k < 3; k++) { ca[k] = x[3 + k]; a[k] = x[6 + k] - ca[k]; b[k] = x[k] - ca[k]; }
-    float na = sqrtf(a[0] * a[0] + a[1] * a[1] + a[2] * a[2] + 1e-8f);
+    for (int k = 0; k < 3; k++) { ca[k] = x[3 + k]; av[k] = x[6 + k] - ca[k]; bv[k] = x[k] - ca[k]; }
+    float na = sqrtf(av[0] * av[0] + av[1] * av[1] + av[2] * av[2] + 1e-8f);
 #pragma unroll
-    for (int k = 0; k < 3; k++) a[k] /= na;
-    float dot = a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
+    for (int k = 0; k < 3; k++) av[k] /= na;
+    float dot = av[0] * bv[0] + av[1] * bv[1] + av[2] * bv[2];
 #pragma unroll
-    for (int k = 0; k < 3; k++) b[k] -= a[k] * dot;
-    float nb = sqrtf(b[0] * b[0] + b[1] * b[1] + b[2] * b[2] + 1e-8f);
+    for (int k = 0; k < 3; k++) bv[k] -= av[k] * dot;
+    float nb = sqrtf(bv[0] * bv[0] + bv[1] * bv[1] + bv[2] * bv[2] + 1e-8f);
 #pragma unroll
-    for (int k = 0; k < 3; k++) b[k] /= nb;
-    float c[3] = {a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]};
+    for (int k = 0; k < 3; k++) bv[k] /= nb;
+    float cv[3] = {av[1] * bv[2] - av[2] * bv[1], av[2] * bv[0] - av[0] * bv[2], av[0] * bv[1] - av[1] * bv[0]};
     Rig G;
 #pragma unroll
-    for (int r = 0; r < 3; r++) { G.R.m[3 * r] = a[r]; G.R.m[3 * r + 1] = b[r]; G.R.m[3 * r + 2] = c[r]; G.t[r] = ca[r]; }
+    for (int r = 0; r < 3; r++) { G.R.m[3 * r] = av[r]; G.R.m[3 * r + 1] = bv[r]; G.R.m[3 * r + 2] = cv[r]; G.t[r] = ca[r]; }
 
-    // the 7 angles as normalised (sin, cos): pre-omega, phi, psi, chi1..4
+    // the 7 angles as normalised (sin, cos): lane k < 7 evaluates angle k (phi-like 0..2, chi 3..6); group g uses angle g-1
+    float my_s = 0.f, my_c = 1.f;
+    if (a < 7) {
+        const float ang = a < 3 ? BB_D[(size_t)n * 3 + a] : chi[(size_t)n * 4 + (a - 3)];
+        const float s0 = sinf(ang), c0 = cosf(ang);
+        const float den = sqrtf(fmaxf(s0 * s0 + c0 * c0, 1e-12f));
+        my_s = s0 / den; my_c = c0 / den;
+    }
     float sn[8], cs[8];
     sn[0] = 0.f; cs[0] = 1.f;
 #pragma unroll
-    for (int k = 0; k < 7; k++) {
-        float ang = k < 3 ? BB_D[(size_t)n * 3 + k] : chi[(size_t)n * 4 + (k - 3)];
-        float s = sinf(ang), co = cosf(ang);
-        float den = sqrtf(fmaxf(s * s + co * co, 1e-12f));
-        sn[k + 1] = s / den; cs[k + 1] = co / den;
-    }
+    for (int g = 1; g < 8; g++) { sn[g] = __shfl(my_s, g - 1, 16); cs[g] = __shfl(my_c, g - 1, 16); }
+
     const float *df = default_frames + (size_t)S * 8 * 16;
-    Rig F[8];
-#pragma unroll
-    for (int g = 0; g < 8; g++) {
-        Rig D;
-#pragma unroll
-        for (int i = 0; i < 3; i++) {
-#pragma unroll
-            for (int jx = 0; jx < 3; jx++) D.R.m[3 * i + jx] = df[g * 16 + 4 * i + jx];
-            D.t[i] = df[g * 16 + 4 * i + 3];
-        }
-        M3 Rx = {{1.f, 0.f, 0.f, 0.f, cs[g], -sn[g], 0.f, sn[g], cs[g]}};
-        F[g].R = mul33(D.R, Rx);
-#pragma unroll
-        for (int i = 0; i < 3; i++) F[g].t[i] = D.t[i];
+    const int g = a < 14 ? a2g[S * 14 + a] : (a == 14 ? 7 : 0);     // lane 14 walks the full chi chain
+    const int g0 = g < 4 ? g : 4;
+    Rig chain = torsion_frame(df, g0, sel8(sn, g0), sel8(cs, g0));
+    const bool axis_lane = a == 14 && axes != nullptr && live;
+    if (axis_lane) {
+        const Rig Fg = compose(G, chain);
+        float *o = axes + ((size_t)n * 4 + 0) * 6;
+        o[0] = Fg.R.m[0]; o[1] = Fg.R.m[3]; o[2] = Fg.R.m[6]; o[3] = Fg.t[0]; o[4] = Fg.t[1]; o[5] = Fg.t[2];
     }
-    F[5] = compose(F[4], F[5]);
-    F[6] = compose(F[5], F[6]);
-    F[7] = compose(F[6], F[7]);
 #pragma unroll
-    for (int g = 0; g < 8; g++) F[g] = compose(G, F[g]);
-    // chi-frame rotation axes (x axis of the frame) and origins, for the analytic gradient
-    if (axes) {
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            float *o = axes + ((size_t)n * 4 + k) * 6;
-            o[0] = F[4 + k].R.m[0]; o[1] = F[4 + k].R.m[3]; o[2] = F[4 + k].R.m[6];
-            o[3] = F[4 + k].t[0]; o[4] = F[4 + k].t[1]; o[5] = F[4 + k].t[2];
+    for (int gg = 5; gg < 8; gg++) {
+        const Rig nx = compose(chain, torsion_frame(df, gg, sn[gg], cs[gg]));
+        if (gg <= g) chain = nx;
+        if (axis_lane) {
+            const Rig Fg = compose(G, chain);
+            float *o = axes + ((size_t)n * 4 + (gg - 4)) * 6;
+            o[0] = Fg.R.m[0]; o[1] = Fg.R.m[3]; o[2] = Fg.R.m[6]; o[3] = Fg.t[0]; o[4] = Fg.t[1]; o[5] = Fg.t[2];
         }
     }
-    float rad2 = 0.f;
-    for (int at = 0; at < 14; at++) {
-        float p[3];
-        if (at < 4) {
+    const Rig F = compose(G, chain);
+    float p[3] = {0.f, 0.f, 0.f}, ex = 0.f, reff = 0.f;
+    if (a < 14) {
+        if (a < 4) {
 #pragma unroll
-            for (int k = 0; k < 3; k++) p[k] = x[3 * at + k];
+            for (int k = 0; k < 3; k++) p[k] = x[3 * a + k];
         } else {
-            const int g = a2g[S * 14 + at];
-            const float *lp = lit + ((size_t)S * 14 + at) * 3;
-            const float am = amask14[S * 14 + at];
-            Rig Fg = F[0];
-#pragma unroll
-            for (int gg = 1; gg < 8; gg++) if (g == gg) Fg = F[gg];
+            const float *lp = lit + ((size_t)S * 14 + a) * 3;
+            const float am = amask14[S * 14 + a];
             float rp[3];
-            rot3(Fg.R, lp, rp);
+            rot3(F.R, lp, rp);
 #pragma unroll
-            for (int k = 0; k < 3; k++) p[k] = (rp[k] + Fg.t[k]) * am;
+            for (int k = 0; k < 3; k++) p[k] = (rp[k] + F.t[k]) * am;
         }
+        ex = atom_exists ? atom_exists[(size_t)n * 14 + a] : 1.f;
+        reff = ex * between_radius[S * 14 + a];
+        if (live) {
 #pragma unroll
-        for (int k = 0; k < 3; k++) xyz[((size_t)n * 14 + at) * 3 + k] = p[k];
-        if (brad && (!atom_exists || atom_exists[(size_t)n * 14 + at] != 0.f)) {
-            float dx = p[0] - ca[0], dy = p[1] - ca[1], dz = p[2] - ca[2];
-            rad2 = fmaxf(rad2, dx * dx + dy * dy + dz * dz);
+            for (int k = 0; k < 3; k++) xyz[((size_t)n * 14 + a) * 3 + k] = p[k];
+            if (rec) rec[(size_t)n * 16 + a] = make_float4(p[0], p[1], p[2], reff);
         }
     }
-    if (brad) brad[n] = sqrtf(rad2) * 1.0001f + 1e-3f;
+    // per-residue reductions over the 16 lanes
+    const bool has = a < 14 && ex != 0.f;
+    float dca = 0.f;
+    if (has) { float dx = p[0] - ca[0], dy = p[1] - ca[1], dz = p[2] - ca[2]; dca = dx * dx + dy * dy + dz * dz; }
+    float cnt = has ? 1.f : 0.f, sx = has ? p[0] : 0.f, sy = has ? p[1] : 0.f, sz = has ? p[2] : 0.f;
+    float nsc = (a >= 4 && a < 14) ? ex : 0.f;
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {
+        dca = fmaxf(dca, __shfl_xor(dca, o, 16));
+        cnt += __shfl_xor(cnt, o, 16); sx += __shfl_xor(sx, o, 16); sy += __shfl_xor(sy, o, 16); sz += __shfl_xor(sz, o, 16);
+        nsc += __shfl_xor(nsc, o, 16);
+    }
+    const float inv = 1.f / fmaxf(cnt, 1.f);
+    const float cen[3] = {sx * inv, sy * inv, sz * inv};
+    float r2 = 0.f;
+    if (has) { float dx = p[0] - cen[0], dy = p[1] - cen[1], dz = p[2] - cen[2]; r2 = dx * dx + dy * dy + dz * dz; }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) r2 = fmaxf(r2, __shfl_xor(r2, o, 16));
+    if (live && a == 0) {
+        if (brad) brad[n] = sqrtf(dca) * 1.0001f + 1e-3f;
+        if (rec) {
+            // bounding sphere about the centroid of the atoms present (tighter than about CA: ~2.5x fewer candidates)
+            rec[(size_t)n * 16 + 14] = make_float4(cen[0], cen[1], cen[2], sqrtf(r2) * 1.0001f + 1e-3f);
+            rec[(size_t)n * 16 + 15] = make_float4(nsc, __int_as_float((int)rindex[n]), __int_as_float(S), 0.f);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -141,52 +186,57 @@ __global__ void k_atom14(int N, const float *__restrict__ X, const int64_t *__re
 #define CL_MAXC 2048     // candidate list capacity per wave (entries beyond are handled by re-scanning)
 
 __global__ void __launch_bounds__(64 * CL_WAVES)
-k_clash(int N, int L, const float *__restrict__ xyz, const float *__restrict__ exists,
-        const int64_t *__restrict__ rtype, const int64_t *__restrict__ rindex,
-        const float *__restrict__ brad, const float *__restrict__ between_radius,
+k_clash(int N, int L, const float *__restrict__ xyz, const float4 *__restrict__ rec, const float *__restrict__ exists,
         const float *__restrict__ lower, const float *__restrict__ upper, const int32_t *__restrict__ a2g,
         const float *__restrict__ axes, float tol, float inv_ntot,
         float *__restrict__ per_res, float *__restrict__ dchi) {
     __shared__ int s_list[CL_WAVES][CL_MAXC];
+    __shared__ float s_red[CL_WAVES][16][4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int i = blockIdx.x * CL_WAVES + wave;
+    const int i = blockIdx.x;              // one workgroup per residue; its waves take interleaved 64-partner windows
     if (i >= N) return;
     const int b = i / L;
     const int a = lane & 15, slot = lane >> 4;
     const bool own = a < 14;
-    const int S = (int)rtype[i];
-    const long ri = rindex[i];
+    // rec[n] (written by k_atom14): 14 x (x, y, z, exists * radius) | (CA, bounding radius) | (n side-chain atoms,
+    // residue_index, residue type): every partner needs 15 coalesced 16-byte reads instead of ~85 scattered ones
+    const float4 me = rec[(size_t)i * 16 + 15];
+    const int S = __float_as_int(me.z);
+    const int ri = __float_as_int(me.y);
     float pa[3] = {0.f, 0.f, 0.f}, ea = 0.f, ra = 0.f;
     if (own) {
-#pragma unroll
-        for (int k = 0; k < 3; k++) pa[k] = xyz[((size_t)i * 14 + a) * 3 + k];
-        ea = exists[(size_t)i * 14 + a];
-        ra = ea * between_radius[S * 14 + a];
+        const float4 q = rec[(size_t)i * 16 + a];
+        pa[0] = q.x; pa[1] = q.y; pa[2] = q.z;
+        ra = q.w;
+        ea = q.w != 0.f ? 1.f : 0.f;
     }
-    // number of side-chain atoms and this residue's weight in the mean
-    float nsc = (own && a >= 4) ? ea : 0.f;
-    for (int o = 8; o > 0; o >>= 1) nsc += __shfl_xor(nsc, o);
+    const float nsc = me.x;                          // number of side-chain atoms -> this residue's weight in the mean
     const float wi = inv_ntot / (nsc + 1e-10f);
-    const float cai[3] = {xyz[((size_t)i * 14 + 1) * 3], xyz[((size_t)i * 14 + 1) * 3 + 1], xyz[((size_t)i * 14 + 1) * 3 + 2]};
-    const float radi = brad[i];
+    const float4 cme = rec[(size_t)i * 16 + 14];          // bounding sphere (centroid, radius)
+    const float cai[3] = {cme.x, cme.y, cme.z};
+    const float radi = cme.w;
     const float reach = 3.6f - tol;                 // largest r_a + r_b - tol (S-S)
 
     float loss_a = 0.f, ga[3] = {0.f, 0.f, 0.f};
     int *list = s_list[wave];
     // partner residues of the same complex, in windows that fit the candidate list
-    for (int base = 0; base < L; ) {
+    for (int base = 64 * wave; base < L; ) {
         int cnt = 0;
         int jscan = base;
-        for (; jscan < L && cnt + 64 <= CL_MAXC; jscan += 64) {
+#ifdef PP_X_CL_NOSCAN      // timing experiment: no candidate scan (and hence no pairs)
+        jscan = L;
+#endif
+        for (; jscan < L && cnt + 64 <= CL_MAXC; jscan += 64 * CL_WAVES) {
             int jl = jscan + lane;
             bool keep = false;
             if (jl < L) {
                 int jg = b * L + jl;
                 if (jg != i) {
-                    float dx = xyz[((size_t)jg * 14 + 1) * 3] - cai[0], dy = xyz[((size_t)jg * 14 + 1) * 3 + 1] - cai[1],
-                          dz = xyz[((size_t)jg * 14 + 1) * 3 + 2] - cai[2];
-                    float lim = radi + brad[jg] + reach;
-                    keep = (lim > 0.f) && (dx * dx + dy * dy + dz * dz < lim * lim) && (rindex[jg] != ri);
+                    const float4 cj = rec[(size_t)jg * 16 + 14];
+                    const float4 mj = rec[(size_t)jg * 16 + 15];
+                    float dx = cj.x - cai[0], dy = cj.y - cai[1], dz = cj.z - cai[2];
+                    float lim = radi + cj.w + reach;
+                    keep = (lim > 0.f) && (dx * dx + dy * dy + dz * dz < lim * lim) && (__float_as_int(mj.y) != ri);
                 }
             }
             unsigned long long bal = __ballot(keep);
@@ -195,31 +245,34 @@ k_clash(int N, int L, const float *__restrict__ xyz, const float *__restrict__ e
         }
         base = jscan;
         __builtin_amdgcn_wave_barrier();
+#ifdef PP_X_CL_NOPAIR      // timing experiment: candidate scan only
+        cnt = 0;
+#endif
         for (int c = slot; c < cnt; c += 4) {
             const int jg = list[c];
-            const int Sj = (int)rtype[jg];
-            const long rj = rindex[jg];
+            const float4 mj = rec[(size_t)jg * 16 + 15];
+            const int rj = __float_as_int(mj.y);
             const bool i_low = ri < rj;
             const bool adjacent = i_low ? (ri + 1 == rj) : (rj + 1 == ri);
-            float nscj = 0.f;
-#pragma unroll
-            for (int bb = 4; bb < 14; bb++) nscj += exists[(size_t)jg * 14 + bb];
-            const float wj = inv_ntot / (nscj + 1e-10f);
+            const float wj = inv_ntot / (mj.x + 1e-10f);
             if (own && ea != 0.f) {
 #pragma unroll
                 for (int bb = 0; bb < 14; bb++) {
-                    const float eb = exists[(size_t)jg * 14 + bb];
-                    bool ok = eb != 0.f && !(a < 4 && bb < 4) && !(a == 5 && bb == 5);
+                    const float4 pb = rec[(size_t)jg * 16 + bb];
+                    bool ok = pb.w != 0.f && !(a < 4 && bb < 4) && !(a == 5 && bb == 5);
                     if (adjacent) {
                         // peptide bond C(lower) - N(higher)
                         if (i_low ? (a == 2 && bb == 0) : (a == 0 && bb == 2)) ok = false;
                     }
                     if (ok) {
-                        const float *pb = xyz + ((size_t)jg * 14 + bb) * 3;
-                        float dx = pa[0] - pb[0], dy = pa[1] - pb[1], dz = pa[2] - pb[2];
-                        float d = sqrtf(1e-10f + dx * dx + dy * dy + dz * dz);
-                        float rb = eb * between_radius[Sj * 14 + bb];
-                        float err = (ra + rb) - tol - d;
+                        float dx = pa[0] - pb.x, dy = pa[1] - pb.y, dz = pa[2] - pb.z;
+                        // squared test first: the IEEE sqrt and the division below are ~50 instructions, and only a few
+                        // per cent of the surviving atom pairs overlap (most trips skip the branch for the whole wave)
+                        const float d2 = 1e-10f + dx * dx + dy * dy + dz * dz;
+                        const float thr = (ra + pb.w) - tol;
+                        if (!(thr > 0.f && d2 < thr * thr)) continue;
+                        float d = sqrtf(d2);
+                        float err = thr - d;
                         if (err > 0.f) {
                             loss_a += err;
                             float cw = (a >= 4 ? wi : 0.f) + (bb >= 4 ? wj : 0.f);
@@ -232,14 +285,31 @@ k_clash(int N, int L, const float *__restrict__ xyz, const float *__restrict__ e
         }
         __builtin_amdgcn_wave_barrier();
     }
+    // fold the 4 partner stripes, then the 4 waves (fixed order: reproducible)
+    for (int o = 16; o <= 32; o <<= 1) {
+        loss_a += __shfl_xor(loss_a, o);
+        ga[0] += __shfl_xor(ga[0], o); ga[1] += __shfl_xor(ga[1], o); ga[2] += __shfl_xor(ga[2], o);
+    }
+    if (lane < 16) {
+        s_red[wave][lane][0] = loss_a; s_red[wave][lane][1] = ga[0]; s_red[wave][lane][2] = ga[1]; s_red[wave][lane][3] = ga[2];
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    if (slot == 0) {
+#pragma unroll
+        for (int w = 1; w < CL_WAVES; w++) {
+            loss_a += s_red[w][a][0]; ga[0] += s_red[w][a][1]; ga[1] += s_red[w][a][2]; ga[2] += s_red[w][a][3];
+        }
+    } else {
+        loss_a = 0.f; ga[0] = ga[1] = ga[2] = 0.f;
+    }
     // within-residue bounds: stripes of partner atoms b = slot, slot+4, ...
     if (own && ea != 0.f) {
         for (int bb = slot; bb < 14; bb += 4) {
             if (bb == a || (a < 4 && bb < 4)) continue;
-            const float eb = exists[(size_t)i * 14 + bb];
-            if (eb == 0.f) continue;
-            const float *pb = xyz + ((size_t)i * 14 + bb) * 3;
-            float dx = pa[0] - pb[0], dy = pa[1] - pb[1], dz = pa[2] - pb[2];
+            const float4 pb = rec[(size_t)i * 16 + bb];
+            if (pb.w == 0.f) continue;
+            float dx = pa[0] - pb.x, dy = pa[1] - pb.y, dz = pa[2] - pb.z;
             float d = sqrtf(1e-10f + dx * dx + dy * dy + dz * dz);
             float lo = lower[(S * 14 + a) * 14 + bb], up = upper[(S * 14 + a) * 14 + bb];
             float e_lo = lo - d, e_up = d - up;
@@ -365,17 +435,19 @@ k_prox_step(int N, int t, float lamda, float step_size, float bc2s, const float 
 
 pp_status pp_launch_atom14(pp_ctx *c, const float *chi, float *xyz, hipStream_t s) {
     const pp_plan *p = c->plan;
-    hipLaunchKernelGGL(k_atom14, dim3((c->N + 63) / 64), dim3(64), 0, s, c->N, c->b.X, c->b.residue_type, c->b.BB_D, chi,
+    // the packed records feed k_clash; they need the residue numbering, which geometry-only batches may not carry
+    float4 *rec = c->b.residue_index ? reinterpret_cast<float4 *>(c->rec) : nullptr;
+    hipLaunchKernelGGL(k_atom14, dim3((c->N + 15) / 16), dim3(256), 0, s, c->N, c->b.X, c->b.residue_type, c->b.BB_D, chi,
                        p->default_frames, p->atom14_to_group, p->atom14_mask, p->lit_positions, c->b.atom_mask,
-                       xyz, c->axes, c->brad);
+                       p->between_radius, c->b.residue_index, xyz, c->axes, c->brad, rec);
     PP_HIP_CHECK(hipGetLastError());
     return PP_OK;
 }
 
 pp_status pp_launch_clash(pp_ctx *c, const float *xyz, float *per_res, float *dchi, hipStream_t s) {
     const pp_plan *p = c->plan;
-    hipLaunchKernelGGL(k_clash, dim3((c->N + CL_WAVES - 1) / CL_WAVES), dim3(64 * CL_WAVES), 0, s, c->N, c->L, xyz,
-                       c->b.atom_mask, c->b.residue_type, c->b.residue_index, c->brad, p->between_radius,
+    hipLaunchKernelGGL(k_clash, dim3(c->N), dim3(64 * CL_WAVES), 0, s, c->N, c->L, xyz,
+                       reinterpret_cast<const float4 *>(c->rec), c->b.atom_mask,
                        p->bounds_lower, p->bounds_upper, p->atom14_to_group, c->axes, p->clash_tol,
                        1.0f / (float)c->N, per_res, dchi);
     PP_HIP_CHECK(hipGetLastError());

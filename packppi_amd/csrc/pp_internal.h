@@ -99,6 +99,7 @@ struct pp_ctx {
     int max_steps;
     // clash / proximal workspaces
     float *xyz;               // [N][14][3]
+    float *rec;               // [N][16][4] packed per-residue records for k_clash (positions + radii, CA + reach, ids)
     float *axes;              // [N][4][6]  chi-frame x-axis (3) | origin (3)
     float *brad;              // [N] bounding radius around CA
     float *per_res;           // [N]
