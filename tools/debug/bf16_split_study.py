@@ -21,6 +21,27 @@ def split3(x):
     l = r2.bfloat16().float()
     return h, m, l
 
+def split2h(x):
+    h = x.half().float(); r = x - h
+    l = r.half().float()
+    return h, l
+
+def make_linear_h(scaled):
+    cache = {}
+    def lin(x, w, b=None):
+        if x.dim() != 4:
+            return orig_linear(x, w, b)
+        key = id(w)
+        if key not in cache:
+            cache[key] = split2h(w)
+        wh, wl = cache[key]
+        xh, xl = split2h(x)
+        y = xh @ wh.T + (xh @ wl.T + xl @ wh.T)
+        if b is not None:
+            y = y + b
+        return y
+    return lin
+
 def make_linear(nterms):
     cache = {}
     def lin(x, w, b=None):
@@ -40,8 +61,8 @@ def make_linear(nterms):
     return lin
 
 sched = torch.linspace(1, 0, steps + 1)
-for name, n in (("fp32", 0), ("bf16x6", 6), ("bf16x3", 3)):
-    R._linear = orig_linear if n == 0 else make_linear(n)
+for name, n in (("fp32", 0), ("fp16x3", -3), ("bf16x6", 6)):
+    R._linear = orig_linear if n == 0 else (make_linear_h(False) if n == -3 else make_linear(n))
     t0 = time.time()
     with torch.no_grad():
         chi = R.sampling(sd, batch, init.clone(), sched)
