@@ -555,6 +555,15 @@ extern "C" pp_status pp_debug_edge(pp_ctx *c, int layer, void *stream) {
     if (!c || !c->plan->has_network) FAIL(PP_ERR_INVALID, "pp_debug_edge: bad ctx");
     return pp_launch_edge_update(c, layer, static_cast<hipStream_t>(stream));
 }
+extern "C" pp_status pp_debug_set_hE(pp_ctx *c, const float *src, size_t n) {
+    if (!c || !src) FAIL(PP_ERR_INVALID, "pp_debug_set_hE: null");
+    PP_HIP_CHECK(hipMemcpy(c->hE, src, n * sizeof(float), hipMemcpyDeviceToDevice));
+    return PP_OK;
+}
+extern "C" pp_status pp_debug_nm(pp_ctx *c, int layer, void *stream) {
+    if (!c || !c->plan->has_network) FAIL(PP_ERR_INVALID, "pp_debug_nm: bad ctx");
+    return pp_launch_node_message(c, layer, static_cast<hipStream_t>(stream));
+}
 extern "C" pp_status pp_debug_buffer(pp_ctx *c, int which, float *dst, size_t n) {
     if (!c || !dst) FAIL(PP_ERR_INVALID, "pp_debug_buffer: null");
     const float *src = which == 0 ? c->hE : which == 1 ? c->S : which == 2 ? c->msum : which == 3 ? c->hE0 : c->Zem;

@@ -202,3 +202,23 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(L, "_LIB_PATH", "/nonexistent/libpackppi_hip.so")
     with pytest.raises(RuntimeError):
         L.load()
+
+
+@pytest.mark.parametrize("L", [400, 800, 1100])
+def test_sampling_is_bit_reproducible(weights, L):
+    """Several workgroups per CU and more than one round of workgroups: the same call twice must agree bit for bit
+    (guards the LDS-DMA weight pipeline against the timing-dependent hazards documented in pp_edge.hip)."""
+    from packppi_amd import synth
+    from packppi_amd.featurize import protein_to_batch
+    from packppi_amd.module import TDiffusionModule
+    m = TDiffusionModule(weights, device=DEV)
+    b = protein_to_batch(synth.make_complex(L, 11)).to(DEV)
+    ctx = m._context(b)
+    sched = torch.linspace(1, 0, 13)
+    g = torch.Generator().manual_seed(L)
+    init = ((torch.rand(1, L, 4, generator=g) * 2 - 1) * 3.0 * b.SC_D_mask.cpu()).to(DEV)
+    ref = ctx.sample(init, sched).cpu()
+    for _ in range(4):
+        again = ctx.sample(init, sched).cpu()
+        assert torch.equal(again, ref), float((again - ref).abs().max())
+    assert torch.isfinite(ref).all()

@@ -17,8 +17,13 @@ l = lib.load()
 l.pp_debug_edge.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
 l.pp_debug_buffer.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
 K = min(32, L)
+LAYER = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+l.pp_debug_set_hE.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+hE_in = torch.empty(L * K * 128, device="cuda:0")
+assert l.pp_debug_buffer(ctx.handle, 0, C.c_void_p(hE_in.data_ptr()), hE_in.numel()) == 0
 def run():
-    assert l.pp_debug_edge(ctx.handle, 0, None) == 0
+    assert l.pp_debug_set_hE(ctx.handle, C.c_void_p(hE_in.data_ptr()), hE_in.numel()) == 0
+    assert l.pp_debug_edge(ctx.handle, LAYER, None) == 0
     hE = torch.empty(L * K * 128, device="cuda:0"); S = torch.empty(L * 128, device="cuda:0")
     assert l.pp_debug_buffer(ctx.handle, 0, C.c_void_p(hE.data_ptr()), hE.numel()) == 0
     assert l.pp_debug_buffer(ctx.handle, 1, C.c_void_p(S.data_ptr()), S.numel()) == 0
