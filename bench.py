@@ -27,7 +27,6 @@ N_DIFFUSION_STEPS = 100
 EDGE_UPDATE_FLOP_PER_EDGE = 2 * (456 * 128 + 128 * 128 + 128 * 128) + 2 * (128 * 512 + 512 * 128)
 NODE_MSG_FLOP_PER_EDGE = 2 * (456 * 128 + 128 * 128 + 128 * 128)
 FP32_MFMA_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
-SPLIT_F16_PEAK_TFLOPS = 16.0 * FP32_MFMA_PEAK_TFLOPS / 3.0     # F16 MFMA runs at 16x the FP32-matrix rate (MI355X_MICROARCH.md); 3 products per MAC
 
 
 def load_t1124():
@@ -198,14 +197,13 @@ def main():
     t_node = insitu["k_node_message"][0] * 1e-3
     t_edge_b2b = ctx.time_kernel(1, 20) * 1e-3
     n_edges = residues * ctx.K
-    # Dominant kernel: k_edge_update.  Its algorithmic work is the reference's edge-message MLP + edge FFN (layers.py:
-    # 133-147), 2 FLOP per MAC of the dense layers, per edge.  The kernel computes every fp32 product as three f16 MFMA
-    # products (hi*hi + hi*lo + lo*hi, fp32 accumulate; accuracy of an fp32 FMA chain), so the roofline it is bound by is
-    # the dense F16 MFMA peak / 3 in fp32-equivalent FLOPs.
-    achieved = EDGE_UPDATE_FLOP_PER_EDGE * n_edges / t_edge / 1e12
-    # executed f16 MFMAs of one launch (average of the layer-0 launch, whose W_B h_E0 products are hoisted, and layer 1)
-    mfma_per_wave = ((47 - 3) * 6 + 15 + (43 - 3) * 6 + 15) / 2.0
-    executed_f16 = mfma_per_wave * 4 * 32768.0 * residues
+    # k_edge_update(l) also computes the node message of layer l + 1 (fused): its algorithmic work is both MLP chains
+    # of the reference (layers.py:119-148), 2 FLOP per MAC of the dense layers, per edge.  Executed MFMA work is lower:
+    # layer 0's W_B h_E0 products are timestep-invariant and computed once per complex.
+    fused_flop_per_edge = EDGE_UPDATE_FLOP_PER_EDGE + NODE_MSG_FLOP_PER_EDGE
+    achieved = fused_flop_per_edge * n_edges / t_edge / 1e12
+    executed_mfma = (2960 + 656 - 128) * 4096.0 * residues        # average of the layer-0 and layer-1 launches
+
     if rank == 0:
         out = {
             "metric": "sampled residues/sec at 100 diffusion steps",
@@ -214,32 +212,29 @@ def main():
             "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (edge MLPs: split-f16 MFMA, 3 products per MAC, fp32 accumulate; node kernels: fp32 VALU)", "data": "synthetic (seeded random weights; T1124 backbone fixture, seeded initial noise)"
+            "dtype": "f32", "data": "synthetic (seeded random weights; T1124 backbone fixture, seeded initial noise)"
             if args.workload == "t1124" else "synthetic",
             "config": {"workload": name, "diffusion_steps": N_DIFFUSION_STEPS, "proximal": bool(args.proximal),
                        "residues_per_gpu": residues, "mode": "ode"},
             "roofline": {"bound": "mfma", "kernel": "k_edge_update", "achieved": achieved,
-                         "peak": SPLIT_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / SPLIT_F16_PEAK_TFLOPS,
-                         "peak_is": "dense F16 MFMA peak 2516.8 TFLOP/s (16 x the 157.3 FP32-matrix peak) / 3 products per "
-                                    "fp32-equivalent MAC",
-                         "achieved_over_fp32_matrix_peak": achieved / FP32_MFMA_PEAK_TFLOPS,
+                         "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
                          "traffic": pmc_traffic("k_edge_update") if args.workload == "t1124" else None,
                          "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate --pmc "
                                          "passes of this command; profiles/*_pmc_traffic.json)",
                          "kernel_ms": t_edge * 1e3,
-                         "algorithmic_flop_per_launch": EDGE_UPDATE_FLOP_PER_EDGE * n_edges,
-                         "executed_f16_mfma_tflops": executed_f16 / t_edge / 1e12,
-                         "executed_frac_of_f16_peak": executed_f16 / t_edge / 1e12 / (3.0 * SPLIT_F16_PEAK_TFLOPS),
+                         "kernel_does": "edge update of layer l + node message of layer l+1, one launch",
+                         "algorithmic_flop_per_launch": fused_flop_per_edge * n_edges,
+                         "executed_mfma_tflops": executed_mfma / t_edge / 1e12,
                          # whole pass against SURVEY 8(d): 46 792 576 algorithmic FLOP per residue per network evaluation
                          "whole_pass_algorithmic_tflops": 46792576.0 * total_res * N_DIFFUSION_STEPS * args.steps / elapsed / 1e12
                                                           / max(args.gpus, 1),
                          "whole_pass_frac_of_peak": 46792576.0 * total_res * N_DIFFUSION_STEPS * args.steps / elapsed / 1e12
-                                                    / max(args.gpus, 1) / SPLIT_F16_PEAK_TFLOPS,
+                                                    / max(args.gpus, 1) / FP32_MFMA_PEAK_TFLOPS,
                          "kernel_launches_timed": insitu["k_edge_update"][1],
                          "kernel_ms_back_to_back": t_edge_b2b * 1e3,
                          "node_update_kernel_ms": insitu["k_node_update"][0],
                          "node_message_kernel_ms": t_node * 1e3,
-                         "node_message_tflops": NODE_MSG_FLOP_PER_EDGE * n_edges / t_node / 1e12},
+                         "node_message_layer0_tflops": NODE_MSG_FLOP_PER_EDGE * n_edges / t_node / 1e12},
             "parity": {"max_abs_dchi_vs_reference_rad": max_dchi, "atom_rmsd": float(m["atom_rmsd"])},
             "metrics_rows_gathered": len(rows),
         }
