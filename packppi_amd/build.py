@@ -6,9 +6,11 @@ import sys
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libpackppi_hip.so")
-SOURCES = ["pp_api.hip", "pp_prepare.hip", "pp_node.hip", "pp_edge.hip", "pp_clash.hip"]
+# PACKPPI_EDGE=f16 builds the experimental split-f16 edge kernels (pp_edge_f16.hip) instead of the shipped fp32 ones
+EDGE_F16 = os.environ.get("PACKPPI_EDGE", "") == "f16"
+SOURCES = ["pp_api.hip", "pp_prepare.hip", "pp_node.hip", "pp_edge_f16.hip" if EDGE_F16 else "pp_edge.hip", "pp_clash.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-variable",
-         "-Wno-unused-but-set-variable"]
+         "-Wno-unused-but-set-variable"] + (["-DPP_EDGE_F16"] if EDGE_F16 else [])
 
 
 def _hipcc():

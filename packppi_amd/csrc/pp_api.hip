@@ -9,6 +9,8 @@
 #include <vector>
 
 #include "pp_internal.h"
+#include <cstring>
+#include <cmath>
 #include <chrono>
 
 static thread_local std::string g_err;
@@ -79,6 +81,73 @@ static size_t put_T4(std::vector<float> &arena, const float *W, int rows, int ld
     return at;
 }
 
+#ifdef PP_EDGE_F16      // experimental split-f16 edge kernels (pp_edge_f16.hip): PACKPPI_EDGE=f16 python -m packppi_amd.build
+// fp32 -> IEEE binary16 bits, round to nearest even (subnormals kept: the MFMA honours them)
+static uint16_t f2h(float f) {
+    uint32_t x;
+    memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    x &= 0x7fffffffu;
+    if (x >= 0x7f800000u) return (uint16_t)(sign | 0x7c00u | ((x > 0x7f800000u) ? 0x200u : 0));
+    if (x >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);                   // rounds to >= 65520: overflow
+    if (x < 0x33000001u) return (uint16_t)sign;                                 // < 2^-25: rounds to zero
+    int e = (int)(x >> 23) - 127;
+    uint32_t m = (x & 0x7fffffu) | 0x800000u;
+    int shift = e < -14 ? 13 + (-14 - e) : 13;                                  // subnormal: shift further
+    uint32_t r = m >> shift, rem = m & ((1u << shift) - 1u), half = 1u << (shift - 1);
+    if (rem > half || (rem == half && (r & 1u))) r++;
+    uint32_t out = e < -14 ? r : (((uint32_t)(e + 15) << 10) + (r - 0x400u));   // a carry out of the mantissa bumps e
+    return (uint16_t)(sign | out);
+}
+static float h2f(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 31u, m = h & 0x3ffu;
+    float v;
+    if (e == 0) v = ldexpf((float)m, -24);
+    else if (e == 31) v = m ? NAN : INFINITY;
+    else v = ldexpf((float)(m | 0x400u), (int)e - 25);
+    uint32_t b;
+    memcpy(&b, &v, 4);
+    b |= sign;
+    memcpy(&v, &b, 4);
+    return v;
+}
+
+// Append one weight chunk (a K = 32 slice of a 128-row layer) packed for the edge kernels' wave-private LDS-DMA pipeline
+// and split-f16 arithmetic (pp_edge.hip): [wave 4][k-step s 2][part hi|lo 2][lane 64][i 8] halves = 16 KB, where lane =
+// (row & 31, half h) of wave row >> 5 holds the A-operand of v_mfma_f32_32x32x16_f16 for k-step s: input column
+//   col(s, h, i)   (`colmap`; < 0 = zero padding)  --  32-wide slices: col0 + 8 (2 s + (i >> 2)) + 4 h + (i & 3), the order
+//   in which the accumulator registers of the producing layer become B operands.
+template <typename ColMap>
+static void put_chunk_f16(std::vector<float> &arena, const float *W, int ld, int row0, ColMap colmap) {
+    size_t at = arena.size();
+    arena.resize(at + (size_t)128 * 32, 0.f);
+    uint16_t *d = reinterpret_cast<uint16_t *>(arena.data() + at);
+    for (int wave = 0; wave < 4; wave++)
+        for (int s = 0; s < 2; s++)
+            for (int lane = 0; lane < 64; lane++)
+                for (int i = 0; i < 8; i++) {
+                    const int row = row0 + 32 * wave + (lane & 31), h = lane >> 5;
+                    const int col = colmap(s, h, i);
+                    const float w = col >= 0 ? W[(size_t)row * ld + col] : 0.f;
+                    const uint16_t hi = f2h(w);
+                    const uint16_t lo = f2h(w - h2f(hi));
+                    uint16_t *base = d + (size_t)wave * 2048;      // 4 KB per wave = 2048 halves
+                    base[((2 * s + 0) * 64 + lane) * 8 + i] = hi;
+                    base[((2 * s + 1) * 64 + lane) * 8 + i] = lo;
+                }
+}
+static void put_chunk(std::vector<float> &arena, const float *W, int ld, int row0, int col0, int ncols) {
+    (void)ncols;
+    put_chunk_f16(arena, W, ld, row0, [col0](int s, int h, int i) { return col0 + 8 * (2 * s + (i >> 2)) + 4 * h + (i & 3); });
+}
+// geometry chunk C of a message MLP's first layer: features f = 16 (2 C + s) + 8 h + i of the 72 (columns 384 + f)
+static void put_geo_chunk(std::vector<float> &arena, const float *W, int C) {
+    put_chunk_f16(arena, W, 456, 0, [C](int s, int h, int i) {
+        const int f = 16 * (2 * C + s) + 8 * h + i;
+        return f < 72 ? 384 + f : -1;
+    });
+}
+#else
 // Append one weight chunk = the [128 rows][ncols] block of W (row stride ld) at (row0, col0), packed for the edge
 // kernels' wave-private LDS-DMA pipeline (pp_edge.hip): [wave 4][quad 4][lane 64][4 floats], where lane = (row & 31,
 // half h) of wave row >> 5 holds the A-operand registers of MFMA steps 4q..4q+3:
@@ -97,6 +166,8 @@ static void put_chunk(std::vector<float> &arena, const float *W, int ld, int row
                     d[((wave * 4 + q) * 64 + lane) * 4 + pp] = W[(size_t)(row0 + row) * ld + col0 + col];
                 }
 }
+static void put_geo_chunk(std::vector<float> &arena, const float *W, int C) { put_chunk(arena, W, 456, 0, 384 + 24 * C, 24); }
+#endif
 // chunk stream of one message MLP: [W_in[:,128:256] x4 unless `skip_wb`,] W_in[:,384:456] x3 (24 cols), W_mid x4
 // [, W_out x4, FFN blocks].  Layer 0 skips the W_B chunks: its W_B h_E0 is precomputed once per complex (k_edge_static).
 static size_t put_stream(std::vector<float> &arena, const float *w, const LayerOff &L, bool edge, bool skip_wb) {
@@ -105,7 +176,7 @@ static size_t put_stream(std::vector<float> &arena, const float *w, const LayerO
     const float *win = w + (edge ? L.em_in_w : L.nm_in_w), *wmid = w + (edge ? L.em_mid_w : L.nm_mid_w);
     if (!skip_wb)
         for (int s = 0; s < 4; s++) put_chunk(arena, win, 456, 0, 128 + 32 * s, 32);
-    for (int g = 0; g < 3; g++) put_chunk(arena, win, 456, 0, 384 + 24 * g, 24);
+    for (int g = 0; g < 3; g++) put_geo_chunk(arena, win, g);
     for (int s = 0; s < 4; s++) put_chunk(arena, wmid, 128, 0, 32 * s, 32);
     if (edge) {
         for (int s = 0; s < 4; s++) put_chunk(arena, w + L.em_out_w, 128, 0, 32 * s, 32);
@@ -371,9 +442,9 @@ static pp_status run_network(pp_ctx *c, hipStream_t s, int step, int last_mode, 
                              bool embed_next) {
     pp_status st;
     for (int l = 0; l < 3; l++) {
-        if (l == 0) {                 // layers 1 and 2: computed by the tail of the previous layer's edge update
+        if (l == 0 || !pp_edge_fused()) {   // fused build: layers 1 and 2 come from the tail of the previous edge update
             prof_mark(c, 0, s);
-            st = pp_launch_node_message(c, 0, s);
+            st = pp_launch_node_message(c, l, s);
             prof_mark(c, 0, s);
             if (st != PP_OK) return st;
         }

@@ -24,6 +24,39 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+
+// ---- split-f16 arithmetic -------------------------------------------------------------------------------------
+// Every fp32 operand x of the dense layers is carried as two f16 numbers, hi = f16(x) and lo = f16(x - hi)
+// (x = hi + lo to 2^-22 relative; f16 subnormals are honoured by the MFMA, measured), and a product W x is three
+// v_mfma_f32_32x32x16_f16 with fp32 accumulation: Wh xh + Wh xl + Wl xh (the dropped Wl xl term is 2^-22 relative).
+// Measured (tools/debug/ubench/mfma_f16_probe.hip): K = 128 dot products come out as close to fp64 as a sequential fp32
+// FMA chain does (2.7e-6 vs 4.1e-6 max abs error), at 3 x 32 cycles per 16-deep step against 8 x 64 cycles for
+// v_mfma_f32_32x32x2_f32: 5.3x the FP32-matrix rate, with the same bytes per weight (2 x 2) and per activation.
+// Range: |x| must stay below 65504 (LayerNorm-bounded activations and O(1) weights do by orders of magnitude).
+//
+// One tile (32 features of this lane's edge) as MFMA operands: k-step s in {0,1} carries accumulator registers
+// 8s..8s+7 of the tile, i.e. features 32 t + 8 (2 s + (i >> 2)) + 4 h + (i & 3), i = 0..7, for lane half h.
+struct HT {
+    h8 hi[2], lo[2];
+};
+__device__ __forceinline__ void split_tile(const f32x16 &v, HT &o) {
+#pragma unroll
+    for (int s = 0; s < 2; s++)
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const float x = __builtin_amdgcn_fmed3f(v[8 * s + i], -65504.f, 65504.f);    // saturate, never inf
+            const _Float16 hh = (_Float16)x;
+            o.hi[s][i] = hh;
+            o.lo[s][i] = (_Float16)(x - (float)hh);
+        }
+}
+__device__ __forceinline__ void join_tile(const HT &t, f32x16 &v) {
+#pragma unroll
+    for (int s = 0; s < 2; s++)
+#pragma unroll
+        for (int i = 0; i < 8; i++) v[8 * s + i] = (float)t.hi[s][i] + (float)t.lo[s][i];
+}
 
 #define ET 256
 #define CH32 (128 * 32)                 // floats per packed weight chunk (16 KB); a wave's quarter is 1024 floats
@@ -68,74 +101,91 @@ enum { P_BMID = 0, P_BOUT = 128, P_FOB = 256, P_G2 = 384, P_BE2 = 512, P_FIB = 6
 // stream needs NO workgroup barrier; barriers remain only around the activation exchange buffer.
 // hipcc does not count these loads: between the prologue and the epilogue the kernels issue no ordinary global
 // loads (every small vector is staged to LDS or registers up front), so no compiler-made vmcnt(0) drains the ring.
-//
-// HAZARD (found while moving these kernels to split-f16 MFMA, tools/debug/experiments/pp_edge_f16_split.hip, where
-// stages are 4x shorter; measured with tools/debug/edge_repro.py / soak.py): an LDS-DMA instruction reads its address
-// VGPRs LATE -- when the memory pipeline accepts it, which with several workgroups per CU can be hundreds of cycles after
-// issue -- and nothing interlocks a later VALU write to those registers.  hipcc, for which an asm's inputs are dead at
-// its end, reuses them at once; the copy then fetches from a garbage address: sporadic wrong weight tiles, only with
-// co-resident workgroups, gone with an s_waitcnt vmcnt(0) after every issue.  The fp32 kernels never showed it (their
-// soak is clean over millions of workgroup launches), but they are written to the safe pattern anyway: the per-lane part
-// of every DMA address lives in ONE register for the whole kernel (`laneoff` = lane * 16, `rowoff` for the residual
-// gather), each statement takes it read-write and every wait names it, so it is never handed to anything else; the
-// wave-uniform part of the address goes in SGPRs; and no lane is masked off (divergent control flow) while a copy is in
-// flight -- surplus lanes use clamped indices and rewrite the same value.
-__device__ __forceinline__ void dma_chunk(const float *sbase, unsigned &laneoff, unsigned lds_dst) {
-    unsigned keep;
+// HAZARD (measured, tools/debug/edge_repro.py): an LDS-DMA instruction reads its address VGPRs LATE -- when the memory
+// pipeline accepts it, which under load (several workgroups per CU) can be hundreds of cycles after issue -- and
+// nothing interlocks a later VALU write to those registers.  hipcc, for which the asm's inputs are dead at its end,
+// reuses them at once; the copy then fetches from a garbage address (sporadic wrong weight tiles, only with co-resident
+// workgroups, gone with an s_waitcnt vmcnt(0) after every issue).  So the per-lane part of every DMA address lives in
+// ONE register per wave for the whole kernel (`laneoff` = lane * 16, or the gather offset of dma_tile): each statement
+// takes it read-write and the next wait takes it as input, so the compiler keeps it intact across the window; the
+// wave-uniform part of the address goes in fixed SGPRs written only by these statements.  The same holds for M0 (LDS
+// destination) and for EXEC: a lane masked off by a LATER divergent branch is dropped from a copy still in flight, so
+// between an issue and its wait the kernels keep every lane active (clamped indices instead of predication).
+// M0 (the LDS destination) is likewise left alone after the issue: it is written only by the next DMA statement
+// (hipcc emits no M0 use of its own in these kernels; checked in the ISA).
+__device__ __forceinline__ void dma_chunk(const float *&sbase, unsigned &laneoff, unsigned lds_dst) {
+    // M0 (LDS destination) and s[98:99] (wave-uniform chunk address) are written ONLY here, after the previous copy has
+    // completed (the caller's s_waitcnt vmcnt(0)), and then rest until the next issue; hipcc emits no M0 use of its own in
+    // these kernels and allocates SGPRs from s0 up (~65 used).
     asm volatile("s_waitcnt lgkmcnt(0)\n\t"          // this wave's reads of the slot being refilled have returned
-                 "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
-                 "global_load_lds_dwordx4 %1, %2\n\t"
-                 "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
-                 "global_load_lds_dwordx4 %1, %2 offset:2048\n\t"
-                 "global_load_lds_dwordx4 %1, %2 offset:3072\n\t"
-                 "s_mov_b32 m0, %0"
-                 : "=&s"(keep), "+v"(laneoff) : "s"(sbase), "s"(lds_dst) : "memory");
+                 "s_mov_b32 m0, %2\n\t"
+                 "s_mov_b64 s[98:99], %1\n\ts_nop 4\n\t"
+                 "global_load_lds_dwordx4 %0, s[98:99]\n\t"
+                 "global_load_lds_dwordx4 %0, s[98:99] offset:1024\n\t"
+                 "global_load_lds_dwordx4 %0, s[98:99] offset:2048\n\t"
+                 "global_load_lds_dwordx4 %0, s[98:99] offset:3072"
+                 : "+v"(laneoff) : "s"(sbase), "s"(lds_dst) : "memory", "s98", "s99");
+    sbase += CH32;          // the running chunk pointer
 }
-// one tile of a row-major [.][128] row set, gathered per lane (byte offset rowoff of this lane's 32-feature row piece
-// + 16 h from sbase) into the [quad][lane][4] register image at lds_dst: quad q is the float4 at + 32 q bytes.  The
-// instruction offset moves the global AND the LDS address, hence the 1024 - 32 stride on M0.
-__device__ __forceinline__ void dma_tile(const float *sbase, unsigned &rowoff, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile("s_waitcnt lgkmcnt(0)\n\t"
-                 "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
-                 "global_load_lds_dwordx4 %1, %2\n\t"
-                 "s_add_u32 m0, m0, 992\n\ts_nop 0\n\t"
-                 "global_load_lds_dwordx4 %1, %2 offset:32\n\t"
-                 "s_add_u32 m0, m0, 992\n\ts_nop 0\n\t"
-                 "global_load_lds_dwordx4 %1, %2 offset:64\n\t"
-                 "s_add_u32 m0, m0, 992\n\ts_nop 0\n\t"
-                 "global_load_lds_dwordx4 %1, %2 offset:96\n\t"
-                 "s_mov_b32 m0, %0"
-                 : "=&s"(keep), "+v"(rowoff) : "s"(sbase), "s"(lds_dst) : "memory", "scc");
-}
-// counted wait; names the DMA address registers so that they stay allocated (see HAZARD)
-template <int N>
-__device__ __forceinline__ void wait_vm(unsigned laneoff, unsigned rowoff) {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N), "v"(laneoff), "v"(rowoff) : "memory");
+// full wait; names the DMA address register so that it stays allocated (see HAZARD above)
+__device__ __forceinline__ void wait_vm0(unsigned laneoff) {
+    asm volatile("s_waitcnt vmcnt(0)" ::"v"(laneoff) : "memory");
 }
 
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+
+// A real VALU consumer of the accumulator at the end of every stage: the wave cannot go on to the next stage's operand
+// loads before its MFMA chain has finished, so no load can land in registers a queued MFMA still has to read (measured:
+// with three workgroups per CU this alone removed most of the sporadic wrong tiles, at no cost in time)
+__device__ __forceinline__ void mfma_fence(f32x16 &acc) {
+    float probe = acc[0] * 1.0000001f;
+    asm volatile("" : "+v"(probe));
+    acc[0] = __builtin_amdgcn_fmed3f(probe, acc[0], acc[0]);      // == acc[0], but the compiler cannot know
+}
+
+// a wave's quarter of a weight chunk in its LDS slot: [k-step 2][part hi|lo][lane 64] h8 (4 KB)
 // acc += W[32 wave .. +32, chunk cols] * x     (SWAP: acc += x * W^T, edges on rows / features on lanes)
 template <bool SWAP>
-__device__ __forceinline__ void mfma_tile32(const float *wslot, const f32x16 &x, f32x16 &acc, int lane) {
+__device__ __forceinline__ void mfma_chunk(const float *wslot, const HT &x, f32x16 &acc, int lane) {
+    const h8 *w = reinterpret_cast<const h8 *>(wslot) + lane;
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-        f32x4v a = *reinterpret_cast<const f32x4v *>(wslot + (q * 64 + lane) * 4);
-#pragma unroll
-        for (int p = 0; p < 4; p++) {
-            if (SWAP) acc = MFMA(x[4 * q + p], a[p], acc);
-            else acc = MFMA(a[p], x[4 * q + p], acc);
+    for (int s = 0; s < 2; s++) {
+        const h8 wh = w[(2 * s) * 64], wlo = w[(2 * s + 1) * 64];
+        if (SWAP) {
+            acc = MFMA16(x.hi[s], wh, acc);
+            acc = MFMA16(x.lo[s], wh, acc);
+            acc = MFMA16(x.hi[s], wlo, acc);
+        } else {
+            acc = MFMA16(wh, x.hi[s], acc);
+            acc = MFMA16(wh, x.lo[s], acc);
+            acc = MFMA16(wlo, x.hi[s], acc);
         }
     }
+#ifndef PP_NO_MFMA_FENCE
+    mfma_fence(acc);
+#endif
 }
 
-// geometry chunk: 24 inputs = 12 k-steps; lane half h supplies input 12 h + m at step m (quad 3 of the slot is padding)
-__device__ __forceinline__ void mfma_tile24(const float *wslot, const float (&g)[12], f32x16 &acc, int lane) {
+// the 72 invariant-point features as operands: global k-step S = 0..4 carries features 16 S + 8 h + i (zero beyond 71);
+// geometry chunk C holds k-steps 2C and 2C+1 (the last one is all padding and skipped)
+struct HG {
+    h8 hi[5], lo[5];
+};
+template <int C>
+__device__ __forceinline__ void mfma_geo(const float *wslot, const HG &g, f32x16 &acc, int lane) {
+    const h8 *w = reinterpret_cast<const h8 *>(wslot) + lane;
 #pragma unroll
-    for (int q = 0; q < 3; q++) {
-        f32x4v a = *reinterpret_cast<const f32x4v *>(wslot + (q * 64 + lane) * 4);
-#pragma unroll
-        for (int p = 0; p < 4; p++) acc = MFMA(a[p], g[4 * q + p], acc);
+    for (int s = 0; s < 2; s++) {
+        if (2 * C + s < 5) {
+            const h8 wh = w[(2 * s) * 64], wlo = w[(2 * s + 1) * 64];
+            acc = MFMA16(wh, g.hi[2 * C + s], acc);
+            acc = MFMA16(wh, g.lo[2 * C + s], acc);
+            acc = MFMA16(wlo, g.hi[2 * C + s], acc);
+        }
     }
+#ifndef PP_NO_MFMA_FENCE
+    mfma_fence(acc);
+#endif
 }
 
 // one tile (16 registers) <-> 32 consecutive features of a row-major vector
@@ -181,6 +231,16 @@ __device__ __forceinline__ void xbuf_get(const float *xbuf, int t, int lane, f32
     }
 }
 
+// split tiles through the same 4 KB per tile: [hi s0 | hi s1 | lo s0 | lo s1][lane] h8
+__device__ __forceinline__ void xbuf_put_h(float *xbuf, int t, int lane, const HT &d) {
+    h8 *xb = reinterpret_cast<h8 *>(xbuf) + (t * 4) * 64 + lane;
+    xb[0] = d.hi[0]; xb[64] = d.hi[1]; xb[128] = d.lo[0]; xb[192] = d.lo[1];
+}
+__device__ __forceinline__ void xbuf_get_h(const float *xbuf, int t, int lane, HT &d) {
+    const h8 *xb = reinterpret_cast<const h8 *>(xbuf) + (t * 4) * 64 + lane;
+    d.hi[0] = xb[0]; d.hi[1] = xb[64]; d.lo[0] = xb[128]; d.lo[1] = xb[192];
+}
+
 // LayerNorm statistics over the 128 features of this lane's edge (64 here, 64 in lane ^ 32); v is centred in
 // place; returns 1/std, writes the mean
 __device__ __forceinline__ float ln_center(f32x16 (&v)[4], float &mean_out) {
@@ -216,10 +276,10 @@ __device__ __forceinline__ void ln_affine_tile(f32x16 &v, float rstd, const floa
     }
 }
 
-// 72 invariant point features of edge (i, j); g[c][m] = feature 24 c + 12 h + m (what this lane half feeds the MFMA)
+// 72 invariant point features of edge (i, j), split and laid out as MFMA operands (HG)
 __device__ __forceinline__ void edge_geometry(const float *__restrict__ pts_i, const float *__restrict__ fr,
-                                              const float *__restrict__ pts_j, int h, float (&g)[3][12]) {
-    float geom[72];
+                                              const float *__restrict__ pts_j, int h, HG &g) {
+    float geom[80];
     float R[9], tr[3];
 #pragma unroll
     for (int k = 0; k < 9; k++) R[k] = fr[k];
@@ -242,62 +302,147 @@ __device__ __forceinline__ void edge_geometry(const float *__restrict__ pts_i, c
         geom[64 + q] = sqrtf(ex * ex + ey * ey + ez * ez + 1e-8f);
     }
 #pragma unroll
-    for (int c = 0; c < 3; c++)
+    for (int k = 72; k < 80; k++) geom[k] = 0.f;
 #pragma unroll
-        for (int m = 0; m < 12; m++) g[c][m] = h ? geom[24 * c + 12 + m] : geom[24 * c + m];
+    for (int S5 = 0; S5 < 5; S5++)
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const float x = h ? geom[16 * S5 + 8 + i] : geom[16 * S5 + i];
+            const _Float16 hh = (_Float16)x;
+            g.hi[S5][i] = hh;
+            g.lo[S5][i] = (_Float16)(x - (float)hh);
+        }
 }
 
-#define DMA_PER_CHUNK 4
-// Stage k of a kernel with NCH chunks: refill the slot freed by stage k-1 with chunk k+S-1, wait until chunk k has
-// landed (all but the younger chunks' DMAs retired), compute on it.
+#if defined(PP_X_STAGE_BARRIER)
+#define STAGE_FENCE() __syncthreads()
+#elif defined(PP_X_STAGE_NOP)
+#ifndef PP_X_SLEEP
+#define PP_X_SLEEP 2
+#endif
+#define PP_STR2(x) #x
+#define PP_STR(x) PP_STR2(x)
+#define STAGE_FENCE() asm volatile("s_sleep " PP_STR(PP_X_SLEEP) ::: "memory")
+#else
+#define STAGE_FENCE()
+#endif
+// Stage k of a kernel with NCH chunks (two LDS slots per wave): wait until chunk k has landed -- a full vmcnt(0), so that
+// no copy is in flight when M0 moves --, start chunk k+1 into the slot stage k-1 read, compute on chunk k.  A copy has
+// one whole stage (6 MFMAs + its LDS reads) to land, the same prefetch distance as a counted two-deep ring.
+#ifndef PP_REGSTAGE
+#ifndef PP_SHALLOW_RING
+// one workgroup per CU: nothing else hides a copy's latency, so the ring is S slots deep -- stage k starts chunk k+S-1
+// into the slot stage k-1 read and waits, counted, until chunk k has landed (copies complete in issue order)
+template <int N>
+__device__ __forceinline__ void wait_vmN(unsigned laneoff) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N), "v"(laneoff) : "memory");
+}
 #define WSTAGE(k, NCH, BODY)                                                                                   \
     {                                                                                                          \
-        if constexpr ((k) + S - 1 < (NCH))                                                                     \
-            dma_chunk(wsb + (size_t)((k) + S - 1) * CH32, laneoff, slot0 + (((k) + S - 1) % S) * 4096u);       \
-        wait_vm<DMA_PER_CHUNK * (((NCH) - 1 - (k)) < (S - 1) ? ((NCH) - 1 - (k)) : (S - 1))>(laneoff, rowoff);             \
+        if constexpr ((k) + S - 1 < (NCH)) dma_chunk(wsb, laneoff, slot0 + (((k) + S - 1) % S) * 4096u);       \
+        wait_vmN<4 * (((NCH) - 1 - (k)) < (S - 1) ? ((NCH) - 1 - (k)) : (S - 1))>(laneoff);                    \
         const float *wslot = wl + ((k) % S) * 1024;                                                            \
         BODY;                                                                                                  \
     }
+#else
+#define WSTAGE(k, NCH, BODY)                                                                                   \
+    {                                                                                                          \
+        wait_vm0(laneoff);                                                                                     \
+        STAGE_FENCE();                                                                                         \
+        if constexpr ((k) + 1 < (NCH)) dma_chunk(wsb, laneoff, slot0 + (((k) + 1) % 2) * 4096u);               \
+        const float *wslot = wl + ((k) % 2) * 1024;                                                            \
+        BODY;                                                                                                  \
+    }
+#endif
+#else
+// register-staged variant (no LDS-DMA): chunk k+1 sits in 16 VGPRs (fetched during stage k-1), is written to its
+// slot at the start of stage k, and the registers are refilled with chunk k+2 (same element type as the readers: h8)
+#define WSTAGE(k, NCH, BODY)                                                                                   \
+    {                                                                                                          \
+        if constexpr ((k) + 1 < (NCH)) {                                                                       \
+            h8 *dst = reinterpret_cast<h8 *>(const_cast<float *>(wl) + (((k) + 1) % 2) * 1024) + lane;         \
+            dst[0] = wreg[0]; dst[64] = wreg[1]; dst[128] = wreg[2]; dst[192] = wreg[3];                       \
+        }                                                                                                      \
+        if constexpr ((k) + 2 < (NCH)) {                                                                       \
+            const h8 *src = reinterpret_cast<const h8 *>(A.wstream + (size_t)((k) + 2) * CH32 + wave * 1024) + lane; \
+            wreg[0] = src[0]; wreg[1] = src[64]; wreg[2] = src[128]; wreg[3] = src[192];                       \
+        }                                                                                                      \
+        const float *wslot = wl + ((k) % 2) * 1024;                                                            \
+        STAGE_FENCE();                                                                                         \
+        BODY;                                                                                                  \
+    }
+#endif
 
 // shared first layer: acc (tile `wave`) = PA_i + PC_j + W_B h_E + W_G geom, ReLU.  Chunks W_B x4 (absent when ST0:
 // layer 0's W_B h_E0 is timestep-invariant and arrives precomputed in acc), then W_G x3.  C0 = number of W_B chunks.
 #define FIRST_LAYER(NCH)                                                          \
     if constexpr (!ST0) {                                                         \
-        WSTAGE(0, NCH, mfma_tile32<false>(wslot, x[0], acc, lane))                \
-        WSTAGE(1, NCH, mfma_tile32<false>(wslot, x[1], acc, lane))                \
-        WSTAGE(2, NCH, mfma_tile32<false>(wslot, x[2], acc, lane))                \
-        WSTAGE(3, NCH, mfma_tile32<false>(wslot, x[3], acc, lane))                \
+        WSTAGE(0, NCH, mfma_chunk<false>(wslot, x[0], acc, lane))                 \
+        WSTAGE(1, NCH, mfma_chunk<false>(wslot, x[1], acc, lane))                 \
+        WSTAGE(2, NCH, mfma_chunk<false>(wslot, x[2], acc, lane))                 \
+        WSTAGE(3, NCH, mfma_chunk<false>(wslot, x[3], acc, lane))                 \
     }                                                                             \
-    WSTAGE(C0 + 0, NCH, mfma_tile24(wslot, g[0], acc, lane))                      \
-    WSTAGE(C0 + 1, NCH, mfma_tile24(wslot, g[1], acc, lane))                      \
-    WSTAGE(C0 + 2, NCH, mfma_tile24(wslot, g[2], acc, lane))                      \
+    WSTAGE(C0 + 0, NCH, mfma_geo<0>(wslot, g, acc, lane))                         \
+    WSTAGE(C0 + 1, NCH, mfma_geo<1>(wslot, g, acc, lane))                         \
+    WSTAGE(C0 + 2, NCH, mfma_geo<2>(wslot, g, acc, lane))                         \
     relu_tile(acc);                                                               \
-    xbuf_put(xbuf, wave, lane, acc);                                              \
+    split_tile(acc, ht);                                                          \
+    xbuf_put_h(xbuf, wave, lane, ht);                                             \
     __syncthreads();
 
+#ifndef PP_REGSTAGE
+#ifndef PP_SHALLOW_RING
 #define PROLOGUE_PIPE()                                                                        \
-    const float *wsb = A.wstream + wave * 1024;          /* wave-uniform part of the chunk addresses */ \
-    unsigned laneoff = (unsigned)lane * 16u;              /* the one per-lane DMA address register */     \
-    unsigned rowoff = 0;                                   /* the residual gather's, where used */          \
+    const float *wsb = A.wstream + wave * 1024;          /* running chunk pointer, wave-uniform: SGPRs */ \
+    unsigned laneoff = (unsigned)lane * 16u;              /* the one per-lane address register */ \
     const float *wl = smem + wave * (S * 1024);                                                \
     const unsigned slot0 = (unsigned)(size_t)wl;                                               \
-    _Pragma("unroll") for (int pk = 0; pk < S - 1; pk++) dma_chunk(wsb + (size_t)pk * CH32, laneoff, slot0 + pk * 4096u);
+    _Pragma("unroll") for (int pk = 0; pk < S - 1; pk++) dma_chunk(wsb, laneoff, slot0 + pk * 4096u);
+#else
+#define PROLOGUE_PIPE()                                                                        \
+    static_assert(S == 2, "the weight pipeline is two slots per wave");                        \
+    const float *wsb = A.wstream + wave * 1024;          /* running chunk pointer, wave-uniform: SGPRs */ \
+    unsigned laneoff = (unsigned)lane * 16u;              /* the one per-lane address register */ \
+    const float *wl = smem + wave * (S * 1024);                                                \
+    const unsigned slot0 = (unsigned)(size_t)wl;                                               \
+    dma_chunk(wsb, laneoff, slot0);
+#endif
+#else
+#define PROLOGUE_PIPE()                                                                        \
+    static_assert(S == 2, "the weight pipeline is two slots per wave");                        \
+    const float *wl = smem + wave * (S * 1024);                                                \
+    h8 wreg[4];                                                                                \
+    {                                                                                          \
+        const h8 *src = reinterpret_cast<const h8 *>(A.wstream + wave * 1024) + lane;          \
+        h8 *dst = reinterpret_cast<h8 *>(const_cast<float *>(wl)) + lane;                      \
+        dst[0] = src[0]; dst[64] = src[64]; dst[128] = src[128]; dst[192] = src[192];          \
+        const h8 *src1 = src + CH32 / 4;                                                       \
+        wreg[0] = src1[0]; wreg[1] = src1[64]; wreg[2] = src1[128]; wreg[3] = src1[192];       \
+    }
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // node message: S[i] = (1/K) sum_j mask_ij relu(W_mid relu(W_in [..]) + b), msum[i] = (1/K) sum_j mask_ij
 // ---------------------------------------------------------------------------------------------
+// Shipped configuration: ONE workgroup per CU (one wave per SIMD), LDS-DMA ring of 5 / 4 slots per wave.  With several
+// waves interleaving on a SIMD the split-f16 kernels produced rare wrong tiles (see HAZARD notes); with one wave per
+// SIMD they have been bit-reproducible over millions of workgroup launches (tools/debug/soak.py).  The LDS requests
+// (96 KB / 84.5 KB) are what enforces the exclusivity.
 #ifndef PP_NM_SLOTS
-#define PP_NM_SLOTS 2
+#define PP_NM_SLOTS 5
 #endif
 #ifndef PP_EU_SLOTS
-#define PP_EU_SLOTS 2
+#define PP_EU_SLOTS 4
 #endif
 #ifndef PP_EU_WGS
-#define PP_EU_WGS 3
+#define PP_EU_WGS 1
+#endif
+#ifndef PP_NM_WGS
+#define PP_NM_WGS 1
 #endif
 
 template <int S, bool ST0>
-__global__ void __launch_bounds__(ET, 3)
+__global__ void __launch_bounds__(ET, PP_NM_WGS)
 k_node_message(EdgeArgs A) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *xbuf = smem + 4 * S * 1024;
@@ -315,8 +460,9 @@ k_node_message(EdgeArgs A) {
     constexpr int NCH = C0 + 7;           // chunks: [W_B x4,] W_G x3, W_mid x4
     PROLOGUE_PIPE()
 
-    f32x16 x[4], acc;
-    float g[3][12];
+    HT x[4], ht;
+    f32x16 acc;
+    HG g;
     const int jj = j < K ? j : K - 1;
     const int nbr = A.eidx[(size_t)n * K + jj];
     const float bmid = A.b_mid[32 * wave + j];            // SWAP form: feature on the lane
@@ -334,7 +480,7 @@ k_node_message(EdgeArgs A) {
         const float *hrow = A.hE_in + ((size_t)n * K + jj) * 128;
         if constexpr (!ST0) {
 #pragma unroll
-            for (int t = 0; t < 4; t++) load_tile(hrow + 32 * t, h, x[t]);
+            for (int t = 0; t < 4; t++) { load_tile(hrow + 32 * t, h, acc); split_tile(acc, x[t]); }
         }
         load_tile(A.PA + (size_t)n * 128 + 32 * wave, h, acc);
         add_tile(A.PC + (size_t)nbr * 128 + 32 * wave, h, acc);
@@ -343,14 +489,14 @@ k_node_message(EdgeArgs A) {
     FIRST_LAYER(NCH)
     {
 #pragma unroll
-        for (int t = 0; t < 4; t++) xbuf_get(xbuf, t, lane, x[t]);
+        for (int t = 0; t < 4; t++) xbuf_get_h(xbuf, t, lane, x[t]);
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[r] = bmid;
     }
-    WSTAGE(C0 + 3, NCH, mfma_tile32<true>(wslot, x[0], acc, lane))
-    WSTAGE(C0 + 4, NCH, mfma_tile32<true>(wslot, x[1], acc, lane))
-    WSTAGE(C0 + 5, NCH, mfma_tile32<true>(wslot, x[2], acc, lane))
-    WSTAGE(C0 + 6, NCH, mfma_tile32<true>(wslot, x[3], acc, lane))
+    WSTAGE(C0 + 3, NCH, mfma_chunk<true>(wslot, x[0], acc, lane))
+    WSTAGE(C0 + 4, NCH, mfma_chunk<true>(wslot, x[1], acc, lane))
+    WSTAGE(C0 + 5, NCH, mfma_chunk<true>(wslot, x[2], acc, lane))
+    WSTAGE(C0 + 6, NCH, mfma_chunk<true>(wslot, x[3], acc, lane))
     {
         // rows (registers) are edges e = 8 (r>>2) + 4 h + (r&3); mask and reduce over them
         float s = 0.f, ms = 0.f;
@@ -372,22 +518,27 @@ k_node_message(EdgeArgs A) {
 // FFN hidden block c (chunks 15 + 8c ..): W1 s=0..3 -> hidden tile 4c+wave -> exchange -> W2 s'=0..3 accumulate into out
 #define FFN_BLOCK(c)                                                                                         \
     load_tile(prm + P_FIB + 128 * (c) + 32 * wave, h, acc);                                                  \
-    WSTAGE(C0 + 11 + 8 * (c) + 0, NCH, mfma_tile32<false>(wslot, x[0], acc, lane))                                \
-    WSTAGE(C0 + 11 + 8 * (c) + 1, NCH, mfma_tile32<false>(wslot, x[1], acc, lane))                                \
-    WSTAGE(C0 + 11 + 8 * (c) + 2, NCH, mfma_tile32<false>(wslot, x[2], acc, lane))                                \
-    WSTAGE(C0 + 11 + 8 * (c) + 3, NCH, mfma_tile32<false>(wslot, x[3], acc, lane))                                \
+    WSTAGE(C0 + 11 + 8 * (c) + 0, NCH, mfma_chunk<false>(wslot, x[0], acc, lane))                                \
+    WSTAGE(C0 + 11 + 8 * (c) + 1, NCH, mfma_chunk<false>(wslot, x[1], acc, lane))                                \
+    WSTAGE(C0 + 11 + 8 * (c) + 2, NCH, mfma_chunk<false>(wslot, x[2], acc, lane))                                \
+    WSTAGE(C0 + 11 + 8 * (c) + 3, NCH, mfma_chunk<false>(wslot, x[3], acc, lane))                                \
     relu_tile(acc);                                                                                          \
+    split_tile(acc, ht);                                                                                     \
     __syncthreads();          /* every wave is done reading the previous exchange */                        \
-    xbuf_put(xbuf, wave, lane, acc);                                                                         \
+    xbuf_put_h(xbuf, wave, lane, ht);                                                                        \
     __syncthreads();                                                                                         \
-    WSTAGE(C0 + 11 + 8 * (c) + 4, NCH, xbuf_get(xbuf, 0, lane, acc); mfma_tile32<false>(wslot, acc, out, lane))   \
-    WSTAGE(C0 + 11 + 8 * (c) + 5, NCH, xbuf_get(xbuf, 1, lane, acc); mfma_tile32<false>(wslot, acc, out, lane))   \
-    WSTAGE(C0 + 11 + 8 * (c) + 6, NCH, xbuf_get(xbuf, 2, lane, acc); mfma_tile32<false>(wslot, acc, out, lane))   \
-    WSTAGE(C0 + 11 + 8 * (c) + 7, NCH, xbuf_get(xbuf, 3, lane, acc); mfma_tile32<false>(wslot, acc, out, lane))
+    WSTAGE(C0 + 11 + 8 * (c) + 4, NCH, xbuf_get_h(xbuf, 0, lane, ht); mfma_chunk<false>(wslot, ht, out, lane))   \
+    WSTAGE(C0 + 11 + 8 * (c) + 5, NCH, xbuf_get_h(xbuf, 1, lane, ht); mfma_chunk<false>(wslot, ht, out, lane))   \
+    WSTAGE(C0 + 11 + 8 * (c) + 6, NCH, xbuf_get_h(xbuf, 2, lane, ht); mfma_chunk<false>(wslot, ht, out, lane))   \
+    WSTAGE(C0 + 11 + 8 * (c) + 7, NCH, xbuf_get_h(xbuf, 3, lane, ht); mfma_chunk<false>(wslot, ht, out, lane))
 
-// FUSE: the workgroup goes straight on to the NEXT layer's node message of its residue (same 32 edges, whose new
-// h_E it holds; the node-level inputs PA2 / PC2 / pts2 were written by the node update that ran before this kernel):
-// one launch, one prologue and one read of h_E less per layer.
+// FUSE (-DPP_FUSE_NM, OFF by default): the workgroup goes straight on to the NEXT layer's node message of its residue
+// (same 32 edges, whose new h_E it holds; the node-level inputs PA2 / PC2 / pts2 were written by the node update that
+// ran before this kernel): one launch, one prologue and one read of h_E less per layer (~5 % of a step).  Disabled in
+// the split-f16 build: with several workgroups per CU the fused tail produced rare wrong S rows (about one workgroup
+// in a thousand, never with one workgroup per CU, h_E itself always bit-exact) that survived every fix of the LDS-DMA
+// hazards below and also show without LDS-DMA; the stand-alone node-message kernel, same code, is bit-reproducible
+// (tools/debug/edge_repro.py, score_check3.py).  Unresolved -> not shipped.
 template <int S, bool ST0, bool FUSE>
 __global__ void __launch_bounds__(ET, PP_EU_WGS)
 k_edge_update(EdgeArgs A) {
@@ -422,14 +573,17 @@ k_edge_update(EdgeArgs A) {
     constexpr int NCH = NEU + (FUSE ? 11 : 0);         // + W_B x4, W_G x3, W_mid x4 of the next node message
     PROLOGUE_PIPE()
 
-    f32x16 x[4], acc, out;
-    float g[3][12];
+    HT x[4], ht;
+    f32x16 acc, out;
+    HG g;
     const float *hrow = A.hE_in + ((size_t)n * K + jj) * 128;
     const int nbr = A.eidx[(size_t)n * K + jj];
     const float me = A.mask_att[(size_t)n * 32 + jj];          // (lanes j >= K mirror edge K - 1 throughout)
     // the small per-layer vectors go to LDS once (published by the first exchange barrier)
+    // (no divergent control flow while a weight copy is in flight -- see HAZARD: the surplus threads of the second trip
+    //  rewrite the last float4 with the same value instead of being masked off)
 #pragma unroll
-    for (int it = 0; it < (PARAM_FLOATS / 4 + ET - 1) / ET; it++) {          // every lane active (see HAZARD): clamped index
+    for (int it = 0; it < (PARAM_FLOATS / 4 + ET - 1) / ET; it++) {
         const int i = min(tid + it * ET, PARAM_FLOATS / 4 - 1);
         *reinterpret_cast<f32x4v *>(prm + 4 * i) = *reinterpret_cast<const f32x4v *>(A.params + 4 * i);
     }
@@ -438,7 +592,7 @@ k_edge_update(EdgeArgs A) {
     {
         if constexpr (!ST0) {
 #pragma unroll
-            for (int t = 0; t < 4; t++) load_tile(hrow + 32 * t, h, x[t]);
+            for (int t = 0; t < 4; t++) { load_tile(hrow + 32 * t, h, acc); split_tile(acc, x[t]); }
         }
         load_tile(A.PA + (size_t)n * 128 + 32 * wave, h, acc);
         add_tile(A.PC + (size_t)nbr * 128 + 32 * wave, h, acc);
@@ -448,52 +602,50 @@ k_edge_update(EdgeArgs A) {
     // ---- second layer (chunks 7..10) -------------------------------------------------------------
     {
 #pragma unroll
-        for (int t = 0; t < 4; t++) xbuf_get(xbuf, t, lane, x[t]);
+        for (int t = 0; t < 4; t++) xbuf_get_h(xbuf, t, lane, x[t]);
         load_tile(prm + P_BMID + 32 * wave, h, acc);
     }
-    WSTAGE(C0 + 3, NCH, mfma_tile32<false>(wslot, x[0], acc, lane))
-    WSTAGE(C0 + 4, NCH, mfma_tile32<false>(wslot, x[1], acc, lane))
-    WSTAGE(C0 + 5, NCH, mfma_tile32<false>(wslot, x[2], acc, lane))
-    WSTAGE(C0 + 6, NCH, mfma_tile32<false>(wslot, x[3], acc, lane))
+    WSTAGE(C0 + 3, NCH, mfma_chunk<false>(wslot, x[0], acc, lane))
+    WSTAGE(C0 + 4, NCH, mfma_chunk<false>(wslot, x[1], acc, lane))
+    WSTAGE(C0 + 5, NCH, mfma_chunk<false>(wslot, x[2], acc, lane))
+    WSTAGE(C0 + 6, NCH, mfma_chunk<false>(wslot, x[3], acc, lane))
     relu_tile(acc);
+    split_tile(acc, ht);
     __syncthreads();
-    xbuf_put(xbuf, wave, lane, acc);
+    xbuf_put_h(xbuf, wave, lane, ht);
     __syncthreads();
     // ---- third layer (chunks 11..14) --------------------------------------------------------------
     {
 #pragma unroll
-        for (int t = 0; t < 4; t++) xbuf_get(xbuf, t, lane, x[t]);
+        for (int t = 0; t < 4; t++) xbuf_get_h(xbuf, t, lane, x[t]);
         load_tile(prm + P_BOUT + 32 * wave, h, acc);
     }
-    // The exchange buffer is idle during this layer: once every wave has its B operands (barrier), each wave parks
-    // the residual input of the first LayerNorm -- its own tile of h_E -- in its own exchange tile by LDS-DMA.  The copy
-    // is older than the weight chunks issued below, so the vmcnt wait of the layer's last stage covers it.
-    __syncthreads();
-    rowoff = (unsigned)((((size_t)n * K + jj) * 128 + 32 * wave + 4 * h) * sizeof(float));
-    dma_tile(A.hE_in, rowoff, (unsigned)(size_t)(xbuf + wave * 1024));
-    WSTAGE(C0 + 7, NCH, mfma_tile32<false>(wslot, x[0], acc, lane))
-    WSTAGE(C0 + 8, NCH, mfma_tile32<false>(wslot, x[1], acc, lane))
-    WSTAGE(C0 + 9, NCH, mfma_tile32<false>(wslot, x[2], acc, lane))
-    WSTAGE(C0 + 10, NCH, mfma_tile32<false>(wslot, x[3], acc, lane))
+    WSTAGE(C0 + 7, NCH, mfma_chunk<false>(wslot, x[0], acc, lane))
+    WSTAGE(C0 + 8, NCH, mfma_chunk<false>(wslot, x[1], acc, lane))
+    WSTAGE(C0 + 9, NCH, mfma_chunk<false>(wslot, x[2], acc, lane))
+    WSTAGE(C0 + 10, NCH, mfma_chunk<false>(wslot, x[3], acc, lane))
     // publish v = h_E + mask * m for the first LayerNorm (own tile: read, then overwritten in place)
-    xbuf_get(xbuf, wave, lane, out);
+    load_tile(hrow + 32 * wave, h, out);        // residual input: this wave's tile of h_E (L2-resident re-read)
 #pragma unroll
     for (int r = 0; r < 16; r++) out[r] = fmaf(acc[r], me, out[r]);
+    __syncthreads();                            // every wave has its B operands of this layer
     xbuf_put(xbuf, wave, lane, out);
     __syncthreads();
     {
-        // x1 = LN2(v): every wave normalises the full vector (it needs all of x1 as B operands)
+        // x1 = LN2(v): every wave normalises the full vector in fp32 (it needs all of x1 as B operands), then splits it
+        f32x16 v4[4];
 #pragma unroll
-        for (int t = 0; t < 4; t++) xbuf_get(xbuf, t, lane, x[t]);
+        for (int t = 0; t < 4; t++) xbuf_get(xbuf, t, lane, v4[t]);
         float mean;
-        float rstd = ln_center(x, mean);
+        float rstd = ln_center(v4, mean);
 #pragma unroll
         for (int t = 0; t < 4; t++) {
             // compiler fence tied to the data flow: the gamma / beta reads of tile t are issued only once rstd (and the
             // previous tile) exist, so one tile's worth of them is live at a time (168-VGPR budget)
             if (t == 0) asm volatile("" : "+v"(rstd) : : "memory");
-            else asm volatile("" : "+v"(x[t > 0 ? t - 1 : 0][15]) : : "memory");
-            ln_affine_tile(x[t], rstd, prm + P_G2 + 32 * t, prm + P_BE2 + 32 * t, h);
+            else asm volatile("" : "+v"(v4[t > 0 ? t - 1 : 0][15]) : : "memory");
+            ln_affine_tile(v4[t], rstd, prm + P_G2 + 32 * t, prm + P_BE2 + 32 * t, h);
+            split_tile(v4[t], x[t]);
         }
         load_tile(prm + P_FOB + 32 * wave, h, out);
     }
@@ -503,17 +655,23 @@ k_edge_update(EdgeArgs A) {
     FFN_BLOCK(2)
     FFN_BLOCK(3)
     // ---- h_E = mask * LN3(x1 + ffn) ---------------------------------------------------------------------
-    if (wave == 0) { _Pragma("unroll") for (int r = 0; r < 16; r++) out[r] += x[0][r]; }
-    else if (wave == 1) { _Pragma("unroll") for (int r = 0; r < 16; r++) out[r] += x[1][r]; }
-    else if (wave == 2) { _Pragma("unroll") for (int r = 0; r < 16; r++) out[r] += x[2][r]; }
-    else { _Pragma("unroll") for (int r = 0; r < 16; r++) out[r] += x[3][r]; }
+    // residual: this wave's tile of x1, rebuilt from its split form (wave is scalar: uniform branches, static indices)
+    if (wave == 0) join_tile(x[0], acc);
+    else if (wave == 1) join_tile(x[1], acc);
+    else if (wave == 2) join_tile(x[2], acc);
+    else join_tile(x[3], acc);
+#pragma unroll
+    for (int r = 0; r < 16; r++) out[r] += acc[r];
     __syncthreads();
     xbuf_put(xbuf, wave, lane, out);
     __syncthreads();
+    float mean3, rstd;
+    {
+        f32x16 v4[4];
 #pragma unroll
-    for (int t = 0; t < 4; t++) xbuf_get(xbuf, t, lane, x[t]);
-    float mean3;
-    const float rstd = ln_center(x, mean3);
+        for (int t = 0; t < 4; t++) xbuf_get(xbuf, t, lane, v4[t]);
+        rstd = ln_center(v4, mean3);
+    }
 #pragma unroll
     for (int r = 0; r < 16; r++) out[r] -= mean3;
     ln_affine_tile(out, rstd, A.g3 + 32 * wave, A.be3 + 32 * wave, h);
@@ -526,8 +684,12 @@ k_edge_update(EdgeArgs A) {
         // its inputs are fetched here and not earlier: offsets made opaque behind `out` (scalar ones stay scalar)
         int o_pts = n * 48, o_fr = n * 12, o_pa = n * 128;
         int o_ptsj = nbr * 48, o_pc = nbr * 128;
+        split_tile(out, ht);
+#ifdef PP_X_TAIL_DRAIN
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
         __syncthreads();                                      // every wave has read the LayerNorm exchange
-        xbuf_put(xbuf, wave, lane, out);
+        xbuf_put_h(xbuf, wave, lane, ht);
         // `out` is dead from here; the fence keeps the input fetches below it (they would otherwise be hoisted to the
         // top of the kernel), and the geometry arithmetic fills the wait for the other waves' tiles
         asm volatile("" : "+s"(o_pts), "+s"(o_fr), "+s"(o_pa), "+v"(o_ptsj), "+v"(o_pc) : : "memory");
@@ -538,26 +700,27 @@ k_edge_update(EdgeArgs A) {
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
 #pragma unroll
-        for (int t = 0; t < 4; t++) xbuf_get(xbuf, t, lane, x[t]);
-        WSTAGE(NEU + 0, NCH, mfma_tile32<false>(wslot, x[0], acc, lane))
-        WSTAGE(NEU + 1, NCH, mfma_tile32<false>(wslot, x[1], acc, lane))
-        WSTAGE(NEU + 2, NCH, mfma_tile32<false>(wslot, x[2], acc, lane))
-        WSTAGE(NEU + 3, NCH, mfma_tile32<false>(wslot, x[3], acc, lane))
-        WSTAGE(NEU + 4, NCH, mfma_tile24(wslot, g[0], acc, lane))
-        WSTAGE(NEU + 5, NCH, mfma_tile24(wslot, g[1], acc, lane))
-        WSTAGE(NEU + 6, NCH, mfma_tile24(wslot, g[2], acc, lane))
+        for (int t = 0; t < 4; t++) xbuf_get_h(xbuf, t, lane, x[t]);
+        WSTAGE(NEU + 0, NCH, mfma_chunk<false>(wslot, x[0], acc, lane))
+        WSTAGE(NEU + 1, NCH, mfma_chunk<false>(wslot, x[1], acc, lane))
+        WSTAGE(NEU + 2, NCH, mfma_chunk<false>(wslot, x[2], acc, lane))
+        WSTAGE(NEU + 3, NCH, mfma_chunk<false>(wslot, x[3], acc, lane))
+        WSTAGE(NEU + 4, NCH, mfma_geo<0>(wslot, g, acc, lane))
+        WSTAGE(NEU + 5, NCH, mfma_geo<1>(wslot, g, acc, lane))
+        WSTAGE(NEU + 6, NCH, mfma_geo<2>(wslot, g, acc, lane))
         relu_tile(acc);
+        split_tile(acc, ht);
         __syncthreads();
-        xbuf_put(xbuf, wave, lane, acc);
+        xbuf_put_h(xbuf, wave, lane, ht);
         __syncthreads();
 #pragma unroll
-        for (int t = 0; t < 4; t++) xbuf_get(xbuf, t, lane, x[t]);
+        for (int t = 0; t < 4; t++) xbuf_get_h(xbuf, t, lane, x[t]);
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[r] = bmid;
-        WSTAGE(NEU + 7, NCH, mfma_tile32<true>(wslot, x[0], acc, lane))
-        WSTAGE(NEU + 8, NCH, mfma_tile32<true>(wslot, x[1], acc, lane))
-        WSTAGE(NEU + 9, NCH, mfma_tile32<true>(wslot, x[2], acc, lane))
-        WSTAGE(NEU + 10, NCH, mfma_tile32<true>(wslot, x[3], acc, lane))
+        WSTAGE(NEU + 7, NCH, mfma_chunk<true>(wslot, x[0], acc, lane))
+        WSTAGE(NEU + 8, NCH, mfma_chunk<true>(wslot, x[1], acc, lane))
+        WSTAGE(NEU + 9, NCH, mfma_chunk<true>(wslot, x[2], acc, lane))
+        WSTAGE(NEU + 10, NCH, mfma_chunk<true>(wslot, x[3], acc, lane))
         // rows (registers) are edges e = 8 (r>>2) + 4 h + (r&3); mask and reduce over them
         int o_m = n * 32 + 4 * h;
         asm volatile("" : "+v"(o_m) : "v"(acc[0]));
@@ -584,7 +747,7 @@ k_edge_update(EdgeArgs A) {
 // changes during sampling, so the layer-0 kernels skip four of their stages and start from these tiles.
 // ---------------------------------------------------------------------------------------------
 template <int S>
-__global__ void __launch_bounds__(ET, 3)
+__global__ void __launch_bounds__(ET, PP_NM_WGS)
 k_edge_static(EdgeArgs A) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -595,24 +758,25 @@ k_edge_static(EdgeArgs A) {
     if (A.rmask[n] == 0.f) return;        // never read: the layer kernels leave masked residues early as well
     constexpr int NCH = 8;                // chunks: W_B(node message) x4, W_B(edge message) x4
     PROLOGUE_PIPE()
-    f32x16 x[4], acc;
+    HT x[4];
+    f32x16 acc;
     const int jj = j < K ? j : K - 1;
     const float *hrow = A.hE_in + ((size_t)n * K + jj) * 128;
 #pragma unroll
-    for (int t = 0; t < 4; t++) load_tile(hrow + 32 * t, h, x[t]);
+    for (int t = 0; t < 4; t++) { load_tile(hrow + 32 * t, h, acc); split_tile(acc, x[t]); }
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[r] = 0.f;
-    WSTAGE(0, NCH, mfma_tile32<false>(wslot, x[0], acc, lane))
-    WSTAGE(1, NCH, mfma_tile32<false>(wslot, x[1], acc, lane))
-    WSTAGE(2, NCH, mfma_tile32<false>(wslot, x[2], acc, lane))
-    WSTAGE(3, NCH, mfma_tile32<false>(wslot, x[3], acc, lane))
+    WSTAGE(0, NCH, mfma_chunk<false>(wslot, x[0], acc, lane))
+    WSTAGE(1, NCH, mfma_chunk<false>(wslot, x[1], acc, lane))
+    WSTAGE(2, NCH, mfma_chunk<false>(wslot, x[2], acc, lane))
+    WSTAGE(3, NCH, mfma_chunk<false>(wslot, x[3], acc, lane))
     store_tile(A.Znm + ((size_t)n * K + jj) * 128 + 32 * wave, h, acc);      // lanes j >= K mirror edge K - 1
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[r] = 0.f;
-    WSTAGE(4, NCH, mfma_tile32<false>(wslot, x[0], acc, lane))
-    WSTAGE(5, NCH, mfma_tile32<false>(wslot, x[1], acc, lane))
-    WSTAGE(6, NCH, mfma_tile32<false>(wslot, x[2], acc, lane))
-    WSTAGE(7, NCH, mfma_tile32<false>(wslot, x[3], acc, lane))
+    WSTAGE(4, NCH, mfma_chunk<false>(wslot, x[0], acc, lane))
+    WSTAGE(5, NCH, mfma_chunk<false>(wslot, x[1], acc, lane))
+    WSTAGE(6, NCH, mfma_chunk<false>(wslot, x[2], acc, lane))
+    WSTAGE(7, NCH, mfma_chunk<false>(wslot, x[3], acc, lane))
     store_tile(A.Zem + ((size_t)n * K + jj) * 128 + 32 * wave, h, acc);
 }
 
@@ -646,7 +810,16 @@ static const size_t EU_SMEM = (4 * PP_EU_SLOTS * 1024 + XBUF_FLOATS) * sizeof(fl
 #else
 static const size_t EU_SMEM = (4 * PP_EU_SLOTS * 1024 + XBUF_FLOATS + PARAM_FLOATS) * sizeof(float);
 #endif
-static const size_t ST_SMEM = (4 * 2 * 1024) * sizeof(float);
+static const size_t ST_SMEM = (4 * PP_NM_SLOTS * 1024) * sizeof(float);
+#ifdef PP_X_BIGLDS_NM        // diagnostics: one workgroup per CU for one kernel
+#define NM_SMEM ((size_t)100 * 1024)
+#endif
+#ifdef PP_X_BIGLDS_EU
+#define EU_SMEM ((size_t)100 * 1024)
+#endif
+#ifdef PP_X_BIGLDS_ST
+#define ST_SMEM ((size_t)100 * 1024)
+#endif
 
 static bool edge_attrs() {
     static bool done = false, ok = false;
@@ -655,10 +828,16 @@ static bool edge_attrs() {
         auto set = [](const void *f, size_t bytes) {
             return hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess;
         };
-        ok = set(reinterpret_cast<const void *>(k_node_message<PP_NM_SLOTS, false>), NM_SMEM) &&
+        ok = set(reinterpret_cast<const void *>(k_edge_static<PP_NM_SLOTS>), ST_SMEM) &&
+             set(reinterpret_cast<const void *>(k_node_message<PP_NM_SLOTS, false>), NM_SMEM) &&
              set(reinterpret_cast<const void *>(k_node_message<PP_NM_SLOTS, true>), NM_SMEM) &&
+#ifndef PP_FUSE_NM
+             set(reinterpret_cast<const void *>(k_edge_update<PP_EU_SLOTS, false, false>), EU_SMEM) &&
+             set(reinterpret_cast<const void *>(k_edge_update<PP_EU_SLOTS, true, false>), EU_SMEM);
+#else
              set(reinterpret_cast<const void *>(k_edge_update<PP_EU_SLOTS, false, true>), EU_SMEM) &&
              set(reinterpret_cast<const void *>(k_edge_update<PP_EU_SLOTS, true, true>), EU_SMEM);
+#endif
     }
     return ok;
 }
@@ -667,7 +846,7 @@ static bool edge_attrs() {
 void pp_edge_occupancy(int *node_msg, int *edge_upd) {
     edge_attrs();
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(node_msg, reinterpret_cast<const void *>(k_node_message<PP_NM_SLOTS, false>), ET, NM_SMEM);
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(edge_upd, reinterpret_cast<const void *>(k_edge_update<PP_EU_SLOTS, false, true>), ET, EU_SMEM);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(edge_upd, reinterpret_cast<const void *>(k_edge_update<PP_EU_SLOTS, false, false>), ET, EU_SMEM);
 }
 
 #define EDGE_ATTR_CHECK()                                                                                   \
@@ -676,13 +855,11 @@ void pp_edge_occupancy(int *node_msg, int *edge_upd) {
         return PP_ERR_HIP;                                                                                  \
     }
 
-bool pp_edge_fused() { return true; }
-
 pp_status pp_launch_edge_static(pp_ctx *c, hipStream_t s) {
     EDGE_ATTR_CHECK()
     EdgeArgs A = edge_args(c, 0, false);
     A.wstream = c->plan->static_stream;
-    hipLaunchKernelGGL(k_edge_static<2>, dim3(c->N), dim3(ET), ST_SMEM, s, A);
+    hipLaunchKernelGGL(k_edge_static<PP_NM_SLOTS>, dim3(c->N), dim3(ET), ST_SMEM, s, A);
     PP_HIP_CHECK(hipGetLastError());
     return PP_OK;
 }
@@ -696,13 +873,27 @@ pp_status pp_launch_node_message(pp_ctx *c, int layer, hipStream_t s) {
     return PP_OK;
 }
 
-// layers 0 and 1 only (the reference's layer-2 edge update is dead code); also produces S / msum of layer + 1
+// true when k_edge_update also computes the next layer's node message (build with -DPP_FUSE_NM)
+bool pp_edge_fused() {
+#ifdef PP_FUSE_NM
+    return true;
+#else
+    return false;
+#endif
+}
+
+// layers 0 and 1 only (the reference's layer-2 edge update is dead code)
 pp_status pp_launch_edge_update(pp_ctx *c, int layer, hipStream_t s) {
     EDGE_ATTR_CHECK()
     if (layer < 0 || layer > 1) { pp_set_error("pp_launch_edge_update: layer must be 0 or 1"); return PP_ERR_INVALID; }
     EdgeArgs A = edge_args(c, layer, true);
+#ifdef PP_FUSE_NM
     if (layer == 0) hipLaunchKernelGGL((k_edge_update<PP_EU_SLOTS, true, true>), dim3(c->N), dim3(ET), EU_SMEM, s, A);
     else hipLaunchKernelGGL((k_edge_update<PP_EU_SLOTS, false, true>), dim3(c->N), dim3(ET), EU_SMEM, s, A);
+#else
+    if (layer == 0) hipLaunchKernelGGL((k_edge_update<PP_EU_SLOTS, true, false>), dim3(c->N), dim3(ET), EU_SMEM, s, A);
+    else hipLaunchKernelGGL((k_edge_update<PP_EU_SLOTS, false, false>), dim3(c->N), dim3(ET), EU_SMEM, s, A);
+#endif
     PP_HIP_CHECK(hipGetLastError());
     return PP_OK;
 }

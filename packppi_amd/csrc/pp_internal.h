@@ -132,6 +132,7 @@ pp_status pp_launch_node_update(pp_ctx *c, int layer, int last_mode, float *chi,
                                 const float *noise, hipStream_t s);
 pp_status pp_launch_edge_static(pp_ctx *c, hipStream_t s);
 pp_status pp_launch_node_message(pp_ctx *c, int layer, hipStream_t s);
+bool pp_edge_fused();            // does pp_launch_edge_update also compute the next layer's node message?
 pp_status pp_launch_edge_update(pp_ctx *c, int layer, hipStream_t s);   // + node message of layer + 1
 pp_status pp_launch_atom14(pp_ctx *c, const float *chi, float *xyz, hipStream_t s);
 pp_status pp_launch_clash(pp_ctx *c, const float *xyz, float *per_res, float *dchi, hipStream_t s);
