@@ -1,25 +1,21 @@
-// Edge-level stages of InvariantPointMessagePassing (layers.py:65-148) as fused FP32-MFMA kernels.
+// EXPERIMENTAL, opt-in (PACKPPI_EDGE=f16 python -m packppi_amd.build --force): the edge-level stages of
+// InvariantPointMessagePassing (layers.py:65-148) on the F16 matrix pipe with fp32-level accuracy.  The shipped kernels
+// are the exact-fp32 ones in pp_edge.hip; this file has the same structure and replaces the same launchers.
 //
-// A workgroup of 4 waves owns ONE residue i and its K<=32 edges (i, j).  Every activation tensor of the
-// chain lives in the accumulator layout of v_mfma_f32_32x32x2_f32 for the transposed product
-//      Y^T[feature][edge] = W[feature][k] * X^T[k][edge]:
-//      lane l = (edge j = l & 31, half h = l >> 5),  register r of tile t  <->  feature
-//      F(t, r, h) = 32 t + 8 (r >> 2) + 4 h + (r & 3).
-// With that k-ordering the D registers of one layer ARE the B operands of the next, and the A operand of
-// 4 consecutive k-steps is one float4 of a row of the nn.Linear weight ([out][in]: no transposition needed).
-//
-// N-split: wave w computes output tile w (32 of the 128 features; for the 512-wide FFN hidden layer,
-// tile 4c + w of hidden block c).  A finished tile is published to a 16 KB LDS exchange buffer
-// (same [tile][quad][lane] float4 layout it has in registers) and every wave reads back the full
-// 128-vector it needs as B operands.  Weights stream L2 -> registers -> LDS in [128 rows][32 | 24 cols]
-// chunks (pre-packed contiguously in consumption order), two chunks in flight, double-buffered LDS; each wave
-// reads its own 32 rows of the shared chunk.  53 KB of LDS and <=168
-// VGPRs per workgroup let up to 3 workgroups share a CU, so one workgroup's barrier / LDS latency is covered
-// by another's MFMAs, and 739 residues x 4 waves spread evenly over the 1024 SIMDs.
-//
-// The 456-wide first layer is never materialised: W_in [h_V_i | h_E_ij | h_V_j | geom] =
-// (W_A h_V_i + b) + W_C h_V_j  (node-level, precomputed per residue in pp_node.hip, gathered here)
-// + W_B h_E_ij + W_G geom_ij (MFMA here; the 72 invariant-point features are built in registers).
+// Same decomposition as pp_edge.hip: a workgroup of 4 waves owns ONE residue and its K<=32 edges, activations live in the
+// 32x32 MFMA accumulator layout (lane = (edge, half h); register r of tile t <-> feature 32 t + 8 (r >> 2) + 4 h + (r & 3))
+// so that a layer's outputs are the next layer's B operands, wave w computes output tile w of every layer (N-split)
+// and publishes it through a 16 KB LDS exchange buffer, weights arrive by wave-private LDS-DMA, the 456-wide first layer
+// is split by linearity.  What differs:
+//   * arithmetic: every fp32 product is three v_mfma_f32_32x32x16_f16 on two-way f16 splits (below);
+//   * occupancy: ONE workgroup per CU.  With several waves interleaving on a SIMD these kernels produced rare wrong
+//     tiles that could not be fully explained ("Split-f16"); with one wave per SIMD they are bit-reproducible
+//     over millions of workgroup launches (tools/debug/soak.py).  The LDS request (96 / 84.5 KB) enforces it;
+//   * pipeline: since no other workgroup hides latency, the DMA ring is 4-5 slots deep (counted waits) and the A operands
+//     of stage k+1 are read into the next of three rotating register sets while stage k computes;
+//   * no fusion of the next node message into the edge update (the fused tail was the least reliable part).
+// Measured (MI355X, T1124, 100 steps): 30.0 k residues/s against 26.6 k for pp_edge.hip; single workgroups take 18 us
+// (edge update) / 7 us (node message), so small complexes gain most (L = 256: 19.8 us vs 43 us per edge update).
 #include "pp_internal.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -63,12 +59,7 @@ __device__ __forceinline__ void join_tile(const HT &t, f32x16 &v) {
 #define XBUF_FLOATS (4 * 4 * 64 * 4)    // exchange buffer: [tile][quad][lane] float4
 #define PARAM_FLOATS 1152               // edge kernel: small per-layer vectors staged once
 
-// Timing-only ablation switch (tools/debug/ablate_edge.py); never defined in a shipped build.
-#ifdef PP_X_NOMFMA
-#define MFMA(a, b, c) ((c) + (a) * (b))
-#else
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
-#endif
 
 struct EdgeArgs {
     int N, K;
@@ -127,67 +118,50 @@ __device__ __forceinline__ void dma_chunk(const float *&sbase, unsigned &laneoff
                  : "+v"(laneoff) : "s"(sbase), "s"(lds_dst) : "memory", "s98", "s99");
     sbase += CH32;          // the running chunk pointer
 }
-// full wait; names the DMA address register so that it stays allocated (see HAZARD above)
-__device__ __forceinline__ void wait_vm0(unsigned laneoff) {
-    asm volatile("s_waitcnt vmcnt(0)" ::"v"(laneoff) : "memory");
-}
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
 
-// A real VALU consumer of the accumulator at the end of every stage: the wave cannot go on to the next stage's operand
-// loads before its MFMA chain has finished, so no load can land in registers a queued MFMA still has to read (measured:
-// with three workgroups per CU this alone removed most of the sporadic wrong tiles, at no cost in time)
-__device__ __forceinline__ void mfma_fence(f32x16 &acc) {
-    float probe = acc[0] * 1.0000001f;
-    asm volatile("" : "+v"(probe));
-    acc[0] = __builtin_amdgcn_fmed3f(probe, acc[0], acc[0]);      // == acc[0], but the compiler cannot know
-}
-
-// a wave's quarter of a weight chunk in its LDS slot: [k-step 2][part hi|lo][lane 64] h8 (4 KB)
-// acc += W[32 wave .. +32, chunk cols] * x     (SWAP: acc += x * W^T, edges on rows / features on lanes)
-template <bool SWAP>
-__device__ __forceinline__ void mfma_chunk(const float *wslot, const HT &x, f32x16 &acc, int lane) {
+// A operands of one stage in registers: [s0 hi, s0 lo, s1 hi, s1 lo].  Three such sets rotate (stage k computes from
+// set k % 3 while set (k+1) % 3 is being loaded): the set a load lands in was last read by the MFMAs of stage k - 2, which
+// have retired by then, so a returning load can never overwrite operands of an MFMA that is still queued.
+struct AOp {
+    h8 r[4];
+};
+__device__ __forceinline__ void load_A(const float *wslot, int lane, AOp &a) {
     const h8 *w = reinterpret_cast<const h8 *>(wslot) + lane;
+    a.r[0] = w[0]; a.r[1] = w[64]; a.r[2] = w[128]; a.r[3] = w[192];
+}
+template <bool SWAP>
+__device__ __forceinline__ void mfma_chunk_r(const AOp &a, const HT &x, f32x16 &acc) {
 #pragma unroll
     for (int s = 0; s < 2; s++) {
-        const h8 wh = w[(2 * s) * 64], wlo = w[(2 * s + 1) * 64];
         if (SWAP) {
-            acc = MFMA16(x.hi[s], wh, acc);
-            acc = MFMA16(x.lo[s], wh, acc);
-            acc = MFMA16(x.hi[s], wlo, acc);
+            acc = MFMA16(x.hi[s], a.r[2 * s], acc);
+            acc = MFMA16(x.lo[s], a.r[2 * s], acc);
+            acc = MFMA16(x.hi[s], a.r[2 * s + 1], acc);
         } else {
-            acc = MFMA16(wh, x.hi[s], acc);
-            acc = MFMA16(wh, x.lo[s], acc);
-            acc = MFMA16(wlo, x.hi[s], acc);
+            acc = MFMA16(a.r[2 * s], x.hi[s], acc);
+            acc = MFMA16(a.r[2 * s], x.lo[s], acc);
+            acc = MFMA16(a.r[2 * s + 1], x.hi[s], acc);
         }
     }
-#ifndef PP_NO_MFMA_FENCE
-    mfma_fence(acc);
-#endif
 }
-
 // the 72 invariant-point features as operands: global k-step S = 0..4 carries features 16 S + 8 h + i (zero beyond 71);
 // geometry chunk C holds k-steps 2C and 2C+1 (the last one is all padding and skipped)
 struct HG {
     h8 hi[5], lo[5];
 };
 template <int C>
-__device__ __forceinline__ void mfma_geo(const float *wslot, const HG &g, f32x16 &acc, int lane) {
-    const h8 *w = reinterpret_cast<const h8 *>(wslot) + lane;
+__device__ __forceinline__ void mfma_geo_r(const AOp &a, const HG &g, f32x16 &acc) {
 #pragma unroll
     for (int s = 0; s < 2; s++) {
         if (2 * C + s < 5) {
-            const h8 wh = w[(2 * s) * 64], wlo = w[(2 * s + 1) * 64];
-            acc = MFMA16(wh, g.hi[2 * C + s], acc);
-            acc = MFMA16(wh, g.lo[2 * C + s], acc);
-            acc = MFMA16(wlo, g.hi[2 * C + s], acc);
+            acc = MFMA16(a.r[2 * s], g.hi[2 * C + s], acc);
+            acc = MFMA16(a.r[2 * s], g.lo[2 * C + s], acc);
+            acc = MFMA16(a.r[2 * s + 1], g.hi[2 * C + s], acc);
         }
     }
-#ifndef PP_NO_MFMA_FENCE
-    mfma_fence(acc);
-#endif
 }
-
 // one tile (16 registers) <-> 32 consecutive features of a row-major vector
 __device__ __forceinline__ void load_tile(const float *__restrict__ row32, int h, f32x16 &d) {
 #pragma unroll
@@ -314,23 +288,6 @@ __device__ __forceinline__ void edge_geometry(const float *__restrict__ pts_i, c
         }
 }
 
-#if defined(PP_X_STAGE_BARRIER)
-#define STAGE_FENCE() __syncthreads()
-#elif defined(PP_X_STAGE_NOP)
-#ifndef PP_X_SLEEP
-#define PP_X_SLEEP 2
-#endif
-#define PP_STR2(x) #x
-#define PP_STR(x) PP_STR2(x)
-#define STAGE_FENCE() asm volatile("s_sleep " PP_STR(PP_X_SLEEP) ::: "memory")
-#else
-#define STAGE_FENCE()
-#endif
-// Stage k of a kernel with NCH chunks (two LDS slots per wave): wait until chunk k has landed -- a full vmcnt(0), so that
-// no copy is in flight when M0 moves --, start chunk k+1 into the slot stage k-1 read, compute on chunk k.  A copy has
-// one whole stage (6 MFMAs + its LDS reads) to land, the same prefetch distance as a counted two-deep ring.
-#ifndef PP_REGSTAGE
-#ifndef PP_SHALLOW_RING
 // one workgroup per CU: nothing else hides a copy's latency, so the ring is S slots deep -- stage k starts chunk k+S-1
 // into the slot stage k-1 read and waits, counted, until chunk k has landed (copies complete in issue order)
 template <int N>
@@ -340,86 +297,45 @@ __device__ __forceinline__ void wait_vmN(unsigned laneoff) {
 #define WSTAGE(k, NCH, BODY)                                                                                   \
     {                                                                                                          \
         if constexpr ((k) + S - 1 < (NCH)) dma_chunk(wsb, laneoff, slot0 + (((k) + S - 1) % S) * 4096u);       \
-        wait_vmN<4 * (((NCH) - 1 - (k)) < (S - 1) ? ((NCH) - 1 - (k)) : (S - 1))>(laneoff);                    \
-        const float *wslot = wl + ((k) % S) * 1024;                                                            \
-        BODY;                                                                                                  \
-    }
-#else
-#define WSTAGE(k, NCH, BODY)                                                                                   \
-    {                                                                                                          \
-        wait_vm0(laneoff);                                                                                     \
-        STAGE_FENCE();                                                                                         \
-        if constexpr ((k) + 1 < (NCH)) dma_chunk(wsb, laneoff, slot0 + (((k) + 1) % 2) * 4096u);               \
-        const float *wslot = wl + ((k) % 2) * 1024;                                                            \
-        BODY;                                                                                                  \
-    }
-#endif
-#else
-// register-staged variant (no LDS-DMA): chunk k+1 sits in 16 VGPRs (fetched during stage k-1), is written to its
-// slot at the start of stage k, and the registers are refilled with chunk k+2 (same element type as the readers: h8)
-#define WSTAGE(k, NCH, BODY)                                                                                   \
-    {                                                                                                          \
-        if constexpr ((k) + 1 < (NCH)) {                                                                       \
-            h8 *dst = reinterpret_cast<h8 *>(const_cast<float *>(wl) + (((k) + 1) % 2) * 1024) + lane;         \
-            dst[0] = wreg[0]; dst[64] = wreg[1]; dst[128] = wreg[2]; dst[192] = wreg[3];                       \
+        if constexpr ((k) + 1 < (NCH)) {      /* chunk k+1 has landed -> its A operands go to the next register set */ \
+            wait_vmN<4 * (((NCH) - 2 - (k)) < (S - 2) ? ((NCH) - 2 - (k)) : (S - 2))>(laneoff);                \
+            load_A(wl + (((k) + 1) % S) * 1024, lane, AR[((k) + 1) % 3]);                                      \
         }                                                                                                      \
-        if constexpr ((k) + 2 < (NCH)) {                                                                       \
-            const h8 *src = reinterpret_cast<const h8 *>(A.wstream + (size_t)((k) + 2) * CH32 + wave * 1024) + lane; \
-            wreg[0] = src[0]; wreg[1] = src[64]; wreg[2] = src[128]; wreg[3] = src[192];                       \
-        }                                                                                                      \
-        const float *wslot = wl + ((k) % 2) * 1024;                                                            \
-        STAGE_FENCE();                                                                                         \
+        const AOp &AK = AR[(k) % 3];                                                                           \
+        HT &HK = HR[(k) % 3];                                                                                  \
         BODY;                                                                                                  \
     }
-#endif
 
 // shared first layer: acc (tile `wave`) = PA_i + PC_j + W_B h_E + W_G geom, ReLU.  Chunks W_B x4 (absent when ST0:
 // layer 0's W_B h_E0 is timestep-invariant and arrives precomputed in acc), then W_G x3.  C0 = number of W_B chunks.
 #define FIRST_LAYER(NCH)                                                          \
     if constexpr (!ST0) {                                                         \
-        WSTAGE(0, NCH, mfma_chunk<false>(wslot, x[0], acc, lane))                 \
-        WSTAGE(1, NCH, mfma_chunk<false>(wslot, x[1], acc, lane))                 \
-        WSTAGE(2, NCH, mfma_chunk<false>(wslot, x[2], acc, lane))                 \
-        WSTAGE(3, NCH, mfma_chunk<false>(wslot, x[3], acc, lane))                 \
+        WSTAGE(0, NCH, mfma_chunk_r<false>(AK, x[0], acc))                 \
+        WSTAGE(1, NCH, mfma_chunk_r<false>(AK, x[1], acc))                 \
+        WSTAGE(2, NCH, mfma_chunk_r<false>(AK, x[2], acc))                 \
+        WSTAGE(3, NCH, mfma_chunk_r<false>(AK, x[3], acc))                 \
     }                                                                             \
-    WSTAGE(C0 + 0, NCH, mfma_geo<0>(wslot, g, acc, lane))                         \
-    WSTAGE(C0 + 1, NCH, mfma_geo<1>(wslot, g, acc, lane))                         \
-    WSTAGE(C0 + 2, NCH, mfma_geo<2>(wslot, g, acc, lane))                         \
+    WSTAGE(C0 + 0, NCH, mfma_geo_r<0>(AK, g, acc))                         \
+    WSTAGE(C0 + 1, NCH, mfma_geo_r<1>(AK, g, acc))                         \
+    WSTAGE(C0 + 2, NCH, mfma_geo_r<2>(AK, g, acc))                         \
     relu_tile(acc);                                                               \
     split_tile(acc, ht);                                                          \
     xbuf_put_h(xbuf, wave, lane, ht);                                             \
     __syncthreads();
 
-#ifndef PP_REGSTAGE
-#ifndef PP_SHALLOW_RING
 #define PROLOGUE_PIPE()                                                                        \
+    static_assert(S >= 3, "the operand prefetch reads slot k+1 while slot k+S-1 is refilled");  \
     const float *wsb = A.wstream + wave * 1024;          /* running chunk pointer, wave-uniform: SGPRs */ \
     unsigned laneoff = (unsigned)lane * 16u;              /* the one per-lane address register */ \
     const float *wl = smem + wave * (S * 1024);                                                \
     const unsigned slot0 = (unsigned)(size_t)wl;                                               \
+    AOp AR[3];                                                                                 \
+    HT HR[3];                                                                                  \
     _Pragma("unroll") for (int pk = 0; pk < S - 1; pk++) dma_chunk(wsb, laneoff, slot0 + pk * 4096u);
-#else
-#define PROLOGUE_PIPE()                                                                        \
-    static_assert(S == 2, "the weight pipeline is two slots per wave");                        \
-    const float *wsb = A.wstream + wave * 1024;          /* running chunk pointer, wave-uniform: SGPRs */ \
-    unsigned laneoff = (unsigned)lane * 16u;              /* the one per-lane address register */ \
-    const float *wl = smem + wave * (S * 1024);                                                \
-    const unsigned slot0 = (unsigned)(size_t)wl;                                               \
-    dma_chunk(wsb, laneoff, slot0);
-#endif
-#else
-#define PROLOGUE_PIPE()                                                                        \
-    static_assert(S == 2, "the weight pipeline is two slots per wave");                        \
-    const float *wl = smem + wave * (S * 1024);                                                \
-    h8 wreg[4];                                                                                \
-    {                                                                                          \
-        const h8 *src = reinterpret_cast<const h8 *>(A.wstream + wave * 1024) + lane;          \
-        h8 *dst = reinterpret_cast<h8 *>(const_cast<float *>(wl)) + lane;                      \
-        dst[0] = src[0]; dst[64] = src[64]; dst[128] = src[128]; dst[192] = src[192];          \
-        const h8 *src1 = src + CH32 / 4;                                                       \
-        wreg[0] = src1[0]; wreg[1] = src1[64]; wreg[2] = src1[128]; wreg[3] = src1[192];       \
-    }
-#endif
+// after the prologue's own loads have been issued: chunk 0's operands into the first register set
+#define PROLOGUE_OPERANDS()                                                                    \
+    wait_vmN<4 * (S - 2)>(laneoff);                                                            \
+    load_A(wl, lane, AR[0]);
 
 // ---------------------------------------------------------------------------------------------
 // node message: S[i] = (1/K) sum_j mask_ij relu(W_mid relu(W_in [..]) + b), msum[i] = (1/K) sum_j mask_ij
@@ -486,6 +402,7 @@ k_node_message(EdgeArgs A) {
         add_tile(A.PC + (size_t)nbr * 128 + 32 * wave, h, acc);
         if constexpr (ST0) add_tile(A.Z + ((size_t)n * K + jj) * 128 + 32 * wave, h, acc);
     }
+    PROLOGUE_OPERANDS()
     FIRST_LAYER(NCH)
     {
 #pragma unroll
@@ -493,10 +410,10 @@ k_node_message(EdgeArgs A) {
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[r] = bmid;
     }
-    WSTAGE(C0 + 3, NCH, mfma_chunk<true>(wslot, x[0], acc, lane))
-    WSTAGE(C0 + 4, NCH, mfma_chunk<true>(wslot, x[1], acc, lane))
-    WSTAGE(C0 + 5, NCH, mfma_chunk<true>(wslot, x[2], acc, lane))
-    WSTAGE(C0 + 6, NCH, mfma_chunk<true>(wslot, x[3], acc, lane))
+    WSTAGE(C0 + 3, NCH, mfma_chunk_r<true>(AK, x[0], acc))
+    WSTAGE(C0 + 4, NCH, mfma_chunk_r<true>(AK, x[1], acc))
+    WSTAGE(C0 + 5, NCH, mfma_chunk_r<true>(AK, x[2], acc))
+    WSTAGE(C0 + 6, NCH, mfma_chunk_r<true>(AK, x[3], acc))
     {
         // rows (registers) are edges e = 8 (r>>2) + 4 h + (r&3); mask and reduce over them
         float s = 0.f, ms = 0.f;
@@ -518,19 +435,19 @@ k_node_message(EdgeArgs A) {
 // FFN hidden block c (chunks 15 + 8c ..): W1 s=0..3 -> hidden tile 4c+wave -> exchange -> W2 s'=0..3 accumulate into out
 #define FFN_BLOCK(c)                                                                                         \
     load_tile(prm + P_FIB + 128 * (c) + 32 * wave, h, acc);                                                  \
-    WSTAGE(C0 + 11 + 8 * (c) + 0, NCH, mfma_chunk<false>(wslot, x[0], acc, lane))                                \
-    WSTAGE(C0 + 11 + 8 * (c) + 1, NCH, mfma_chunk<false>(wslot, x[1], acc, lane))                                \
-    WSTAGE(C0 + 11 + 8 * (c) + 2, NCH, mfma_chunk<false>(wslot, x[2], acc, lane))                                \
-    WSTAGE(C0 + 11 + 8 * (c) + 3, NCH, mfma_chunk<false>(wslot, x[3], acc, lane))                                \
+    WSTAGE(C0 + 11 + 8 * (c) + 0, NCH, mfma_chunk_r<false>(AK, x[0], acc))                                \
+    WSTAGE(C0 + 11 + 8 * (c) + 1, NCH, mfma_chunk_r<false>(AK, x[1], acc))                                \
+    WSTAGE(C0 + 11 + 8 * (c) + 2, NCH, mfma_chunk_r<false>(AK, x[2], acc))                                \
+    WSTAGE(C0 + 11 + 8 * (c) + 3, NCH, mfma_chunk_r<false>(AK, x[3], acc))                                \
     relu_tile(acc);                                                                                          \
     split_tile(acc, ht);                                                                                     \
     __syncthreads();          /* every wave is done reading the previous exchange */                        \
     xbuf_put_h(xbuf, wave, lane, ht);                                                                        \
     __syncthreads();                                                                                         \
-    WSTAGE(C0 + 11 + 8 * (c) + 4, NCH, xbuf_get_h(xbuf, 0, lane, ht); mfma_chunk<false>(wslot, ht, out, lane))   \
-    WSTAGE(C0 + 11 + 8 * (c) + 5, NCH, xbuf_get_h(xbuf, 1, lane, ht); mfma_chunk<false>(wslot, ht, out, lane))   \
-    WSTAGE(C0 + 11 + 8 * (c) + 6, NCH, xbuf_get_h(xbuf, 2, lane, ht); mfma_chunk<false>(wslot, ht, out, lane))   \
-    WSTAGE(C0 + 11 + 8 * (c) + 7, NCH, xbuf_get_h(xbuf, 3, lane, ht); mfma_chunk<false>(wslot, ht, out, lane))
+    WSTAGE(C0 + 11 + 8 * (c) + 4, NCH, xbuf_get_h(xbuf, 0, lane, HK); mfma_chunk_r<false>(AK, HK, out))   \
+    WSTAGE(C0 + 11 + 8 * (c) + 5, NCH, xbuf_get_h(xbuf, 1, lane, HK); mfma_chunk_r<false>(AK, HK, out))   \
+    WSTAGE(C0 + 11 + 8 * (c) + 6, NCH, xbuf_get_h(xbuf, 2, lane, HK); mfma_chunk_r<false>(AK, HK, out))   \
+    WSTAGE(C0 + 11 + 8 * (c) + 7, NCH, xbuf_get_h(xbuf, 3, lane, HK); mfma_chunk_r<false>(AK, HK, out))
 
 // FUSE (-DPP_FUSE_NM, OFF by default): the workgroup goes straight on to the NEXT layer's node message of its residue
 // (same 32 edges, whose new h_E it holds; the node-level inputs PA2 / PC2 / pts2 were written by the node update that
@@ -543,11 +460,7 @@ template <int S, bool ST0, bool FUSE>
 __global__ void __launch_bounds__(ET, PP_EU_WGS)
 k_edge_update(EdgeArgs A) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-#ifdef PP_X_PRM_ALIAS          // timing only: params alias the exchange buffer (wrong results) to test an 80 KB footprint
-    float *xbuf = smem + 4 * S * 1024, *prm = xbuf;
-#else
     float *xbuf = smem + 4 * S * 1024, *prm = xbuf + XBUF_FLOATS;
-#endif
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, h = lane >> 5;
@@ -598,6 +511,7 @@ k_edge_update(EdgeArgs A) {
         add_tile(A.PC + (size_t)nbr * 128 + 32 * wave, h, acc);
         if constexpr (ST0) add_tile(A.Z + ((size_t)n * K + jj) * 128 + 32 * wave, h, acc);
     }
+    PROLOGUE_OPERANDS()
     FIRST_LAYER(NCH)
     // ---- second layer (chunks 7..10) -------------------------------------------------------------
     {
@@ -605,10 +519,10 @@ k_edge_update(EdgeArgs A) {
         for (int t = 0; t < 4; t++) xbuf_get_h(xbuf, t, lane, x[t]);
         load_tile(prm + P_BMID + 32 * wave, h, acc);
     }
-    WSTAGE(C0 + 3, NCH, mfma_chunk<false>(wslot, x[0], acc, lane))
-    WSTAGE(C0 + 4, NCH, mfma_chunk<false>(wslot, x[1], acc, lane))
-    WSTAGE(C0 + 5, NCH, mfma_chunk<false>(wslot, x[2], acc, lane))
-    WSTAGE(C0 + 6, NCH, mfma_chunk<false>(wslot, x[3], acc, lane))
+    WSTAGE(C0 + 3, NCH, mfma_chunk_r<false>(AK, x[0], acc))
+    WSTAGE(C0 + 4, NCH, mfma_chunk_r<false>(AK, x[1], acc))
+    WSTAGE(C0 + 5, NCH, mfma_chunk_r<false>(AK, x[2], acc))
+    WSTAGE(C0 + 6, NCH, mfma_chunk_r<false>(AK, x[3], acc))
     relu_tile(acc);
     split_tile(acc, ht);
     __syncthreads();
@@ -620,10 +534,10 @@ k_edge_update(EdgeArgs A) {
         for (int t = 0; t < 4; t++) xbuf_get_h(xbuf, t, lane, x[t]);
         load_tile(prm + P_BOUT + 32 * wave, h, acc);
     }
-    WSTAGE(C0 + 7, NCH, mfma_chunk<false>(wslot, x[0], acc, lane))
-    WSTAGE(C0 + 8, NCH, mfma_chunk<false>(wslot, x[1], acc, lane))
-    WSTAGE(C0 + 9, NCH, mfma_chunk<false>(wslot, x[2], acc, lane))
-    WSTAGE(C0 + 10, NCH, mfma_chunk<false>(wslot, x[3], acc, lane))
+    WSTAGE(C0 + 7, NCH, mfma_chunk_r<false>(AK, x[0], acc))
+    WSTAGE(C0 + 8, NCH, mfma_chunk_r<false>(AK, x[1], acc))
+    WSTAGE(C0 + 9, NCH, mfma_chunk_r<false>(AK, x[2], acc))
+    WSTAGE(C0 + 10, NCH, mfma_chunk_r<false>(AK, x[3], acc))
     // publish v = h_E + mask * m for the first LayerNorm (own tile: read, then overwritten in place)
     load_tile(hrow + 32 * wave, h, out);        // residual input: this wave's tile of h_E (L2-resident re-read)
 #pragma unroll
@@ -685,9 +599,6 @@ k_edge_update(EdgeArgs A) {
         int o_pts = n * 48, o_fr = n * 12, o_pa = n * 128;
         int o_ptsj = nbr * 48, o_pc = nbr * 128;
         split_tile(out, ht);
-#ifdef PP_X_TAIL_DRAIN
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#endif
         __syncthreads();                                      // every wave has read the LayerNorm exchange
         xbuf_put_h(xbuf, wave, lane, ht);
         // `out` is dead from here; the fence keeps the input fetches below it (they would otherwise be hoisted to the
@@ -701,13 +612,13 @@ k_edge_update(EdgeArgs A) {
         __syncthreads();
 #pragma unroll
         for (int t = 0; t < 4; t++) xbuf_get_h(xbuf, t, lane, x[t]);
-        WSTAGE(NEU + 0, NCH, mfma_chunk<false>(wslot, x[0], acc, lane))
-        WSTAGE(NEU + 1, NCH, mfma_chunk<false>(wslot, x[1], acc, lane))
-        WSTAGE(NEU + 2, NCH, mfma_chunk<false>(wslot, x[2], acc, lane))
-        WSTAGE(NEU + 3, NCH, mfma_chunk<false>(wslot, x[3], acc, lane))
-        WSTAGE(NEU + 4, NCH, mfma_geo<0>(wslot, g, acc, lane))
-        WSTAGE(NEU + 5, NCH, mfma_geo<1>(wslot, g, acc, lane))
-        WSTAGE(NEU + 6, NCH, mfma_geo<2>(wslot, g, acc, lane))
+        WSTAGE(NEU + 0, NCH, mfma_chunk_r<false>(AK, x[0], acc))
+        WSTAGE(NEU + 1, NCH, mfma_chunk_r<false>(AK, x[1], acc))
+        WSTAGE(NEU + 2, NCH, mfma_chunk_r<false>(AK, x[2], acc))
+        WSTAGE(NEU + 3, NCH, mfma_chunk_r<false>(AK, x[3], acc))
+        WSTAGE(NEU + 4, NCH, mfma_geo_r<0>(AK, g, acc))
+        WSTAGE(NEU + 5, NCH, mfma_geo_r<1>(AK, g, acc))
+        WSTAGE(NEU + 6, NCH, mfma_geo_r<2>(AK, g, acc))
         relu_tile(acc);
         split_tile(acc, ht);
         __syncthreads();
@@ -717,10 +628,10 @@ k_edge_update(EdgeArgs A) {
         for (int t = 0; t < 4; t++) xbuf_get_h(xbuf, t, lane, x[t]);
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[r] = bmid;
-        WSTAGE(NEU + 7, NCH, mfma_chunk<true>(wslot, x[0], acc, lane))
-        WSTAGE(NEU + 8, NCH, mfma_chunk<true>(wslot, x[1], acc, lane))
-        WSTAGE(NEU + 9, NCH, mfma_chunk<true>(wslot, x[2], acc, lane))
-        WSTAGE(NEU + 10, NCH, mfma_chunk<true>(wslot, x[3], acc, lane))
+        WSTAGE(NEU + 7, NCH, mfma_chunk_r<true>(AK, x[0], acc))
+        WSTAGE(NEU + 8, NCH, mfma_chunk_r<true>(AK, x[1], acc))
+        WSTAGE(NEU + 9, NCH, mfma_chunk_r<true>(AK, x[2], acc))
+        WSTAGE(NEU + 10, NCH, mfma_chunk_r<true>(AK, x[3], acc))
         // rows (registers) are edges e = 8 (r>>2) + 4 h + (r&3); mask and reduce over them
         int o_m = n * 32 + 4 * h;
         asm volatile("" : "+v"(o_m) : "v"(acc[0]));
@@ -766,17 +677,18 @@ k_edge_static(EdgeArgs A) {
     for (int t = 0; t < 4; t++) { load_tile(hrow + 32 * t, h, acc); split_tile(acc, x[t]); }
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[r] = 0.f;
-    WSTAGE(0, NCH, mfma_chunk<false>(wslot, x[0], acc, lane))
-    WSTAGE(1, NCH, mfma_chunk<false>(wslot, x[1], acc, lane))
-    WSTAGE(2, NCH, mfma_chunk<false>(wslot, x[2], acc, lane))
-    WSTAGE(3, NCH, mfma_chunk<false>(wslot, x[3], acc, lane))
+    PROLOGUE_OPERANDS()
+    WSTAGE(0, NCH, mfma_chunk_r<false>(AK, x[0], acc))
+    WSTAGE(1, NCH, mfma_chunk_r<false>(AK, x[1], acc))
+    WSTAGE(2, NCH, mfma_chunk_r<false>(AK, x[2], acc))
+    WSTAGE(3, NCH, mfma_chunk_r<false>(AK, x[3], acc))
     store_tile(A.Znm + ((size_t)n * K + jj) * 128 + 32 * wave, h, acc);      // lanes j >= K mirror edge K - 1
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[r] = 0.f;
-    WSTAGE(4, NCH, mfma_chunk<false>(wslot, x[0], acc, lane))
-    WSTAGE(5, NCH, mfma_chunk<false>(wslot, x[1], acc, lane))
-    WSTAGE(6, NCH, mfma_chunk<false>(wslot, x[2], acc, lane))
-    WSTAGE(7, NCH, mfma_chunk<false>(wslot, x[3], acc, lane))
+    WSTAGE(4, NCH, mfma_chunk_r<false>(AK, x[0], acc))
+    WSTAGE(5, NCH, mfma_chunk_r<false>(AK, x[1], acc))
+    WSTAGE(6, NCH, mfma_chunk_r<false>(AK, x[2], acc))
+    WSTAGE(7, NCH, mfma_chunk_r<false>(AK, x[3], acc))
     store_tile(A.Zem + ((size_t)n * K + jj) * 128 + 32 * wave, h, acc);
 }
 
@@ -805,21 +717,8 @@ static EdgeArgs edge_args(pp_ctx *c, int layer, bool edge) {
 }
 
 static const size_t NM_SMEM = (4 * PP_NM_SLOTS * 1024 + XBUF_FLOATS) * sizeof(float);
-#ifdef PP_X_PRM_ALIAS
-static const size_t EU_SMEM = (4 * PP_EU_SLOTS * 1024 + XBUF_FLOATS) * sizeof(float);
-#else
 static const size_t EU_SMEM = (4 * PP_EU_SLOTS * 1024 + XBUF_FLOATS + PARAM_FLOATS) * sizeof(float);
-#endif
 static const size_t ST_SMEM = (4 * PP_NM_SLOTS * 1024) * sizeof(float);
-#ifdef PP_X_BIGLDS_NM        // diagnostics: one workgroup per CU for one kernel
-#define NM_SMEM ((size_t)100 * 1024)
-#endif
-#ifdef PP_X_BIGLDS_EU
-#define EU_SMEM ((size_t)100 * 1024)
-#endif
-#ifdef PP_X_BIGLDS_ST
-#define ST_SMEM ((size_t)100 * 1024)
-#endif
 
 static bool edge_attrs() {
     static bool done = false, ok = false;
