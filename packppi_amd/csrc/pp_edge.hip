@@ -11,11 +11,13 @@
 // N-split: wave w computes output tile w (32 of the 128 features; for the 512-wide FFN hidden layer,
 // tile 4c + w of hidden block c).  A finished tile is published to a 16 KB LDS exchange buffer
 // (same [tile][quad][lane] float4 layout it has in registers) and every wave reads back the full
-// 128-vector it needs as B operands.  Weights stream L2 -> registers -> LDS in [128 rows][32 | 24 cols]
-// chunks (pre-packed contiguously in consumption order), two chunks in flight, double-buffered LDS; each wave
-// reads its own 32 rows of the shared chunk.  53 KB of LDS and <=168
-// VGPRs per workgroup let up to 3 workgroups share a CU, so one workgroup's barrier / LDS latency is covered
-// by another's MFMAs, and 739 residues x 4 waves spread evenly over the 1024 SIMDs.
+// 128-vector it needs as B operands.  Since wave w needs only weight rows 32w..32w+31, each wave streams its own
+// quarter of every [128 rows][32 cols] weight chunk (pre-packed in consumption order) by LDS-DMA into a private
+// two-slot ring: no barrier on the weight path, only around the exchanges.  53 KB of LDS and <=168 VGPRs per
+// workgroup let 3 workgroups share a CU, so one workgroup's barrier / LDS latency is covered by another's MFMAs,
+// and 739 residues x 4 waves spread evenly over the 1024 SIMDs.
+// Kernels: k_edge_static (once per complex: layer 0's W_B h_E0), k_node_message (layer 0), k_edge_update (edge update of
+// layer l, then the node message of layer l+1 on the fresh edges, in the same workgroup).
 //
 // The 456-wide first layer is never materialised: W_in [h_V_i | h_E_ij | h_V_j | geom] =
 // (W_A h_V_i + b) + W_C h_V_j  (node-level, precomputed per residue in pp_node.hip, gathered here)
