@@ -135,6 +135,10 @@ pp_status pp_time_kernel(pp_ctx *ctx, int which, int iters, float *avg_ms, void 
 pp_status pp_profile_kernel(pp_ctx *ctx, int which);
 pp_status pp_profile_read(pp_ctx *ctx, float *total_ms, int *launches);
 
+/* The library also exports a few undocumented pp_debug_* entry points (single-kernel launches and internal-buffer
+ * copies) used only by tools/debug/ to test kernels for run-to-run reproducibility.  They are not part of the
+ * drop-in boundary and may change. */
+
 #ifdef __cplusplus
 }
 #endif

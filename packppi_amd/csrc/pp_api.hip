@@ -450,7 +450,7 @@ static pp_status run_network(pp_ctx *c, hipStream_t s, int step, int last_mode, 
         }
         if (l < 2) {
             prof_mark(c, 2, s);
-            st = pp_launch_node_update(c, l, PP_NU_MID, chi, step, mode, noise, s);
+            st = pp_launch_node_update(c, l, PP_NU_MID, chi, step, mode, noise, false, s);
             prof_mark(c, 2, s);
             if (st != PP_OK) return st;
             prof_mark(c, 1, s);
@@ -458,10 +458,8 @@ static pp_status run_network(pp_ctx *c, hipStream_t s, int step, int last_mode, 
             prof_mark(c, 1, s);
             if (st != PP_OK) return st;
         } else {
-            int enc = step;
-            if (last_mode == PP_NU_STEP && !embed_next) enc = -step - 1;
             prof_mark(c, 2, s);
-            st = pp_launch_node_update(c, l, last_mode, chi, enc, mode, noise, s);
+            st = pp_launch_node_update(c, l, last_mode, chi, step, mode, noise, last_mode == PP_NU_STEP && embed_next, s);
             prof_mark(c, 2, s);
             if (st != PP_OK) return st;
         }

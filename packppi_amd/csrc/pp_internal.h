@@ -129,7 +129,7 @@ void pp_set_error(const std::string &msg);
 pp_status pp_launch_prepare(pp_ctx *c, hipStream_t s);
 pp_status pp_launch_node_embed(pp_ctx *c, const float *chi, int step, hipStream_t s);
 pp_status pp_launch_node_update(pp_ctx *c, int layer, int last_mode, float *chi, int step, int mode,
-                                const float *noise, hipStream_t s);
+                                const float *noise, bool embed_next, hipStream_t s);
 pp_status pp_launch_edge_static(pp_ctx *c, hipStream_t s);
 pp_status pp_launch_node_message(pp_ctx *c, int layer, hipStream_t s);
 bool pp_edge_fused();            // does pp_launch_edge_update also compute the next layer's node message?

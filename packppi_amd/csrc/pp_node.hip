@@ -699,7 +699,7 @@ pp_status pp_launch_node_embed(pp_ctx *c, const float *chi, int step, hipStream_
 }
 
 pp_status pp_launch_node_update(pp_ctx *c, int layer, int last_mode, float *chi, int step, int mode,
-                                const float *noise, hipStream_t s) {
+                                const float *noise, bool embed_next_step, hipStream_t s) {
     pp_status st0 = node_attrs();
     if (st0 != PP_OK) return st0;
     const pp_plan *p = c->plan;
@@ -719,10 +719,8 @@ pp_status pp_launch_node_update(pp_ctx *c, int layer, int last_mode, float *chi,
     W.d2_inT = p->d2_in_T; W.d2_in_b = p->w + p->off.d2_in_b;
     W.d2_outT = p->d2_out_T; W.d2_out_b = p->w + p->off.d2_out_b;
     PreW pre0 = make_pre(p, 0, false);
-    // step >= 0: re-embed for step + 1 afterwards; step < 0 encodes "last step (-step-1), no re-embed"
-    int embed_next = (last_mode == PP_NU_STEP && step >= 0) ? 1 : 0;
-    int st = step;
-    if (last_mode == PP_NU_STEP && step < 0) { st = -step - 1; embed_next = 0; }
+    const int embed_next = (last_mode == PP_NU_STEP && embed_next_step) ? 1 : 0;    // node embedding for step + 1 afterwards
+    const int st = step;
     const dim3 grid((c->N + NB - 1) / NB), block(NT);
     const int sde = mode == PP_MODE_SDE ? 1 : 0;
     if (last_mode == PP_NU_MID)
