@@ -82,33 +82,36 @@ enum { P_BMID = 0, P_BOUT = 128, P_FOB = 256, P_G2 = 384, P_BE2 = 512, P_FIB = 6
 // gather), each statement takes it read-write and every wait names it, so it is never handed to anything else; the
 // wave-uniform part of the address goes in SGPRs; and no lane is masked off (divergent control flow) while a copy is in
 // flight -- surplus lanes use clamped indices and rewrite the same value.
+// M0 (the LDS destination) and the SGPR pairs holding the wave-uniform part of the address are written only by these
+// statements, into registers hipcc never allocates here (s90..s99; it uses ~60 from s0 up and no M0), and then rest until
+// the next issue a whole stage later: whatever the hardware reads late, it finds unchanged.
 __device__ __forceinline__ void dma_chunk(const float *sbase, unsigned &laneoff, unsigned lds_dst) {
-    unsigned keep;
     asm volatile("s_waitcnt lgkmcnt(0)\n\t"          // this wave's reads of the slot being refilled have returned
-                 "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
-                 "global_load_lds_dwordx4 %1, %2\n\t"
-                 "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
-                 "global_load_lds_dwordx4 %1, %2 offset:2048\n\t"
-                 "global_load_lds_dwordx4 %1, %2 offset:3072\n\t"
-                 "s_mov_b32 m0, %0"
-                 : "=&s"(keep), "+v"(laneoff) : "s"(sbase), "s"(lds_dst) : "memory");
+                 "s_mov_b32 m0, %2\n\t"
+                 "s_mov_b64 s[98:99], %1\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %0, s[98:99]\n\t"
+                 "global_load_lds_dwordx4 %0, s[98:99] offset:1024\n\t"
+                 "global_load_lds_dwordx4 %0, s[98:99] offset:2048\n\t"
+                 "global_load_lds_dwordx4 %0, s[98:99] offset:3072"
+                 : "+v"(laneoff) : "s"(sbase), "s"(lds_dst) : "memory", "s98", "s99");
 }
 // one tile of a row-major [.][128] row set, gathered per lane (byte offset rowoff of this lane's 32-feature row piece
 // + 16 h from sbase) into the [quad][lane][4] register image at lds_dst: quad q is the float4 at + 32 q bytes.  The
-// instruction offset moves the global AND the LDS address, hence the 1024 - 32 stride on M0.
+// instruction offset moves the global AND the LDS address by the same amount, so quad q is issued with offset 1024 q
+// (its LDS place) from a base pulled back by 992 q; M0 is the same for all four.
 __device__ __forceinline__ void dma_tile(const float *sbase, unsigned &rowoff, unsigned lds_dst) {
-    unsigned keep;
     asm volatile("s_waitcnt lgkmcnt(0)\n\t"
-                 "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
-                 "global_load_lds_dwordx4 %1, %2\n\t"
-                 "s_add_u32 m0, m0, 992\n\ts_nop 0\n\t"
-                 "global_load_lds_dwordx4 %1, %2 offset:32\n\t"
-                 "s_add_u32 m0, m0, 992\n\ts_nop 0\n\t"
-                 "global_load_lds_dwordx4 %1, %2 offset:64\n\t"
-                 "s_add_u32 m0, m0, 992\n\ts_nop 0\n\t"
-                 "global_load_lds_dwordx4 %1, %2 offset:96\n\t"
-                 "s_mov_b32 m0, %0"
-                 : "=&s"(keep), "+v"(rowoff) : "s"(sbase), "s"(lds_dst) : "memory", "scc");
+                 "s_mov_b32 m0, %2\n\t"
+                 "s_mov_b64 s[90:91], %1\n\t"
+                 "s_sub_u32 s92, s90, 992\n\ts_subb_u32 s93, s91, 0\n\t"
+                 "s_sub_u32 s94, s90, 1984\n\ts_subb_u32 s95, s91, 0\n\t"
+                 "s_sub_u32 s96, s90, 2976\n\ts_subb_u32 s97, s91, 0\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %0, s[90:91]\n\t"
+                 "global_load_lds_dwordx4 %0, s[92:93] offset:1024\n\t"
+                 "global_load_lds_dwordx4 %0, s[94:95] offset:2048\n\t"
+                 "global_load_lds_dwordx4 %0, s[96:97] offset:3072"
+                 : "+v"(rowoff) : "s"(sbase), "s"(lds_dst)
+                 : "memory", "scc", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97");
 }
 // counted wait; names the DMA address registers so that they stay allocated (see HAZARD)
 template <int N>
