@@ -299,9 +299,9 @@ extern "C" pp_status pp_plan_create(const float *weights, size_t n_weights, cons
 
 extern "C" void pp_plan_destroy(pp_plan *p) {
     if (!p) return;
-    hipFree(p->w); hipFree(p->wT); hipFree(p->default_frames); hipFree(p->atom14_to_group);
-    hipFree(p->atom14_mask); hipFree(p->lit_positions); hipFree(p->between_radius);
-    hipFree(p->bounds_lower); hipFree(p->bounds_upper);
+    void *ptrs[] = {p->w, p->wT, p->default_frames, p->atom14_to_group, p->atom14_mask, p->lit_positions,
+                    p->between_radius, p->bounds_lower, p->bounds_upper};
+    for (void *q : ptrs) if (q) (void)hipFree(q);
     delete p;
 }
 
@@ -329,8 +329,8 @@ extern "C" void pp_ctx_destroy(pp_ctx *c) {
     void *ptrs[] = {c->rec, c->Znm, c->Zem, c->eidx, c->mask_att, c->frames, c->bbpos, c->hE0, c->hE, c->hV, c->S, c->msum, c->ptsN, c->PAn,
                     c->PCn, c->ptsE, c->PAe, c->PCe, c->score, c->chi_tmp, c->steps, c->xyz, c->axes, c->brad,
                     c->per_res, c->dchi, c->px, c->pm, c->pv, c->pz, c->pxeff, c->pmask, c->scal};
-    for (void *q : ptrs) if (q) hipFree(q);
-    if (c->steps_host) hipHostFree(c->steps_host);
+    for (void *q : ptrs) if (q) (void)hipFree(q);
+    if (c->steps_host) (void)hipHostFree(c->steps_host);
     for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
     delete c;
 }
@@ -566,8 +566,8 @@ extern "C" pp_status pp_time_kernel(pp_ctx *c, int which, int iters, float *avg_
     PP_HIP_CHECK(hipEventSynchronize(e1));
     float ms = 0.f;
     PP_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
     *avg_ms = ms / (float)iters;
     return st;
 }
