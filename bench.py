@@ -40,6 +40,22 @@ def load_t1124():
     return b, torch.from_numpy(z["init_chi_seed1124"]), torch.from_numpy(z["chi_ode_100"])
 
 
+def load_s1500():
+    """The 1500-residue synthetic complex with the reference's own 100-step output on the same noise, if the fixture
+    is present (tests/golden/g5_S1500.npz, tools/oracle/make_golden.py --only g5)."""
+    from packppi_amd.batch import Batch
+    path = os.path.join(ROOT, "tests", "golden", "g5_S1500.npz")
+    if not os.path.exists(path):
+        return None
+    z = np.load(path)
+    b = Batch()
+    for k in z.files:
+        if k.startswith("batch."):
+            key = k[6:]
+            b[key] = int(z[k]) if key in ("num_proteins", "max_size") else torch.from_numpy(z[k])
+    return b, torch.from_numpy(z["init_chi_seed1500"]), torch.from_numpy(z["chi_ode_100"])
+
+
 def synth_workload(kind, rank):
     from packppi_amd import synth
     from packppi_amd.batch import collate
@@ -126,6 +142,8 @@ def main():
     else:
         batch = synth_workload(args.workload, rank)
         init = None
+        if args.workload == "s1500" and load_s1500() is not None:      # same complex, with the reference's output
+            batch, init, ref_chi = load_s1500()
         name = {"s1500": "synthetic 1500-residue 2-chain complex (default_rng(1500)), 1 per GPU",
                 "c5": "32 synthetic complexes L~U{270..330} per GPU (default_rng(256))"}[args.workload]
     residues = batch.true_residues()

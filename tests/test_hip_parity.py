@@ -196,6 +196,19 @@ def test_T1124_100_steps(model):
     assert (pr - g["clash_final"]).abs().max() < 2e-5
 
 
+def test_S1500_100_steps(model):
+    """BASELINE config 3's complex (1500 synthetic residues, where the reference's clash code goes OOM): 100 diffusion
+    steps vs the reference CPU output on identical noise."""
+    import os
+    if not os.path.exists(os.path.join(os.path.dirname(__file__), "golden", "g5_S1500.npz")):
+        pytest.skip("g5_S1500 fixture not generated")
+    b, g = load_golden("g5_S1500")
+    gb = _gpu(b)
+    chi = model._context(gb).sample(g["init_chi_seed1500"].to(DEV), torch.linspace(1, 0, 101))
+    d = wrapped_absdiff(chi.cpu(), g["chi_ode_100"])[b.SC_D_mask.bool()]
+    assert d.max() < 1e-4, float(d.max())
+
+
 def test_missing_library_fails_loudly(monkeypatch):
     import packppi_amd.lib as L
     monkeypatch.setattr(L, "_lib", None)

@@ -201,6 +201,18 @@ def main():
         chi = run_sampling(sde_model, rb, init, 30)
         save("g3_sampling_sde_L33", **pack_batch(b), init_chi_seed11=init, chi_sde_30_seed99=chi)
 
+    # ---- g5: the 1500-residue synthetic complex of BASELINE config 3 (bench.py --workload s1500), 100 steps ----------
+    if want("g5"):
+        b = synth_batch(1500, 1500)
+        rb = ref_batch(b)
+        out = pack_batch(b)
+        init = seeded_init(model, rb, 1500)
+        out["init_chi_seed1500"] = init
+        t0 = time.time()
+        out["chi_ode_100"] = run_sampling(model, rb, init, 100)
+        print(f"  S1500 ode 100 steps {time.time() - t0:.1f}s", flush=True)
+        save("g5_S1500", **out)
+
     # ---- g3p: proximal optimiser ------------------------------------------------------------------
     if want("g3p"):
         for tag, b in (("L64", synth_batch(64, 164)), ("L120", synth_batch(120, 1120))):
