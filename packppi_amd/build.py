@@ -10,7 +10,7 @@ LIB = os.path.join(CSRC, "libpackppi_hip.so")
 EDGE_F16 = os.environ.get("PACKPPI_EDGE", "") == "f16"
 SOURCES = ["pp_api.hip", "pp_prepare.hip", "pp_node.hip", "pp_edge_f16.hip" if EDGE_F16 else "pp_edge.hip", "pp_clash.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-variable",
-         "-Wno-unused-but-set-variable"] + (["-DPP_EDGE_F16"] if EDGE_F16 else [])
+         "-Wno-unused-but-set-variable"] + (["-DPP_EDGE_F16"] if EDGE_F16 else []) + os.environ.get("PACKPPI_CFLAGS", "").split()
 
 
 def _hipcc():

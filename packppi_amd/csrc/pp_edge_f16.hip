@@ -2,7 +2,8 @@
 // InvariantPointMessagePassing (layers.py:65-148) on the F16 matrix pipe with fp32-level accuracy.  The shipped kernels
 // are the exact-fp32 ones in pp_edge.hip; this file has the same structure and replaces the same launchers.
 //
-// Same decomposition as pp_edge.hip: a workgroup of 4 waves owns ONE residue and its K<=32 edges, activations live in the
+// Same decomposition as pp_edge.hip: a workgroup of 4 waves owns R residues (R = 1..3, template) and their K<=32 edges each
+// -- every weight chunk a wave fetches is applied to R independent accumulator chains --, activations live in the
 // 32x32 MFMA accumulator layout (lane = (edge, half h); register r of tile t <-> feature 32 t + 8 (r >> 2) + 4 h + (r & 3))
 // so that a layer's outputs are the next layer's B operands, wave w computes output tile w of every layer (N-split)
 // and publishes it through a 16 KB LDS exchange buffer, weights arrive by wave-private LDS-DMA, the 456-wide first layer
@@ -80,70 +81,78 @@ struct EdgeArgs {
     const float *Z;            // layer 0: precomputed W_B h_E0 of this message function [N][K][128]
     const float *pts2, *PA2, *PC2, *b_mid2;   // fused edge update: node-level inputs / bias of the NEXT node message
     float *Znm, *Zem;          // k_edge_static outputs
+    float *dbg;                // diagnostics: [N][4 waves][64 lanes][8] or null
 };
 enum { P_BMID = 0, P_BOUT = 128, P_FOB = 256, P_G2 = 384, P_BE2 = 512, P_FIB = 640 };
 
-// ---- weight pipeline: LDS-DMA, private to each wave ------------------------------------------------------------
-// Wave w only ever needs rows 32w..32w+31 of a weight chunk (its output tile), so its quarter of every chunk is
-// packed (pp_plan_create) as [quad q][lane][4 floats] = exactly the A-operand registers of 16 MFMAs: one 4 KB piece,
-// copied global -> LDS by four `global_load_lds_dwordx4` (1 KB each, no VGPRs, no ds_write) into a per-wave ring of S
-// slots and read back lane-linear (conflict-free ds_read_b128).  No other wave touches the slot, so the only
-// ordering needed is this wave's own counted s_waitcnt vmcnt (MI355X_MICROARCH.md, co-residence item 7): the weight
-// stream needs NO workgroup barrier; barriers remain only around the activation exchange buffer.
-// hipcc does not count these loads: between the prologue and the epilogue the kernels issue no ordinary global
-// loads (every small vector is staged to LDS or registers up front), so no compiler-made vmcnt(0) drains the ring.
-// HAZARD (measured, tools/debug/edge_repro.py): an LDS-DMA instruction reads its address VGPRs LATE -- when the memory
-// pipeline accepts it, which under load (several workgroups per CU) can be hundreds of cycles after issue -- and
-// nothing interlocks a later VALU write to those registers.  hipcc, for which the asm's inputs are dead at its end,
-// reuses them at once; the copy then fetches from a garbage address (sporadic wrong weight tiles, only with co-resident
-// workgroups, gone with an s_waitcnt vmcnt(0) after every issue).  So the per-lane part of every DMA address lives in
-// ONE register per wave for the whole kernel (`laneoff` = lane * 16, or the gather offset of dma_tile): each statement
-// takes it read-write and the next wait takes it as input, so the compiler keeps it intact across the window; the
-// wave-uniform part of the address goes in fixed SGPRs written only by these statements.  The same holds for M0 (LDS
-// destination) and for EXEC: a lane masked off by a LATER divergent branch is dropped from a copy still in flight, so
-// between an issue and its wait the kernels keep every lane active (clamped indices instead of predication).
-// M0 (the LDS destination) is likewise left alone after the issue: it is written only by the next DMA statement
-// (hipcc emits no M0 use of its own in these kernels; checked in the ISA).
-__device__ __forceinline__ void dma_chunk(const float *&sbase, unsigned &laneoff, unsigned lds_dst) {
-    // M0 (LDS destination) and s[98:99] (wave-uniform chunk address) are written ONLY here, after the previous copy has
-    // completed (the caller's s_waitcnt vmcnt(0)), and then rest until the next issue; hipcc emits no M0 use of its own in
-    // these kernels and allocates SGPRs from s0 up (~65 used).
-    asm volatile("s_waitcnt lgkmcnt(0)\n\t"          // this wave's reads of the slot being refilled have returned
-                 "s_mov_b32 m0, %2\n\t"
-                 "s_mov_b64 s[98:99], %1\n\ts_nop 4\n\t"
-                 "global_load_lds_dwordx4 %0, s[98:99]\n\t"
-                 "global_load_lds_dwordx4 %0, s[98:99] offset:1024\n\t"
-                 "global_load_lds_dwordx4 %0, s[98:99] offset:2048\n\t"
-                 "global_load_lds_dwordx4 %0, s[98:99] offset:3072"
-                 : "+v"(laneoff) : "s"(sbase), "s"(lds_dst) : "memory", "s98", "s99");
-    sbase += CH32;          // the running chunk pointer
-}
+// ---- weight pipeline: global memory -> registers, private to each wave -------------------------------------------
+// Wave w only ever needs rows 32w..32w+31 of a weight chunk (its output tile), so its quarter of every chunk is packed
+// (pp_plan_create, put_chunk_f16) as [quad q][lane][8 halves] = exactly the A-operand registers of the stage's MFMAs
+// (q = k-step 0 hi, lo, k-step 1 hi, lo): four coalesced global_load_dwordx4 (1 KB each) per wave per stage, straight
+// into one of PP_WDEPTH + 1 rotating operand sets, PP_WDEPTH stages ahead of their use.  The stream (0.9 MB per launch)
+// is L2-resident; every fetch is amortised over the R residues of the workgroup.  No LDS hop, no M0, no hand-counted
+// waits: these are ordinary loads, hipcc counts them (vmcnt) itself.  The earlier LDS-DMA ring (pp_edge.hip's scheme)
+// needs M0 and a scalar base rewritten for every copy while earlier copies are still queued, which the hardware does not
+// interlock ("Split-f16"); with a wave alone on its SIMD there are registers to spare instead.
+// The chunk offset is made opaque and every stage starts with a scheduling barrier, so each fetch is issued where it is
+// written (as read-only kernel arguments the compiler would otherwise hoist all of them to the top of the kernel).
+#ifndef PP_WDEPTH
+#define PP_WDEPTH 3
+#endif
+#ifndef PP_NM_WGS
+#define PP_NM_WGS 1
+#endif
+#ifndef PP_WGS
+#define PP_WGS 1           // resident workgroups per CU the kernels are compiled for (register budget)
+#endif
+#define NRING (PP_WDEPTH + 1)
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
 
-// A operands of one stage in registers: [s0 hi, s0 lo, s1 hi, s1 lo].  Three such sets rotate (stage k computes from
-// set k % 3 while set (k+1) % 3 is being loaded): the set a load lands in was last read by the MFMAs of stage k - 2, which
-// have retired by then, so a returning load can never overwrite operands of an MFMA that is still queued.
+// A operands of one stage in registers: [s0 hi, s0 lo, s1 hi, s1 lo]
 struct AOp {
     h8 r[4];
 };
-__device__ __forceinline__ void load_A(const float *wslot, int lane, AOp &a) {
-    const h8 *w = reinterpret_cast<const h8 *>(wslot) + lane;
-    a.r[0] = w[0]; a.r[1] = w[64]; a.r[2] = w[128]; a.r[3] = w[192];
+__device__ __forceinline__ void gload_A(const h8 *__restrict__ wq, int chunk, AOp &a) {
+    int off = chunk * 1024;                  // h8 units per 16 KB chunk
+    asm volatile("" : "+s"(off));
+    const h8 *p = wq + off;
+    a.r[0] = p[0]; a.r[1] = p[64]; a.r[2] = p[128]; a.r[3] = p[192];
 }
-template <bool SWAP>
-__device__ __forceinline__ void mfma_chunk_r(const AOp &a, const HT &x, f32x16 &acc) {
+// R residues share the A operands (weights) of a stage: R independent accumulator chains, issued interleaved so that a
+// wave alone on its SIMD never waits on its own previous MFMA.  x[r][T] = input tile T of residue r.
+template <int R, int T, bool SWAP>
+__device__ __forceinline__ void mfma_x(const AOp &a, const HT (&x)[R][4], f32x16 (&acc)[R]) {
 #pragma unroll
     for (int s = 0; s < 2; s++) {
         if (SWAP) {
-            acc = MFMA16(x.hi[s], a.r[2 * s], acc);
-            acc = MFMA16(x.lo[s], a.r[2 * s], acc);
-            acc = MFMA16(x.hi[s], a.r[2 * s + 1], acc);
+#pragma unroll
+            for (int r = 0; r < R; r++) acc[r] = MFMA16(x[r][T].hi[s], a.r[2 * s], acc[r]);
+#pragma unroll
+            for (int r = 0; r < R; r++) acc[r] = MFMA16(x[r][T].lo[s], a.r[2 * s], acc[r]);
+#pragma unroll
+            for (int r = 0; r < R; r++) acc[r] = MFMA16(x[r][T].hi[s], a.r[2 * s + 1], acc[r]);
         } else {
-            acc = MFMA16(a.r[2 * s], x.hi[s], acc);
-            acc = MFMA16(a.r[2 * s], x.lo[s], acc);
-            acc = MFMA16(a.r[2 * s + 1], x.hi[s], acc);
+#pragma unroll
+            for (int r = 0; r < R; r++) acc[r] = MFMA16(a.r[2 * s], x[r][T].hi[s], acc[r]);
+#pragma unroll
+            for (int r = 0; r < R; r++) acc[r] = MFMA16(a.r[2 * s], x[r][T].lo[s], acc[r]);
+#pragma unroll
+            for (int r = 0; r < R; r++) acc[r] = MFMA16(a.r[2 * s + 1], x[r][T].hi[s], acc[r]);
         }
+    }
+}
+// same with one tile per residue (the FFN's hidden tiles, read from the exchange buffer stage by stage)
+template <int R>
+__device__ __forceinline__ void mfma_h(const AOp &a, const HT (&x)[R], f32x16 (&acc)[R]) {
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+#pragma unroll
+        for (int r = 0; r < R; r++) acc[r] = MFMA16(a.r[2 * s], x[r].hi[s], acc[r]);
+#pragma unroll
+        for (int r = 0; r < R; r++) acc[r] = MFMA16(a.r[2 * s], x[r].lo[s], acc[r]);
+#pragma unroll
+        for (int r = 0; r < R; r++) acc[r] = MFMA16(a.r[2 * s + 1], x[r].hi[s], acc[r]);
     }
 }
 // the 72 invariant-point features as operands: global k-step S = 0..4 carries features 16 S + 8 h + i (zero beyond 71);
@@ -151,14 +160,17 @@ __device__ __forceinline__ void mfma_chunk_r(const AOp &a, const HT &x, f32x16 &
 struct HG {
     h8 hi[5], lo[5];
 };
-template <int C>
-__device__ __forceinline__ void mfma_geo_r(const AOp &a, const HG &g, f32x16 &acc) {
+template <int R, int C>
+__device__ __forceinline__ void mfma_geo(const AOp &a, const HG (&g)[R], f32x16 (&acc)[R]) {
 #pragma unroll
     for (int s = 0; s < 2; s++) {
         if (2 * C + s < 5) {
-            acc = MFMA16(a.r[2 * s], g.hi[2 * C + s], acc);
-            acc = MFMA16(a.r[2 * s], g.lo[2 * C + s], acc);
-            acc = MFMA16(a.r[2 * s + 1], g.hi[2 * C + s], acc);
+#pragma unroll
+            for (int r = 0; r < R; r++) acc[r] = MFMA16(a.r[2 * s], g[r].hi[2 * C + s], acc[r]);
+#pragma unroll
+            for (int r = 0; r < R; r++) acc[r] = MFMA16(a.r[2 * s], g[r].lo[2 * C + s], acc[r]);
+#pragma unroll
+            for (int r = 0; r < R; r++) acc[r] = MFMA16(a.r[2 * s + 1], g[r].hi[2 * C + s], acc[r]);
         }
     }
 }
@@ -288,144 +300,178 @@ __device__ __forceinline__ void edge_geometry(const float *__restrict__ pts_i, c
         }
 }
 
-// one workgroup per CU: nothing else hides a copy's latency, so the ring is S slots deep -- stage k starts chunk k+S-1
-// into the slot stage k-1 read and waits, counted, until chunk k has landed (copies complete in issue order)
-template <int N>
-__device__ __forceinline__ void wait_vmN(unsigned laneoff) {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N), "v"(laneoff) : "memory");
-}
-#define WSTAGE(k, NCH, BODY)                                                                                   \
+// ACC names the accumulator array the stage's MFMAs chain on: the empty asm at the end uses one element of every chain,
+// which keeps the MFMAs inside their stage (they are pure, and instruction selection would otherwise let them sink past
+// the following stages' fetches, keeping every operand set alive).
+#define WSTAGE(k, NCH, ACC, BODY)                                                                              \
     {                                                                                                          \
-        if constexpr ((k) + S - 1 < (NCH)) dma_chunk(wsb, laneoff, slot0 + (((k) + S - 1) % S) * 4096u);       \
-        if constexpr ((k) + 1 < (NCH)) {      /* chunk k+1 has landed -> its A operands go to the next register set */ \
-            wait_vmN<4 * (((NCH) - 2 - (k)) < (S - 2) ? ((NCH) - 2 - (k)) : (S - 2))>(laneoff);                \
-            load_A(wl + (((k) + 1) % S) * 1024, lane, AR[((k) + 1) % 3]);                                      \
-        }                                                                                                      \
-        const AOp &AK = AR[(k) % 3];                                                                           \
-        HT &HK = HR[(k) % 3];                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        if constexpr ((k) + PP_WDEPTH < (NCH)) gload_A(wq, (k) + PP_WDEPTH, AR[((k) + PP_WDEPTH) % NRING]);    \
+        const AOp &AK = AR[(k) % NRING];                                                                       \
         BODY;                                                                                                  \
+        _Pragma("unroll") for (int r_ = 0; r_ < R; r_++) asm volatile("" ::"v"(ACC[r_][0]));                   \
     }
+
+// publish this wave's tile of every residue (ReLU, split) and meet the other waves
+#ifdef PP_X_DRAIN
+#define MFMA_DRAIN() asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory")
+#else
+#define MFMA_DRAIN()
+#endif
+#define PUBLISH_RELU()                                                            \
+    MFMA_DRAIN();                                                                 \
+    _Pragma("unroll") for (int r = 0; r < R; r++) {                               \
+        HT ht;                                                                    \
+        relu_tile(acc[r]);                                                        \
+        split_tile(acc[r], ht);                                                   \
+        xbuf_put_h(xbuf + r * XBUF_FLOATS, wave, lane, ht);                       \
+    }                                                                             \
+    __syncthreads();
+#define FETCH_X()                                                                 \
+    _Pragma("unroll") for (int r = 0; r < R; r++)                                 \
+        _Pragma("unroll") for (int t = 0; t < 4; t++) xbuf_get_h(xbuf + r * XBUF_FLOATS, t, lane, x[r][t]);
 
 // shared first layer: acc (tile `wave`) = PA_i + PC_j + W_B h_E + W_G geom, ReLU.  Chunks W_B x4 (absent when ST0:
 // layer 0's W_B h_E0 is timestep-invariant and arrives precomputed in acc), then W_G x3.  C0 = number of W_B chunks.
 #define FIRST_LAYER(NCH)                                                          \
     if constexpr (!ST0) {                                                         \
-        WSTAGE(0, NCH, mfma_chunk_r<false>(AK, x[0], acc))                 \
-        WSTAGE(1, NCH, mfma_chunk_r<false>(AK, x[1], acc))                 \
-        WSTAGE(2, NCH, mfma_chunk_r<false>(AK, x[2], acc))                 \
-        WSTAGE(3, NCH, mfma_chunk_r<false>(AK, x[3], acc))                 \
+        WSTAGE(0, NCH, acc, (mfma_x<R, 0, false>(AK, x, acc)))                         \
+        WSTAGE(1, NCH, acc, (mfma_x<R, 1, false>(AK, x, acc)))                         \
+        WSTAGE(2, NCH, acc, (mfma_x<R, 2, false>(AK, x, acc)))                         \
+        WSTAGE(3, NCH, acc, (mfma_x<R, 3, false>(AK, x, acc)))                         \
     }                                                                             \
-    WSTAGE(C0 + 0, NCH, mfma_geo_r<0>(AK, g, acc))                         \
-    WSTAGE(C0 + 1, NCH, mfma_geo_r<1>(AK, g, acc))                         \
-    WSTAGE(C0 + 2, NCH, mfma_geo_r<2>(AK, g, acc))                         \
-    relu_tile(acc);                                                               \
-    split_tile(acc, ht);                                                          \
-    xbuf_put_h(xbuf, wave, lane, ht);                                             \
-    __syncthreads();
+    WSTAGE(C0 + 0, NCH, acc, (mfma_geo<R, 0>(AK, g, acc)))                             \
+    WSTAGE(C0 + 1, NCH, acc, (mfma_geo<R, 1>(AK, g, acc)))                             \
+    WSTAGE(C0 + 2, NCH, acc, (mfma_geo<R, 2>(AK, g, acc)))                             \
+    PUBLISH_RELU()
 
-#define PROLOGUE_PIPE()                                                                        \
-    static_assert(S >= 3, "the operand prefetch reads slot k+1 while slot k+S-1 is refilled");  \
-    const float *wsb = A.wstream + wave * 1024;          /* running chunk pointer, wave-uniform: SGPRs */ \
-    unsigned laneoff = (unsigned)lane * 16u;              /* the one per-lane address register */ \
-    const float *wl = smem + wave * (S * 1024);                                                \
-    const unsigned slot0 = (unsigned)(size_t)wl;                                               \
-    AOp AR[3];                                                                                 \
-    HT HR[3];                                                                                  \
-    _Pragma("unroll") for (int pk = 0; pk < S - 1; pk++) dma_chunk(wsb, laneoff, slot0 + pk * 4096u);
-// after the prologue's own loads have been issued: chunk 0's operands into the first register set
-#define PROLOGUE_OPERANDS()                                                                    \
-    wait_vmN<4 * (S - 2)>(laneoff);                                                            \
-    load_A(wl, lane, AR[0]);
+#define PROLOGUE_PIPE(NCH)                                                                                     \
+    const h8 *wq = reinterpret_cast<const h8 *>(A.wstream) + wave * 256 + lane;    /* this wave's quarter, this lane */ \
+    AOp AR[NRING];                                                                                             \
+    _Pragma("unroll") for (int pk = 0; pk < PP_WDEPTH && pk < (NCH); pk++) gload_A(wq, pk, AR[pk]);
+#define PROLOGUE_OPERANDS()
+
+// The R residues of workgroup b are rows b R .. b R + R - 1.  `live` = in range and not masked; a dead slot computes on
+// a live residue's inputs (no garbage enters the pipes) and stores nothing.  All of it is wave-uniform.
+#define GROUP_SETUP()                                                                          \
+    int n[R];                                                                                  \
+    bool live[R], inr[R];                                                                      \
+    int first = -1;                                                                            \
+    _Pragma("unroll") for (int r = 0; r < R; r++) {                                            \
+        const int nr = blockIdx.x * R + r;                                                     \
+        inr[r] = nr < A.N;                                                                     \
+        n[r] = inr[r] ? nr : A.N - 1;                                                          \
+        live[r] = inr[r] && A.rmask[n[r]] != 0.f;                                              \
+        if (live[r] && first < 0) first = n[r];                                                \
+    }
 
 // ---------------------------------------------------------------------------------------------
 // node message: S[i] = (1/K) sum_j mask_ij relu(W_mid relu(W_in [..]) + b), msum[i] = (1/K) sum_j mask_ij
 // ---------------------------------------------------------------------------------------------
-// Shipped configuration: ONE workgroup per CU (one wave per SIMD), LDS-DMA ring of 5 / 4 slots per wave.  With several
-// waves interleaving on a SIMD the split-f16 kernels produced rare wrong tiles (see HAZARD notes); with one wave per
-// SIMD they have been bit-reproducible over millions of workgroup launches (tools/debug/soak.py).  The LDS requests
-// (96 KB / 84.5 KB) are what enforces the exclusivity.
+// ONE workgroup per CU (one wave per SIMD), enforced by the LDS request (ring + R exchange buffers > 80 KB).
 #ifndef PP_NM_SLOTS
 #define PP_NM_SLOTS 5
 #endif
 #ifndef PP_EU_SLOTS
 #define PP_EU_SLOTS 4
 #endif
-#ifndef PP_EU_WGS
-#define PP_EU_WGS 1
-#endif
-#ifndef PP_NM_WGS
-#define PP_NM_WGS 1
-#endif
 
-template <int S, bool ST0>
+template <int S, int R, bool ST0>
 __global__ void __launch_bounds__(ET, PP_NM_WGS)
 k_node_message(EdgeArgs A) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *xbuf = smem + 4 * S * 1024;
+    float *xbuf = smem;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, h = lane >> 5;
-    const int n = blockIdx.x;
     const int K = A.K;
-    if (A.rmask[n] == 0.f) {              // masked / padded residue: whole workgroup leaves
-        if (tid < 128) A.S[(size_t)n * 128 + tid] = 0.f;
-        if (tid == 0) A.msum[n] = 0.f;
-        return;
-    }
+    GROUP_SETUP()
+#pragma unroll
+    for (int r = 0; r < R; r++)
+        if (inr[r] && !live[r]) {         // masked / padded residue
+            if (tid < 128) A.S[(size_t)n[r] * 128 + tid] = 0.f;
+            if (tid == 0) A.msum[n[r]] = 0.f;
+        }
+    if (first < 0) return;
+#pragma unroll
+    for (int r = 0; r < R; r++)
+        if (!live[r]) n[r] = first;
     constexpr int C0 = ST0 ? 0 : 4;
     constexpr int NCH = C0 + 7;           // chunks: [W_B x4,] W_G x3, W_mid x4
-    PROLOGUE_PIPE()
+    PROLOGUE_PIPE(NCH)
 
-    HT x[4], ht;
-    f32x16 acc;
-    HG g;
+    HT x[R][4];
+    f32x16 acc[R];
+    HG g[R];
     const int jj = j < K ? j : K - 1;
-    const int nbr = A.eidx[(size_t)n * K + jj];
     const float bmid = A.b_mid[32 * wave + j];            // SWAP form: feature on the lane
-    float m16[16];
-    {
-        const float *mrow = A.mask_att + (size_t)n * 32;
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            f32x4v mm = *reinterpret_cast<const f32x4v *>(mrow + 8 * q + 4 * h);
-            m16[4 * q] = mm[0]; m16[4 * q + 1] = mm[1]; m16[4 * q + 2] = mm[2]; m16[4 * q + 3] = mm[3];
-        }
-    }
-    edge_geometry(A.pts + (size_t)n * 48, A.frames + (size_t)n * 12, A.pts + (size_t)nbr * 48, h, g);
-    {
-        const float *hrow = A.hE_in + ((size_t)n * K + jj) * 128;
+    for (int r = 0; r < R; r++) {
+        const int nbr = A.eidx[(size_t)n[r] * K + jj];
+        edge_geometry(A.pts + (size_t)n[r] * 48, A.frames + (size_t)n[r] * 12, A.pts + (size_t)nbr * 48, h, g[r]);
+        const float *hrow = A.hE_in + ((size_t)n[r] * K + jj) * 128;
         if constexpr (!ST0) {
 #pragma unroll
-            for (int t = 0; t < 4; t++) { load_tile(hrow + 32 * t, h, acc); split_tile(acc, x[t]); }
+            for (int t = 0; t < 4; t++) { load_tile(hrow + 32 * t, h, acc[r]); split_tile(acc[r], x[r][t]); }
         }
-        load_tile(A.PA + (size_t)n * 128 + 32 * wave, h, acc);
-        add_tile(A.PC + (size_t)nbr * 128 + 32 * wave, h, acc);
-        if constexpr (ST0) add_tile(A.Z + ((size_t)n * K + jj) * 128 + 32 * wave, h, acc);
+        load_tile(A.PA + (size_t)n[r] * 128 + 32 * wave, h, acc[r]);
+        add_tile(A.PC + (size_t)nbr * 128 + 32 * wave, h, acc[r]);
+        if constexpr (ST0) add_tile(A.Z + ((size_t)n[r] * K + jj) * 128 + 32 * wave, h, acc[r]);
+    }
+    float dv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (A.dbg) {
+        dv[0] = (float)A.eidx[(size_t)n[0] * K + jj];
+        for (int q = 0; q < 16; q++) dv[1] += acc[0][q];
+        for (int S5 = 0; S5 < 5; S5++)
+            for (int i = 0; i < 8; i++) dv[2] += (float)g[0].hi[S5][i] + (float)g[0].lo[S5][i];
     }
     PROLOGUE_OPERANDS()
     FIRST_LAYER(NCH)
-    {
+    if (A.dbg)
+        for (int q = 0; q < 16; q++) dv[3] += acc[0][q];
+    FETCH_X()
+    if (A.dbg)
+        for (int t = 0; t < 4; t++)
+            for (int s2 = 0; s2 < 2; s2++)
+                for (int i = 0; i < 8; i++) dv[4] += (float)x[0][t].hi[s2][i] + (float)x[0][t].lo[s2][i];
 #pragma unroll
-        for (int t = 0; t < 4; t++) xbuf_get_h(xbuf, t, lane, x[t]);
+    for (int r = 0; r < R; r++)
 #pragma unroll
-        for (int r = 0; r < 16; r++) acc[r] = bmid;
-    }
-    WSTAGE(C0 + 3, NCH, mfma_chunk_r<true>(AK, x[0], acc))
-    WSTAGE(C0 + 4, NCH, mfma_chunk_r<true>(AK, x[1], acc))
-    WSTAGE(C0 + 5, NCH, mfma_chunk_r<true>(AK, x[2], acc))
-    WSTAGE(C0 + 6, NCH, mfma_chunk_r<true>(AK, x[3], acc))
-    {
+        for (int q = 0; q < 16; q++) acc[r][q] = bmid;
+    WSTAGE(C0 + 3, NCH, acc, (mfma_x<R, 0, true>(AK, x, acc)))
+    WSTAGE(C0 + 4, NCH, acc, (mfma_x<R, 1, true>(AK, x, acc)))
+    WSTAGE(C0 + 5, NCH, acc, (mfma_x<R, 2, true>(AK, x, acc)))
+    WSTAGE(C0 + 6, NCH, acc, (mfma_x<R, 3, true>(AK, x, acc)))
+    MFMA_DRAIN();
+#pragma unroll
+    for (int r = 0; r < R; r++) {
         // rows (registers) are edges e = 8 (r>>2) + 4 h + (r&3); mask and reduce over them
+        const float *mrow = A.mask_att + (size_t)n[r] * 32 + 4 * h;
         float s = 0.f, ms = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            s = fmaf(fmaxf(acc[r], 0.f), m16[r], s);
-            ms += m16[r];
+        for (int q = 0; q < 4; q++) {
+            const f32x4v mm = *reinterpret_cast<const f32x4v *>(mrow + 8 * q);
+#pragma unroll
+            for (int pq = 0; pq < 4; pq++) {
+                s = fmaf(fmaxf(acc[r][4 * q + pq], 0.f), mm[pq], s);
+                ms += mm[pq];
+            }
+        }
+        if (A.dbg && r == 0) {
+            for (int q = 0; q < 16; q++) dv[5] += acc[0][q];
+            dv[6] = s;
         }
         s += __shfl_xor(s, 32);
         ms += __shfl_xor(ms, 32);
-        if (h == 0) A.S[(size_t)n * 128 + 32 * wave + j] = s * A.inv_K;
-        if (tid == 0) A.msum[n] = ms * A.inv_K;
+        if (A.dbg && r == 0) {
+            dv[7] = s;
+            float *d = A.dbg + (((size_t)n[0] * 4 + wave) * 64 + lane) * 8;
+            for (int q = 0; q < 8; q++) d[q] = dv[q];
+        }
+        if (live[r]) {
+            if (h == 0) A.S[(size_t)n[r] * 128 + 32 * wave + j] = s * A.inv_K;
+            if (tid == 0) A.msum[n[r]] = ms * A.inv_K;
+        }
     }
 }
 
@@ -433,65 +479,68 @@ k_node_message(EdgeArgs A) {
 // edge update: h_E <- mask * LN3(x1 + FFN(x1)),  x1 = LN2(h_E + mask * MLP3([..]))
 // ---------------------------------------------------------------------------------------------
 // FFN hidden block c (chunks 15 + 8c ..): W1 s=0..3 -> hidden tile 4c+wave -> exchange -> W2 s'=0..3 accumulate into out
+#define FFN_W2(kk, t)                                                                                        \
+    WSTAGE(kk, NCH, out, {                                                                                   \
+        HT hk[R];                                                                                            \
+        _Pragma("unroll") for (int r = 0; r < R; r++) xbuf_get_h(xbuf + r * XBUF_FLOATS, t, lane, hk[r]);    \
+        mfma_h<R>(AK, hk, out);                                                                              \
+    })
 #define FFN_BLOCK(c)                                                                                         \
-    load_tile(prm + P_FIB + 128 * (c) + 32 * wave, h, acc);                                                  \
-    WSTAGE(C0 + 11 + 8 * (c) + 0, NCH, mfma_chunk_r<false>(AK, x[0], acc))                                \
-    WSTAGE(C0 + 11 + 8 * (c) + 1, NCH, mfma_chunk_r<false>(AK, x[1], acc))                                \
-    WSTAGE(C0 + 11 + 8 * (c) + 2, NCH, mfma_chunk_r<false>(AK, x[2], acc))                                \
-    WSTAGE(C0 + 11 + 8 * (c) + 3, NCH, mfma_chunk_r<false>(AK, x[3], acc))                                \
-    relu_tile(acc);                                                                                          \
-    split_tile(acc, ht);                                                                                     \
+    _Pragma("unroll") for (int r = 0; r < R; r++) load_tile(prm + P_FIB + 128 * (c) + 32 * wave, h, acc[r]); \
+    WSTAGE(C0 + 11 + 8 * (c) + 0, NCH, acc, (mfma_x<R, 0, false>(AK, x, acc)))                                   \
+    WSTAGE(C0 + 11 + 8 * (c) + 1, NCH, acc, (mfma_x<R, 1, false>(AK, x, acc)))                                   \
+    WSTAGE(C0 + 11 + 8 * (c) + 2, NCH, acc, (mfma_x<R, 2, false>(AK, x, acc)))                                   \
+    WSTAGE(C0 + 11 + 8 * (c) + 3, NCH, acc, (mfma_x<R, 3, false>(AK, x, acc)))                                   \
     __syncthreads();          /* every wave is done reading the previous exchange */                        \
-    xbuf_put_h(xbuf, wave, lane, ht);                                                                        \
-    __syncthreads();                                                                                         \
-    WSTAGE(C0 + 11 + 8 * (c) + 4, NCH, xbuf_get_h(xbuf, 0, lane, HK); mfma_chunk_r<false>(AK, HK, out))   \
-    WSTAGE(C0 + 11 + 8 * (c) + 5, NCH, xbuf_get_h(xbuf, 1, lane, HK); mfma_chunk_r<false>(AK, HK, out))   \
-    WSTAGE(C0 + 11 + 8 * (c) + 6, NCH, xbuf_get_h(xbuf, 2, lane, HK); mfma_chunk_r<false>(AK, HK, out))   \
-    WSTAGE(C0 + 11 + 8 * (c) + 7, NCH, xbuf_get_h(xbuf, 3, lane, HK); mfma_chunk_r<false>(AK, HK, out))
+    PUBLISH_RELU()                                                                                           \
+    FFN_W2(C0 + 11 + 8 * (c) + 4, 0)                                                                         \
+    FFN_W2(C0 + 11 + 8 * (c) + 5, 1)                                                                         \
+    FFN_W2(C0 + 11 + 8 * (c) + 6, 2)                                                                         \
+    FFN_W2(C0 + 11 + 8 * (c) + 7, 3)
 
-// FUSE (-DPP_FUSE_NM, OFF by default): the workgroup goes straight on to the NEXT layer's node message of its residue
-// (same 32 edges, whose new h_E it holds; the node-level inputs PA2 / PC2 / pts2 were written by the node update that
-// ran before this kernel): one launch, one prologue and one read of h_E less per layer (~5 % of a step).  Disabled in
-// the split-f16 build: with several workgroups per CU the fused tail produced rare wrong S rows (about one workgroup
-// in a thousand, never with one workgroup per CU, h_E itself always bit-exact) that survived every fix of the LDS-DMA
-// hazards below and also show without LDS-DMA; the stand-alone node-message kernel, same code, is bit-reproducible
-// (tools/debug/edge_repro.py, score_check3.py).  Unresolved -> not shipped.
-template <int S, bool ST0, bool FUSE>
-__global__ void __launch_bounds__(ET, PP_EU_WGS)
+// FUSE: the workgroup goes straight on to the NEXT layer's node message of its residues (same edges, whose new h_E it
+// holds; the node-level inputs PA2 / PC2 / pts2 were written by the node update that ran before this kernel): one
+// launch, one prologue and one read of h_E less per layer.
+template <int S, int R, bool ST0, bool FUSE>
+__global__ void __launch_bounds__(ET, PP_WGS)
 k_edge_update(EdgeArgs A) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *xbuf = smem + 4 * S * 1024, *prm = xbuf + XBUF_FLOATS;
+    float *xbuf = smem, *prm = xbuf + R * XBUF_FLOATS;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, h = lane >> 5;
-    const int n = blockIdx.x;
     const int K = A.K;
     const int jj = j < K ? j : K - 1;
-    if (A.rmask[n] == 0.f) {              // masked / padded residue: its edges are zero, whole workgroup leaves
-        if (j < K) {
-            f32x4v z = {0.f, 0.f, 0.f, 0.f};
-            float *orow = A.hE_out + ((size_t)n * K + j) * 128 + 32 * wave;
+    GROUP_SETUP()
 #pragma unroll
-            for (int q = 0; q < 4; q++) *reinterpret_cast<f32x4v *>(orow + 8 * q + 4 * h) = z;
+    for (int r = 0; r < R; r++)
+        if (inr[r] && !live[r]) {         // masked / padded residue: its edges are zero
+            if (j < K) {
+                f32x4v z = {0.f, 0.f, 0.f, 0.f};
+                float *orow = A.hE_out + ((size_t)n[r] * K + j) * 128 + 32 * wave;
+#pragma unroll
+                for (int q = 0; q < 4; q++) *reinterpret_cast<f32x4v *>(orow + 8 * q + 4 * h) = z;
+            }
+            if constexpr (FUSE) {
+                if (tid < 128) A.S[(size_t)n[r] * 128 + tid] = 0.f;
+                if (tid == 0) A.msum[n[r]] = 0.f;
+            }
         }
-        if constexpr (FUSE) {
-            if (tid < 128) A.S[(size_t)n * 128 + tid] = 0.f;
-            if (tid == 0) A.msum[n] = 0.f;
-        }
-        return;
-    }
+    if (first < 0) return;
+#pragma unroll
+    for (int r = 0; r < R; r++)
+        if (!live[r]) n[r] = first;
     // chunks: [W_B x4,] W_G x3, W_mid x4, W_out x4, then per hidden block c: W1 x4, W2 x4
     constexpr int C0 = ST0 ? 0 : 4;
     constexpr int NEU = C0 + 43;                       // chunks of the edge update itself
     constexpr int NCH = NEU + (FUSE ? 11 : 0);         // + W_B x4, W_G x3, W_mid x4 of the next node message
-    PROLOGUE_PIPE()
+    PROLOGUE_PIPE(NCH)
 
-    HT x[4], ht;
-    f32x16 acc, out;
-    HG g;
-    const float *hrow = A.hE_in + ((size_t)n * K + jj) * 128;
-    const int nbr = A.eidx[(size_t)n * K + jj];
-    const float me = A.mask_att[(size_t)n * 32 + jj];          // (lanes j >= K mirror edge K - 1 throughout)
+    HT x[R][4];
+    f32x16 acc[R], out[R];
+    HG g[R];
+    int nbr[R];
+    float me[R];
     // the small per-layer vectors go to LDS once (published by the first exchange barrier)
     // (no divergent control flow while a weight copy is in flight -- see HAZARD: the surplus threads of the second trip
     //  rewrite the last float4 with the same value instead of being masked off)
@@ -500,68 +549,65 @@ k_edge_update(EdgeArgs A) {
         const int i = min(tid + it * ET, PARAM_FLOATS / 4 - 1);
         *reinterpret_cast<f32x4v *>(prm + 4 * i) = *reinterpret_cast<const f32x4v *>(A.params + 4 * i);
     }
-    edge_geometry(A.pts + (size_t)n * 48, A.frames + (size_t)n * 12, A.pts + (size_t)nbr * 48, h, g);
-    __builtin_amdgcn_sched_barrier(0);        // geometry temporaries die before the activation tiles are loaded
-    {
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        nbr[r] = A.eidx[(size_t)n[r] * K + jj];
+        me[r] = A.mask_att[(size_t)n[r] * 32 + jj];            // (lanes j >= K mirror edge K - 1 throughout)
+        edge_geometry(A.pts + (size_t)n[r] * 48, A.frames + (size_t)n[r] * 12, A.pts + (size_t)nbr[r] * 48, h, g[r]);
+        const float *hrow = A.hE_in + ((size_t)n[r] * K + jj) * 128;
         if constexpr (!ST0) {
 #pragma unroll
-            for (int t = 0; t < 4; t++) { load_tile(hrow + 32 * t, h, acc); split_tile(acc, x[t]); }
+            for (int t = 0; t < 4; t++) { load_tile(hrow + 32 * t, h, acc[r]); split_tile(acc[r], x[r][t]); }
         }
-        load_tile(A.PA + (size_t)n * 128 + 32 * wave, h, acc);
-        add_tile(A.PC + (size_t)nbr * 128 + 32 * wave, h, acc);
-        if constexpr (ST0) add_tile(A.Z + ((size_t)n * K + jj) * 128 + 32 * wave, h, acc);
+        load_tile(A.PA + (size_t)n[r] * 128 + 32 * wave, h, acc[r]);
+        add_tile(A.PC + (size_t)nbr[r] * 128 + 32 * wave, h, acc[r]);
+        if constexpr (ST0) add_tile(A.Z + ((size_t)n[r] * K + jj) * 128 + 32 * wave, h, acc[r]);
     }
     PROLOGUE_OPERANDS()
     FIRST_LAYER(NCH)
     // ---- second layer (chunks 7..10) -------------------------------------------------------------
-    {
+    FETCH_X()
 #pragma unroll
-        for (int t = 0; t < 4; t++) xbuf_get_h(xbuf, t, lane, x[t]);
-        load_tile(prm + P_BMID + 32 * wave, h, acc);
-    }
-    WSTAGE(C0 + 3, NCH, mfma_chunk_r<false>(AK, x[0], acc))
-    WSTAGE(C0 + 4, NCH, mfma_chunk_r<false>(AK, x[1], acc))
-    WSTAGE(C0 + 5, NCH, mfma_chunk_r<false>(AK, x[2], acc))
-    WSTAGE(C0 + 6, NCH, mfma_chunk_r<false>(AK, x[3], acc))
-    relu_tile(acc);
-    split_tile(acc, ht);
+    for (int r = 0; r < R; r++) load_tile(prm + P_BMID + 32 * wave, h, acc[r]);
+    WSTAGE(C0 + 3, NCH, acc, (mfma_x<R, 0, false>(AK, x, acc)))
+    WSTAGE(C0 + 4, NCH, acc, (mfma_x<R, 1, false>(AK, x, acc)))
+    WSTAGE(C0 + 5, NCH, acc, (mfma_x<R, 2, false>(AK, x, acc)))
+    WSTAGE(C0 + 6, NCH, acc, (mfma_x<R, 3, false>(AK, x, acc)))
     __syncthreads();
-    xbuf_put_h(xbuf, wave, lane, ht);
-    __syncthreads();
+    PUBLISH_RELU()
     // ---- third layer (chunks 11..14) --------------------------------------------------------------
-    {
+    FETCH_X()
 #pragma unroll
-        for (int t = 0; t < 4; t++) xbuf_get_h(xbuf, t, lane, x[t]);
-        load_tile(prm + P_BOUT + 32 * wave, h, acc);
-    }
-    WSTAGE(C0 + 7, NCH, mfma_chunk_r<false>(AK, x[0], acc))
-    WSTAGE(C0 + 8, NCH, mfma_chunk_r<false>(AK, x[1], acc))
-    WSTAGE(C0 + 9, NCH, mfma_chunk_r<false>(AK, x[2], acc))
-    WSTAGE(C0 + 10, NCH, mfma_chunk_r<false>(AK, x[3], acc))
+    for (int r = 0; r < R; r++) load_tile(prm + P_BOUT + 32 * wave, h, acc[r]);
+    WSTAGE(C0 + 7, NCH, acc, (mfma_x<R, 0, false>(AK, x, acc)))
+    WSTAGE(C0 + 8, NCH, acc, (mfma_x<R, 1, false>(AK, x, acc)))
+    WSTAGE(C0 + 9, NCH, acc, (mfma_x<R, 2, false>(AK, x, acc)))
+    WSTAGE(C0 + 10, NCH, acc, (mfma_x<R, 3, false>(AK, x, acc)))
     // publish v = h_E + mask * m for the first LayerNorm (own tile: read, then overwritten in place)
-    load_tile(hrow + 32 * wave, h, out);        // residual input: this wave's tile of h_E (L2-resident re-read)
 #pragma unroll
-    for (int r = 0; r < 16; r++) out[r] = fmaf(acc[r], me, out[r]);
+    for (int r = 0; r < R; r++) {
+        load_tile(A.hE_in + ((size_t)n[r] * K + jj) * 128 + 32 * wave, h, out[r]);   // residual (L2-resident re-read)
+#pragma unroll
+        for (int q = 0; q < 16; q++) out[r][q] = fmaf(acc[r][q], me[r], out[r][q]);
+    }
     __syncthreads();                            // every wave has its B operands of this layer
-    xbuf_put(xbuf, wave, lane, out);
+#pragma unroll
+    for (int r = 0; r < R; r++) xbuf_put(xbuf + r * XBUF_FLOATS, wave, lane, out[r]);
     __syncthreads();
-    {
+#pragma unroll
+    for (int r = 0; r < R; r++) {
         // x1 = LN2(v): every wave normalises the full vector in fp32 (it needs all of x1 as B operands), then splits it
         f32x16 v4[4];
 #pragma unroll
-        for (int t = 0; t < 4; t++) xbuf_get(xbuf, t, lane, v4[t]);
+        for (int t = 0; t < 4; t++) xbuf_get(xbuf + r * XBUF_FLOATS, t, lane, v4[t]);
         float mean;
         float rstd = ln_center(v4, mean);
 #pragma unroll
         for (int t = 0; t < 4; t++) {
-            // compiler fence tied to the data flow: the gamma / beta reads of tile t are issued only once rstd (and the
-            // previous tile) exist, so one tile's worth of them is live at a time (168-VGPR budget)
-            if (t == 0) asm volatile("" : "+v"(rstd) : : "memory");
-            else asm volatile("" : "+v"(v4[t > 0 ? t - 1 : 0][15]) : : "memory");
             ln_affine_tile(v4[t], rstd, prm + P_G2 + 32 * t, prm + P_BE2 + 32 * t, h);
-            split_tile(v4[t], x[t]);
+            split_tile(v4[t], x[r][t]);
         }
-        load_tile(prm + P_FOB + 32 * wave, h, out);
+        load_tile(prm + P_FOB + 32 * wave, h, out[r]);
     }
     // ---- FFN 128 -> 512 -> 128 in four hidden blocks of 128 ------------------------------------------
     FFN_BLOCK(0)
@@ -570,97 +616,110 @@ k_edge_update(EdgeArgs A) {
     FFN_BLOCK(3)
     // ---- h_E = mask * LN3(x1 + ffn) ---------------------------------------------------------------------
     // residual: this wave's tile of x1, rebuilt from its split form (wave is scalar: uniform branches, static indices)
-    if (wave == 0) join_tile(x[0], acc);
-    else if (wave == 1) join_tile(x[1], acc);
-    else if (wave == 2) join_tile(x[2], acc);
-    else join_tile(x[3], acc);
 #pragma unroll
-    for (int r = 0; r < 16; r++) out[r] += acc[r];
-    __syncthreads();
-    xbuf_put(xbuf, wave, lane, out);
-    __syncthreads();
-    float mean3, rstd;
-    {
-        f32x16 v4[4];
+    for (int r = 0; r < R; r++) {
+        if (wave == 0) join_tile(x[r][0], acc[r]);
+        else if (wave == 1) join_tile(x[r][1], acc[r]);
+        else if (wave == 2) join_tile(x[r][2], acc[r]);
+        else join_tile(x[r][3], acc[r]);
 #pragma unroll
-        for (int t = 0; t < 4; t++) xbuf_get(xbuf, t, lane, v4[t]);
-        rstd = ln_center(v4, mean3);
+        for (int q = 0; q < 16; q++) out[r][q] += acc[r][q];
     }
+    __syncthreads();
 #pragma unroll
-    for (int r = 0; r < 16; r++) out[r] -= mean3;
-    ln_affine_tile(out, rstd, A.g3 + 32 * wave, A.be3 + 32 * wave, h);
+    for (int r = 0; r < R; r++) xbuf_put(xbuf + r * XBUF_FLOATS, wave, lane, out[r]);
+    __syncthreads();
 #pragma unroll
-    for (int r = 0; r < 16; r++) out[r] *= me;
-    // lanes j >= K mirror edge K - 1 (same inputs, same value): they store it again rather than being masked off
-    store_tile(A.hE_out + ((size_t)n * K + jj) * 128 + 32 * wave, h, out);
+    for (int r = 0; r < R; r++) {
+        float mean3, rstd;
+        {
+            f32x16 v4[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) xbuf_get(xbuf + r * XBUF_FLOATS, t, lane, v4[t]);
+            rstd = ln_center(v4, mean3);
+        }
+#pragma unroll
+        for (int q = 0; q < 16; q++) out[r][q] -= mean3;
+        ln_affine_tile(out[r], rstd, A.g3 + 32 * wave, A.be3 + 32 * wave, h);
+#pragma unroll
+        for (int q = 0; q < 16; q++) out[r][q] *= me[r];
+        // lanes j >= K mirror edge K - 1 (same inputs, same value): they store it again rather than being masked off
+        if (live[r]) store_tile(A.hE_out + ((size_t)n[r] * K + jj) * 128 + 32 * wave, h, out[r]);
+    }
     if constexpr (FUSE) {
         // ---- next layer's node message on the fresh edges ------------------------------------------------
-        // its inputs are fetched here and not earlier: offsets made opaque behind `out` (scalar ones stay scalar)
-        int o_pts = n * 48, o_fr = n * 12, o_pa = n * 128;
-        int o_ptsj = nbr * 48, o_pc = nbr * 128;
-        split_tile(out, ht);
         __syncthreads();                                      // every wave has read the LayerNorm exchange
-        xbuf_put_h(xbuf, wave, lane, ht);
-        // `out` is dead from here; the fence keeps the input fetches below it (they would otherwise be hoisted to the
-        // top of the kernel), and the geometry arithmetic fills the wait for the other waves' tiles
-        asm volatile("" : "+s"(o_pts), "+s"(o_fr), "+s"(o_pa), "+v"(o_ptsj), "+v"(o_pc) : : "memory");
-        edge_geometry(A.pts2 + o_pts, A.frames + o_fr, A.pts2 + o_ptsj, h, g);
-        load_tile(A.PA2 + o_pa + 32 * wave, h, acc);
-        add_tile(A.PC2 + o_pc + 32 * wave, h, acc);
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            HT ht;
+            split_tile(out[r], ht);
+            xbuf_put_h(xbuf + r * XBUF_FLOATS, wave, lane, ht);
+        }
+        // `out` is dead from here; its inputs are fetched here and not earlier: offsets made opaque behind `out`
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            int o_pts = n[r] * 48, o_fr = n[r] * 12, o_pa = n[r] * 128;
+            int o_ptsj = nbr[r] * 48, o_pc = nbr[r] * 128;
+            asm volatile("" : "+s"(o_pts), "+s"(o_fr), "+s"(o_pa), "+v"(o_ptsj), "+v"(o_pc) : "v"(out[r][0]) : "memory");
+            edge_geometry(A.pts2 + o_pts, A.frames + o_fr, A.pts2 + o_ptsj, h, g[r]);
+            load_tile(A.PA2 + o_pa + 32 * wave, h, acc[r]);
+            add_tile(A.PC2 + o_pc + 32 * wave, h, acc[r]);
+        }
         const float bmid = A.b_mid2[32 * wave + j];           // SWAP form: feature on the lane
-        __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
-#pragma unroll
-        for (int t = 0; t < 4; t++) xbuf_get_h(xbuf, t, lane, x[t]);
-        WSTAGE(NEU + 0, NCH, mfma_chunk_r<false>(AK, x[0], acc))
-        WSTAGE(NEU + 1, NCH, mfma_chunk_r<false>(AK, x[1], acc))
-        WSTAGE(NEU + 2, NCH, mfma_chunk_r<false>(AK, x[2], acc))
-        WSTAGE(NEU + 3, NCH, mfma_chunk_r<false>(AK, x[3], acc))
-        WSTAGE(NEU + 4, NCH, mfma_geo_r<0>(AK, g, acc))
-        WSTAGE(NEU + 5, NCH, mfma_geo_r<1>(AK, g, acc))
-        WSTAGE(NEU + 6, NCH, mfma_geo_r<2>(AK, g, acc))
-        relu_tile(acc);
-        split_tile(acc, ht);
+        FETCH_X()
+        WSTAGE(NEU + 0, NCH, acc, (mfma_x<R, 0, false>(AK, x, acc)))
+        WSTAGE(NEU + 1, NCH, acc, (mfma_x<R, 1, false>(AK, x, acc)))
+        WSTAGE(NEU + 2, NCH, acc, (mfma_x<R, 2, false>(AK, x, acc)))
+        WSTAGE(NEU + 3, NCH, acc, (mfma_x<R, 3, false>(AK, x, acc)))
+        WSTAGE(NEU + 4, NCH, acc, (mfma_geo<R, 0>(AK, g, acc)))
+        WSTAGE(NEU + 5, NCH, acc, (mfma_geo<R, 1>(AK, g, acc)))
+        WSTAGE(NEU + 6, NCH, acc, (mfma_geo<R, 2>(AK, g, acc)))
         __syncthreads();
-        xbuf_put_h(xbuf, wave, lane, ht);
-        __syncthreads();
+        PUBLISH_RELU()
+        FETCH_X()
 #pragma unroll
-        for (int t = 0; t < 4; t++) xbuf_get_h(xbuf, t, lane, x[t]);
+        for (int r = 0; r < R; r++)
 #pragma unroll
-        for (int r = 0; r < 16; r++) acc[r] = bmid;
-        WSTAGE(NEU + 7, NCH, mfma_chunk_r<true>(AK, x[0], acc))
-        WSTAGE(NEU + 8, NCH, mfma_chunk_r<true>(AK, x[1], acc))
-        WSTAGE(NEU + 9, NCH, mfma_chunk_r<true>(AK, x[2], acc))
-        WSTAGE(NEU + 10, NCH, mfma_chunk_r<true>(AK, x[3], acc))
-        // rows (registers) are edges e = 8 (r>>2) + 4 h + (r&3); mask and reduce over them
-        int o_m = n * 32 + 4 * h;
-        asm volatile("" : "+v"(o_m) : "v"(acc[0]));
-        float sacc = 0.f, ms = 0.f;
+            for (int q = 0; q < 16; q++) acc[r][q] = bmid;
+        WSTAGE(NEU + 7, NCH, acc, (mfma_x<R, 0, true>(AK, x, acc)))
+        WSTAGE(NEU + 8, NCH, acc, (mfma_x<R, 1, true>(AK, x, acc)))
+        WSTAGE(NEU + 9, NCH, acc, (mfma_x<R, 2, true>(AK, x, acc)))
+        WSTAGE(NEU + 10, NCH, acc, (mfma_x<R, 3, true>(AK, x, acc)))
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const f32x4v mm = *reinterpret_cast<const f32x4v *>(A.mask_att + o_m + 8 * q);
+        for (int r = 0; r < R; r++) {
+            // rows (registers) are edges e = 8 (r>>2) + 4 h + (r&3); mask and reduce over them
+            int o_m = n[r] * 32 + 4 * h;
+            asm volatile("" : "+v"(o_m) : "v"(acc[r][0]));
+            float sacc = 0.f, ms = 0.f;
 #pragma unroll
-            for (int pq = 0; pq < 4; pq++) {
-                sacc = fmaf(fmaxf(acc[4 * q + pq], 0.f), mm[pq], sacc);
-                ms += mm[pq];
+            for (int q = 0; q < 4; q++) {
+                const f32x4v mm = *reinterpret_cast<const f32x4v *>(A.mask_att + o_m + 8 * q);
+#pragma unroll
+                for (int pq = 0; pq < 4; pq++) {
+                    sacc = fmaf(fmaxf(acc[r][4 * q + pq], 0.f), mm[pq], sacc);
+                    ms += mm[pq];
+                }
+            }
+            sacc += __shfl_xor(sacc, 32);
+            ms += __shfl_xor(ms, 32);
+            if (live[r]) {
+                if (h == 0) A.S[(size_t)n[r] * 128 + 32 * wave + j] = sacc * A.inv_K;
+                if (tid == 0) A.msum[n[r]] = ms * A.inv_K;
             }
         }
-        sacc += __shfl_xor(sacc, 32);
-        ms += __shfl_xor(ms, 32);
-        if (h == 0) A.S[(size_t)n * 128 + 32 * wave + j] = sacc * A.inv_K;
-        if (tid == 0) A.msum[n] = ms * A.inv_K;
     }
 }
 
-// ---------------------------------------------------------------------------------------------
 // ---------------------------------------------------------------------------------------------
 // once per complex: Z_nm = W_B(node message, layer 0) h_E0 and Z_em = W_B(edge message, layer 0) h_E0.  h_E0 never
 // changes during sampling, so the layer-0 kernels skip four of their stages and start from these tiles.
 // ---------------------------------------------------------------------------------------------
 template <int S>
-__global__ void __launch_bounds__(ET, PP_NM_WGS)
+__global__ void __launch_bounds__(ET, 1)
 k_edge_static(EdgeArgs A) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int R = 1;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, h = lane >> 5;
@@ -668,30 +727,32 @@ k_edge_static(EdgeArgs A) {
     const int K = A.K;
     if (A.rmask[n] == 0.f) return;        // never read: the layer kernels leave masked residues early as well
     constexpr int NCH = 8;                // chunks: W_B(node message) x4, W_B(edge message) x4
-    PROLOGUE_PIPE()
-    HT x[4];
-    f32x16 acc;
+    PROLOGUE_PIPE(NCH)
+    HT x[1][4];
+    f32x16 acc[1];
     const int jj = j < K ? j : K - 1;
     const float *hrow = A.hE_in + ((size_t)n * K + jj) * 128;
 #pragma unroll
-    for (int t = 0; t < 4; t++) { load_tile(hrow + 32 * t, h, acc); split_tile(acc, x[t]); }
+    for (int t = 0; t < 4; t++) { load_tile(hrow + 32 * t, h, acc[0]); split_tile(acc[0], x[0][t]); }
 #pragma unroll
-    for (int r = 0; r < 16; r++) acc[r] = 0.f;
+    for (int r = 0; r < 16; r++) acc[0][r] = 0.f;
     PROLOGUE_OPERANDS()
-    WSTAGE(0, NCH, mfma_chunk_r<false>(AK, x[0], acc))
-    WSTAGE(1, NCH, mfma_chunk_r<false>(AK, x[1], acc))
-    WSTAGE(2, NCH, mfma_chunk_r<false>(AK, x[2], acc))
-    WSTAGE(3, NCH, mfma_chunk_r<false>(AK, x[3], acc))
-    store_tile(A.Znm + ((size_t)n * K + jj) * 128 + 32 * wave, h, acc);      // lanes j >= K mirror edge K - 1
+    WSTAGE(0, NCH, acc, (mfma_x<1, 0, false>(AK, x, acc)))
+    WSTAGE(1, NCH, acc, (mfma_x<1, 1, false>(AK, x, acc)))
+    WSTAGE(2, NCH, acc, (mfma_x<1, 2, false>(AK, x, acc)))
+    WSTAGE(3, NCH, acc, (mfma_x<1, 3, false>(AK, x, acc)))
+    store_tile(A.Znm + ((size_t)n * K + jj) * 128 + 32 * wave, h, acc[0]);      // lanes j >= K mirror edge K - 1
 #pragma unroll
-    for (int r = 0; r < 16; r++) acc[r] = 0.f;
-    WSTAGE(4, NCH, mfma_chunk_r<false>(AK, x[0], acc))
-    WSTAGE(5, NCH, mfma_chunk_r<false>(AK, x[1], acc))
-    WSTAGE(6, NCH, mfma_chunk_r<false>(AK, x[2], acc))
-    WSTAGE(7, NCH, mfma_chunk_r<false>(AK, x[3], acc))
-    store_tile(A.Zem + ((size_t)n * K + jj) * 128 + 32 * wave, h, acc);
+    for (int r = 0; r < 16; r++) acc[0][r] = 0.f;
+    WSTAGE(4, NCH, acc, (mfma_x<1, 0, false>(AK, x, acc)))
+    WSTAGE(5, NCH, acc, (mfma_x<1, 1, false>(AK, x, acc)))
+    WSTAGE(6, NCH, acc, (mfma_x<1, 2, false>(AK, x, acc)))
+    WSTAGE(7, NCH, acc, (mfma_x<1, 3, false>(AK, x, acc)))
+    store_tile(A.Zem + ((size_t)n * K + jj) * 128 + 32 * wave, h, acc[0]);
 }
 
+static float *g_dbg = nullptr;
+extern "C" void pp_debug_set_dbg(float *p) { g_dbg = p; }
 static EdgeArgs edge_args(pp_ctx *c, int layer, bool edge) {
     const pp_plan *p = c->plan;
     const LayerOff &o = p->off.layer[layer];
@@ -713,13 +774,58 @@ static EdgeArgs edge_args(pp_ctx *c, int layer, bool edge) {
     A.Znm = c->Znm; A.Zem = c->Zem;
     A.pts2 = c->ptsN; A.PA2 = c->PAn; A.PC2 = c->PCn;
     A.b_mid2 = p->w + p->off.layer[layer < 2 ? layer + 1 : 2].nm_mid_b;
+    A.dbg = g_dbg;
     return A;
 }
 
-static const size_t NM_SMEM = (4 * PP_NM_SLOTS * 1024 + XBUF_FLOATS) * sizeof(float);
-static const size_t EU_SMEM = (4 * PP_EU_SLOTS * 1024 + XBUF_FLOATS + PARAM_FLOATS) * sizeof(float);
-static const size_t ST_SMEM = (4 * PP_NM_SLOTS * 1024) * sizeof(float);
+#ifdef PP_NO_FUSE_NM
+#define PP_FUSED false
+#else
+#define PP_FUSED true
+#endif
+#ifndef PP_RMAX
+#define PP_RMAX 3
+#endif
 
+// one workgroup per CU: the request is padded beyond half of the CU's 160 KB (the kernels need R x 16 KB + 4.5 KB)
+#ifndef PP_LDS_PAD
+#define PP_LDS_PAD (84 * 1024)
+#endif
+static size_t g_lds_pad = PP_LDS_PAD;     // pp_debug_set_lds_pad(): occupancy experiments
+extern "C" void pp_debug_set_lds_pad(int bytes) { g_lds_pad = (size_t)bytes; }
+static size_t env_pad(const char *name) {
+    const char *e = getenv(name);
+    return e ? (size_t)atoi(e) : g_lds_pad;
+}
+static size_t pad_smem(size_t b) { return b > g_lds_pad ? b : g_lds_pad; }
+static size_t nm_smem(int R) {
+    static const size_t pad = env_pad("PP_PAD_NM");
+    const size_t b = R * XBUF_FLOATS * sizeof(float), p = getenv("PP_PAD_NM") ? pad : g_lds_pad;
+    return b > p ? b : p;
+}
+static size_t eu_smem(int R) {
+    static const size_t pad = env_pad("PP_PAD_EU");
+    const size_t b = (R * XBUF_FLOATS + PARAM_FLOATS) * sizeof(float), p = getenv("PP_PAD_EU") ? pad : g_lds_pad;
+    return b > p ? b : p;
+}
+#define ST_SMEM pad_smem(0)
+#define MAX_SMEM (160 * 1024)
+
+typedef void (*edge_kernel_t)(EdgeArgs);
+template <int R> static edge_kernel_t nm_kernel(bool st0) {
+    return st0 ? k_node_message<PP_NM_SLOTS, R, true> : k_node_message<PP_NM_SLOTS, R, false>;
+}
+template <int R> static edge_kernel_t eu_kernel(bool st0) {
+    return st0 ? k_edge_update<PP_EU_SLOTS, R, true, PP_FUSED> : k_edge_update<PP_EU_SLOTS, R, false, PP_FUSED>;
+}
+static edge_kernel_t nm_kernel_r(int R, bool st0) {
+    return R == 1 ? nm_kernel<1>(st0) : R == 2 ? nm_kernel<2>(st0) : nm_kernel<3>(st0);
+}
+static edge_kernel_t eu_kernel_r(int R, bool st0) {
+    return R == 1 ? eu_kernel<1>(st0) : R == 2 ? eu_kernel<2>(st0) : eu_kernel<3>(st0);
+}
+
+static int g_num_cu = 0;
 static bool edge_attrs() {
     static bool done = false, ok = false;
     if (!done) {
@@ -727,25 +833,47 @@ static bool edge_attrs() {
         auto set = [](const void *f, size_t bytes) {
             return hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess;
         };
-        ok = set(reinterpret_cast<const void *>(k_edge_static<PP_NM_SLOTS>), ST_SMEM) &&
-             set(reinterpret_cast<const void *>(k_node_message<PP_NM_SLOTS, false>), NM_SMEM) &&
-             set(reinterpret_cast<const void *>(k_node_message<PP_NM_SLOTS, true>), NM_SMEM) &&
-#ifndef PP_FUSE_NM
-             set(reinterpret_cast<const void *>(k_edge_update<PP_EU_SLOTS, false, false>), EU_SMEM) &&
-             set(reinterpret_cast<const void *>(k_edge_update<PP_EU_SLOTS, true, false>), EU_SMEM);
-#else
-             set(reinterpret_cast<const void *>(k_edge_update<PP_EU_SLOTS, false, true>), EU_SMEM) &&
-             set(reinterpret_cast<const void *>(k_edge_update<PP_EU_SLOTS, true, true>), EU_SMEM);
-#endif
+        ok = set(reinterpret_cast<const void *>(k_edge_static<PP_NM_SLOTS>), MAX_SMEM);
+        for (int R = 1; R <= 3 && ok; R++)
+            for (int st0 = 0; st0 < 2 && ok; st0++)
+                ok = set(reinterpret_cast<const void *>(nm_kernel_r(R, st0)), MAX_SMEM) &&
+                     set(reinterpret_cast<const void *>(eu_kernel_r(R, st0)), MAX_SMEM);
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            g_num_cu = prop.multiProcessorCount;
+        if (g_num_cu <= 0) g_num_cu = 256;
     }
     return ok;
+}
+
+// Residues per workgroup.  One workgroup occupies a CU, so a launch takes ceil(ceil(N / R) / CUs) rounds of a workgroup's
+// duration, which grows by ~45 % per extra residue (measured: the weight stream, barriers and prologue are shared):
+// take the R with the least rounds x duration (T1124: 739 residues -> R = 3, 247 workgroups, one round on 256 CUs).
+static int g_forced_R = -1;          // measurement / debugging: PP_EDGE_R=1..3 or pp_debug_set_edge_R()
+extern "C" void pp_debug_set_edge_R(int R) { g_forced_R = R; }
+static int pick_R(int N) {
+    if (g_forced_R < 0) {
+        const char *e = getenv("PP_EDGE_R");
+        g_forced_R = e ? atoi(e) : 0;
+    }
+    if (g_forced_R >= 1 && g_forced_R <= PP_RMAX) return g_forced_R;
+    const float cost[4] = {0.f, 1.f, 1.45f, 1.9f};
+    int best = 1;
+    float best_t = 1e30f;
+    for (int R = 1; R <= PP_RMAX; R++) {
+        const int wgs = (N + R - 1) / R, rounds = (wgs + g_num_cu - 1) / g_num_cu;
+        const float t = rounds * cost[R];
+        if (t < best_t - 1e-6f) { best_t = t; best = R; }
+    }
+    return best;
 }
 
 // resident workgroups per CU the runtime predicts for the two kernels (measurement aid)
 void pp_edge_occupancy(int *node_msg, int *edge_upd) {
     edge_attrs();
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(node_msg, reinterpret_cast<const void *>(k_node_message<PP_NM_SLOTS, false>), ET, NM_SMEM);
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(edge_upd, reinterpret_cast<const void *>(k_edge_update<PP_EU_SLOTS, false, false>), ET, EU_SMEM);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(node_msg, reinterpret_cast<const void *>(nm_kernel_r(1, false)), ET, nm_smem(1));
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(edge_upd, reinterpret_cast<const void *>(eu_kernel_r(1, false)), ET, eu_smem(1));
 }
 
 #define EDGE_ATTR_CHECK()                                                                                   \
@@ -766,33 +894,22 @@ pp_status pp_launch_edge_static(pp_ctx *c, hipStream_t s) {
 pp_status pp_launch_node_message(pp_ctx *c, int layer, hipStream_t s) {
     EDGE_ATTR_CHECK()
     EdgeArgs A = edge_args(c, layer, false);
-    if (layer == 0) hipLaunchKernelGGL((k_node_message<PP_NM_SLOTS, true>), dim3(c->N), dim3(ET), NM_SMEM, s, A);
-    else hipLaunchKernelGGL((k_node_message<PP_NM_SLOTS, false>), dim3(c->N), dim3(ET), NM_SMEM, s, A);
+    const int R = pick_R(c->N);
+    hipLaunchKernelGGL(nm_kernel_r(R, layer == 0), dim3((c->N + R - 1) / R), dim3(ET), nm_smem(R), s, A);
     PP_HIP_CHECK(hipGetLastError());
     return PP_OK;
 }
 
-// true when k_edge_update also computes the next layer's node message (build with -DPP_FUSE_NM)
-bool pp_edge_fused() {
-#ifdef PP_FUSE_NM
-    return true;
-#else
-    return false;
-#endif
-}
+// true when k_edge_update also computes the next layer's node message
+bool pp_edge_fused() { return PP_FUSED; }
 
 // layers 0 and 1 only (the reference's layer-2 edge update is dead code)
 pp_status pp_launch_edge_update(pp_ctx *c, int layer, hipStream_t s) {
     EDGE_ATTR_CHECK()
     if (layer < 0 || layer > 1) { pp_set_error("pp_launch_edge_update: layer must be 0 or 1"); return PP_ERR_INVALID; }
     EdgeArgs A = edge_args(c, layer, true);
-#ifdef PP_FUSE_NM
-    if (layer == 0) hipLaunchKernelGGL((k_edge_update<PP_EU_SLOTS, true, true>), dim3(c->N), dim3(ET), EU_SMEM, s, A);
-    else hipLaunchKernelGGL((k_edge_update<PP_EU_SLOTS, false, true>), dim3(c->N), dim3(ET), EU_SMEM, s, A);
-#else
-    if (layer == 0) hipLaunchKernelGGL((k_edge_update<PP_EU_SLOTS, true, false>), dim3(c->N), dim3(ET), EU_SMEM, s, A);
-    else hipLaunchKernelGGL((k_edge_update<PP_EU_SLOTS, false, false>), dim3(c->N), dim3(ET), EU_SMEM, s, A);
-#endif
+    const int R = pick_R(c->N);
+    hipLaunchKernelGGL(eu_kernel_r(R, layer == 0), dim3((c->N + R - 1) / R), dim3(ET), eu_smem(R), s, A);
     PP_HIP_CHECK(hipGetLastError());
     return PP_OK;
 }
