@@ -37,15 +37,27 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 struct HT {
     h8 hi[2], lo[2];
 };
+// RELU: the tile is max(v, 0) (hidden activations: also saturated at the f16 maximum, one v_med3 for both); otherwise v
+// is a LayerNorm output or an h_E row (|v| far below 65504 by construction) and is split as it is.  Two values at a time
+// so that hipcc emits v_cvt_pk_f16_f32 / v_pk_add_f32: 2.5 VALU instructions per value (3.5 with RELU).
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+template <bool RELU>
 __device__ __forceinline__ void split_tile(const f32x16 &v, HT &o) {
 #pragma unroll
     for (int s = 0; s < 2; s++)
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const float x = __builtin_amdgcn_fmed3f(v[8 * s + i], -65504.f, 65504.f);    // saturate, never inf
-            const _Float16 hh = (_Float16)x;
-            o.hi[s][i] = hh;
-            o.lo[s][i] = (_Float16)(x - (float)hh);
+        for (int i = 0; i < 8; i += 2) {
+            f32x2v x = {v[8 * s + i], v[8 * s + i + 1]};
+            if (RELU) {
+                x[0] = __builtin_amdgcn_fmed3f(x[0], 0.f, 65504.f);
+                x[1] = __builtin_amdgcn_fmed3f(x[1], 0.f, 65504.f);
+            }
+            const h2v hh = __builtin_convertvector(x, h2v);
+            const f32x2v d = {fmaf((float)hh[0], -1.0f, x[0]), fmaf((float)hh[1], -1.0f, x[1])};
+            const h2v ll = __builtin_convertvector(d, h2v);
+            o.hi[s][i] = hh[0]; o.hi[s][i + 1] = hh[1];
+            o.lo[s][i] = ll[0]; o.lo[s][i + 1] = ll[1];
         }
 }
 __device__ __forceinline__ void join_tile(const HT &t, f32x16 &v) {
@@ -262,41 +274,46 @@ __device__ __forceinline__ void ln_affine_tile(f32x16 &v, float rstd, const floa
     }
 }
 
-// 72 invariant point features of edge (i, j), split and laid out as MFMA operands (HG)
+// 72 invariant point features of edge (i, j), split and laid out as MFMA operands (HG).  Lane half h carries the
+// features of points 4h .. 4h+3 (pp_api.hip put_geo_chunk permutes W_G's columns to match): 40 slots =
+// p_loc xyz x4 | |p_loc| x4 | R_i^T (p_glob_j - t_i) xyz x4 | its norm x4 | |p_glob_i - p_glob_j| x4 | 0 x4.
 __device__ __forceinline__ void edge_geometry(const float *__restrict__ pts_i, const float *__restrict__ fr,
                                               const float *__restrict__ pts_j, int h, HG &g) {
-    float geom[80];
+    float sl[40];
     float R[9], tr[3];
 #pragma unroll
     for (int k = 0; k < 9; k++) R[k] = fr[k];
 #pragma unroll
     for (int k = 0; k < 3; k++) tr[k] = fr[9 + k];
+    const float *pl = pts_i + 12 * h, *pg = pts_i + 24 + 12 * h, *pj = pts_j + 24 + 12 * h;
 #pragma unroll
-    for (int q = 0; q < 8; q++) {
-        float lx = pts_i[3 * q], ly = pts_i[3 * q + 1], lz = pts_i[3 * q + 2];
-        float gx = pts_i[24 + 3 * q], gy = pts_i[24 + 3 * q + 1], gz = pts_i[24 + 3 * q + 2];
-        float jx = pts_j[24 + 3 * q], jy = pts_j[24 + 3 * q + 1], jz = pts_j[24 + 3 * q + 2];
-        geom[3 * q] = lx; geom[3 * q + 1] = ly; geom[3 * q + 2] = lz;
-        geom[24 + q] = sqrtf(lx * lx + ly * ly + lz * lz + 1e-8f);
+    for (int q = 0; q < 4; q++) {
+        float lx = pl[3 * q], ly = pl[3 * q + 1], lz = pl[3 * q + 2];
+        float gx = pg[3 * q], gy = pg[3 * q + 1], gz = pg[3 * q + 2];
+        float jx = pj[3 * q], jy = pj[3 * q + 1], jz = pj[3 * q + 2];
+        sl[3 * q] = lx; sl[3 * q + 1] = ly; sl[3 * q + 2] = lz;
+        sl[12 + q] = sqrtf(lx * lx + ly * ly + lz * lz + 1e-8f);
         float dx = jx - tr[0], dy = jy - tr[1], dz = jz - tr[2];
         float nx = R[0] * dx + R[3] * dy + R[6] * dz;
         float ny = R[1] * dx + R[4] * dy + R[7] * dz;
         float nz = R[2] * dx + R[5] * dy + R[8] * dz;
-        geom[32 + 3 * q] = nx; geom[32 + 3 * q + 1] = ny; geom[32 + 3 * q + 2] = nz;
-        geom[56 + q] = sqrtf(nx * nx + ny * ny + nz * nz + 1e-8f);
+        sl[16 + 3 * q] = nx; sl[16 + 3 * q + 1] = ny; sl[16 + 3 * q + 2] = nz;
+        sl[28 + q] = sqrtf(nx * nx + ny * ny + nz * nz + 1e-8f);
         float ex = gx - jx, ey = gy - jy, ez = gz - jz;
-        geom[64 + q] = sqrtf(ex * ex + ey * ey + ez * ez + 1e-8f);
+        sl[32 + q] = sqrtf(ex * ex + ey * ey + ez * ez + 1e-8f);
     }
 #pragma unroll
-    for (int k = 72; k < 80; k++) geom[k] = 0.f;
+    for (int k = 36; k < 40; k++) sl[k] = 0.f;
 #pragma unroll
     for (int S5 = 0; S5 < 5; S5++)
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const float x = h ? geom[16 * S5 + 8 + i] : geom[16 * S5 + i];
-            const _Float16 hh = (_Float16)x;
-            g.hi[S5][i] = hh;
-            g.lo[S5][i] = (_Float16)(x - (float)hh);
+        for (int i = 0; i < 8; i += 2) {
+            const f32x2v x = {sl[8 * S5 + i], sl[8 * S5 + i + 1]};
+            const h2v hh = __builtin_convertvector(x, h2v);
+            const f32x2v d = {fmaf((float)hh[0], -1.0f, x[0]), fmaf((float)hh[1], -1.0f, x[1])};
+            const h2v ll = __builtin_convertvector(d, h2v);
+            g.hi[S5][i] = hh[0]; g.hi[S5][i + 1] = hh[1];
+            g.lo[S5][i] = ll[0]; g.lo[S5][i + 1] = ll[1];
         }
 }
 
@@ -322,8 +339,7 @@ __device__ __forceinline__ void edge_geometry(const float *__restrict__ pts_i, c
     MFMA_DRAIN();                                                                 \
     _Pragma("unroll") for (int r = 0; r < R; r++) {                               \
         HT ht;                                                                    \
-        relu_tile(acc[r]);                                                        \
-        split_tile(acc[r], ht);                                                   \
+        split_tile<true>(acc[r], ht);                                             \
         xbuf_put_h(xbuf + r * XBUF_FLOATS, wave, lane, ht);                       \
     }                                                                             \
     __syncthreads();
@@ -412,7 +428,7 @@ k_node_message(EdgeArgs A) {
         const float *hrow = A.hE_in + ((size_t)n[r] * K + jj) * 128;
         if constexpr (!ST0) {
 #pragma unroll
-            for (int t = 0; t < 4; t++) { load_tile(hrow + 32 * t, h, acc[r]); split_tile(acc[r], x[r][t]); }
+            for (int t = 0; t < 4; t++) { load_tile(hrow + 32 * t, h, acc[r]); split_tile<false>(acc[r], x[r][t]); }
         }
         load_tile(A.PA + (size_t)n[r] * 128 + 32 * wave, h, acc[r]);
         add_tile(A.PC + (size_t)nbr * 128 + 32 * wave, h, acc[r]);
@@ -557,7 +573,7 @@ k_edge_update(EdgeArgs A) {
         const float *hrow = A.hE_in + ((size_t)n[r] * K + jj) * 128;
         if constexpr (!ST0) {
 #pragma unroll
-            for (int t = 0; t < 4; t++) { load_tile(hrow + 32 * t, h, acc[r]); split_tile(acc[r], x[r][t]); }
+            for (int t = 0; t < 4; t++) { load_tile(hrow + 32 * t, h, acc[r]); split_tile<false>(acc[r], x[r][t]); }
         }
         load_tile(A.PA + (size_t)n[r] * 128 + 32 * wave, h, acc[r]);
         add_tile(A.PC + (size_t)nbr[r] * 128 + 32 * wave, h, acc[r]);
@@ -605,7 +621,7 @@ k_edge_update(EdgeArgs A) {
 #pragma unroll
         for (int t = 0; t < 4; t++) {
             ln_affine_tile(v4[t], rstd, prm + P_G2 + 32 * t, prm + P_BE2 + 32 * t, h);
-            split_tile(v4[t], x[r][t]);
+            split_tile<false>(v4[t], x[r][t]);
         }
         load_tile(prm + P_FOB + 32 * wave, h, out[r]);
     }
@@ -652,7 +668,7 @@ k_edge_update(EdgeArgs A) {
 #pragma unroll
         for (int r = 0; r < R; r++) {
             HT ht;
-            split_tile(out[r], ht);
+            split_tile<false>(out[r], ht);
             xbuf_put_h(xbuf + r * XBUF_FLOATS, wave, lane, ht);
         }
         // `out` is dead from here; its inputs are fetched here and not earlier: offsets made opaque behind `out`
@@ -733,7 +749,7 @@ k_edge_static(EdgeArgs A) {
     const int jj = j < K ? j : K - 1;
     const float *hrow = A.hE_in + ((size_t)n * K + jj) * 128;
 #pragma unroll
-    for (int t = 0; t < 4; t++) { load_tile(hrow + 32 * t, h, acc[0]); split_tile(acc[0], x[0][t]); }
+    for (int t = 0; t < 4; t++) { load_tile(hrow + 32 * t, h, acc[0]); split_tile<false>(acc[0], x[0][t]); }
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[0][r] = 0.f;
     PROLOGUE_OPERANDS()
