@@ -6,8 +6,9 @@ import sys
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libpackppi_hip.so")
-# PACKPPI_EDGE=f16 builds the experimental split-f16 edge kernels (pp_edge_f16.hip) instead of the shipped fp32 ones
-EDGE_F16 = os.environ.get("PACKPPI_EDGE", "") == "f16"
+# The edge kernels exist twice: pp_edge_f16.hip (default: split-f16 MFMA, fp32-equivalent accuracy, one workgroup per CU)
+# and pp_edge.hip (PACKPPI_EDGE=f32: exact-fp32 MFMA, three workgroups per CU).  Same launchers, same results to ~1e-6.
+EDGE_F16 = os.environ.get("PACKPPI_EDGE", "f16") != "f32"
 SOURCES = ["pp_api.hip", "pp_prepare.hip", "pp_node.hip", "pp_edge_f16.hip" if EDGE_F16 else "pp_edge.hip", "pp_clash.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-variable",
          "-Wno-unused-but-set-variable"] + (["-DPP_EDGE_F16"] if EDGE_F16 else []) + os.environ.get("PACKPPI_CFLAGS", "").split()
@@ -46,6 +47,20 @@ def build_library(force=False, verbose=True, extra_flags=()):
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
     return LIB
+
+
+def compile_alternate(verbose=True):
+    """Compile (not link) the edge-kernel source the library was NOT built from, so that both variants are known to build."""
+    src = "pp_edge.hip" if EDGE_F16 else "pp_edge_f16.hip"
+    flags = [f for f in FLAGS if f != "-DPP_EDGE_F16"] + ([] if EDGE_F16 else ["-DPP_EDGE_F16"])
+    obj = os.path.join(CSRC, src.replace(".hip", ".alt.o"))
+    if os.path.exists(obj) and os.path.getmtime(obj) > os.path.getmtime(os.path.join(CSRC, src)):
+        return obj
+    cmd = [_hipcc(), *flags, "-c", os.path.join(CSRC, src), "-o", obj]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    return obj
 
 
 if __name__ == "__main__":

@@ -111,12 +111,28 @@ enum { P_BMID = 0, P_BOUT = 128, P_FOB = 256, P_G2 = 384, P_BE2 = 512, P_FIB = 6
 #ifndef PP_WDEPTH
 #define PP_WDEPTH 3
 #endif
+#ifndef PP_NM_WGS
+#define PP_NM_WGS 1
+#endif
 #ifndef PP_WGS
-#define PP_WGS 1           // register budget = 512 / PP_WGS per lane; > 1 only for the occupancy experiments (tools/debug)
+#define PP_WGS 1           // resident workgroups per CU the kernels are compiled for (register budget)
 #endif
 #define NRING (PP_WDEPTH + 1)
+#ifdef PP_X_NOWLOAD      /* timing experiment: results are wrong */
+#define PP_X_NOWLOAD_ true
+#else
+#define PP_X_NOWLOAD_ false
+#endif
 
+#ifdef PP_X_NOMFMA       /* timing experiment: results are wrong */
+__device__ __forceinline__ f32x16 mfma_skip(h8 a, h8 b, f32x16 c) {
+    c[0] += (float)a[0] * (float)b[0];          // operands stay alive (their loads are not removed), no MFMA issued
+    return c;
+}
+#define MFMA16(a, b, c) mfma_skip((a), (b), (c))
+#else
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+#endif
 
 // A operands of one stage in registers: [s0 hi, s0 lo, s1 hi, s1 lo]
 struct AOp {
@@ -274,44 +290,61 @@ __device__ __forceinline__ void ln_affine_tile(f32x16 &v, float rstd, const floa
 // 72 invariant point features of edge (i, j), split and laid out as MFMA operands (HG).  Lane half h carries the
 // features of points 4h .. 4h+3 (pp_api.hip put_geo_chunk permutes W_G's columns to match): 40 slots =
 // p_loc xyz x4 | |p_loc| x4 | R_i^T (p_glob_j - t_i) xyz x4 | its norm x4 | |p_glob_i - p_glob_j| x4 | 0 x4.
-__device__ __forceinline__ void edge_geometry(const float *__restrict__ pts_i, const float *__restrict__ fr,
-                                              const float *__restrict__ pts_j, int h, HG &g) {
-    float sl[40];
-    float R[9], tr[3];
+// Split in pieces so that the fused tail's geometry can be spread over MFMA stages: geo_point (point q of this half
+// -> slots), geo_pack (k-step S5 of the slots -> operands).
+__device__ __forceinline__ void geo_point(int q, const float (&pi)[24], const float *__restrict__ fr,
+                                          const float (&pj)[12], float (&sl)[40]) {
+    const float *pl = pi, *pg = pi + 12;       // this lane half's four points of residue i: local | global
+    float lx = pl[3 * q], ly = pl[3 * q + 1], lz = pl[3 * q + 2];
+    float gx = pg[3 * q], gy = pg[3 * q + 1], gz = pg[3 * q + 2];
+    float jx = pj[3 * q], jy = pj[3 * q + 1], jz = pj[3 * q + 2];
+    sl[3 * q] = lx; sl[3 * q + 1] = ly; sl[3 * q + 2] = lz;
+    sl[12 + q] = sqrtf(lx * lx + ly * ly + lz * lz + 1e-8f);
+    float dx = jx - fr[9], dy = jy - fr[10], dz = jz - fr[11];
+    float nx = fr[0] * dx + fr[3] * dy + fr[6] * dz;
+    float ny = fr[1] * dx + fr[4] * dy + fr[7] * dz;
+    float nz = fr[2] * dx + fr[5] * dy + fr[8] * dz;
+    sl[16 + 3 * q] = nx; sl[16 + 3 * q + 1] = ny; sl[16 + 3 * q + 2] = nz;
+    sl[28 + q] = sqrtf(nx * nx + ny * ny + nz * nz + 1e-8f);
+    float ex = gx - jx, ey = gy - jy, ez = gz - jz;
+    sl[32 + q] = sqrtf(ex * ex + ey * ey + ez * ez + 1e-8f);
+}
+__device__ __forceinline__ void geo_pack(int S5, const float (&sl)[40], HG &g) {
 #pragma unroll
-    for (int k = 0; k < 9; k++) R[k] = fr[k];
-#pragma unroll
-    for (int k = 0; k < 3; k++) tr[k] = fr[9 + k];
-    const float *pl = pts_i + 12 * h, *pg = pts_i + 24 + 12 * h, *pj = pts_j + 24 + 12 * h;
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        float lx = pl[3 * q], ly = pl[3 * q + 1], lz = pl[3 * q + 2];
-        float gx = pg[3 * q], gy = pg[3 * q + 1], gz = pg[3 * q + 2];
-        float jx = pj[3 * q], jy = pj[3 * q + 1], jz = pj[3 * q + 2];
-        sl[3 * q] = lx; sl[3 * q + 1] = ly; sl[3 * q + 2] = lz;
-        sl[12 + q] = sqrtf(lx * lx + ly * ly + lz * lz + 1e-8f);
-        float dx = jx - tr[0], dy = jy - tr[1], dz = jz - tr[2];
-        float nx = R[0] * dx + R[3] * dy + R[6] * dz;
-        float ny = R[1] * dx + R[4] * dy + R[7] * dz;
-        float nz = R[2] * dx + R[5] * dy + R[8] * dz;
-        sl[16 + 3 * q] = nx; sl[16 + 3 * q + 1] = ny; sl[16 + 3 * q + 2] = nz;
-        sl[28 + q] = sqrtf(nx * nx + ny * ny + nz * nz + 1e-8f);
-        float ex = gx - jx, ey = gy - jy, ez = gz - jz;
-        sl[32 + q] = sqrtf(ex * ex + ey * ey + ez * ez + 1e-8f);
+    for (int i = 0; i < 8; i += 2) {
+        const int k0 = 8 * S5 + i;
+        const f32x2v x = {k0 < 36 ? sl[k0] : 0.f, k0 + 1 < 36 ? sl[k0 + 1] : 0.f};
+        const h2v hh = __builtin_convertvector(x, h2v);
+        const f32x2v d = {fmaf((float)hh[0], -1.0f, x[0]), fmaf((float)hh[1], -1.0f, x[1])};
+        const h2v ll = __builtin_convertvector(d, h2v);
+        g.hi[S5][i] = hh[0]; g.hi[S5][i + 1] = hh[1];
+        g.lo[S5][i] = ll[0]; g.lo[S5][i + 1] = ll[1];
     }
+}
+__device__ __forceinline__ void load_pj(const float *__restrict__ pts_j, int h, float (&pj)[12]) {
 #pragma unroll
-    for (int k = 36; k < 40; k++) sl[k] = 0.f;
+    for (int q = 0; q < 3; q++) {
+        const f32x4v v = *reinterpret_cast<const f32x4v *>(pts_j + 24 + 12 * h + 4 * q);
+        pj[4 * q] = v[0]; pj[4 * q + 1] = v[1]; pj[4 * q + 2] = v[2]; pj[4 * q + 3] = v[3];
+    }
+}
+__device__ __forceinline__ void load_pi(const float *__restrict__ pts_i, int h, float (&pi)[24]) {
 #pragma unroll
-    for (int S5 = 0; S5 < 5; S5++)
+    for (int q = 0; q < 3; q++) {
+        const f32x4v a = *reinterpret_cast<const f32x4v *>(pts_i + 12 * h + 4 * q);
+        const f32x4v b = *reinterpret_cast<const f32x4v *>(pts_i + 24 + 12 * h + 4 * q);
+        pi[4 * q] = a[0]; pi[4 * q + 1] = a[1]; pi[4 * q + 2] = a[2]; pi[4 * q + 3] = a[3];
+        pi[12 + 4 * q] = b[0]; pi[12 + 4 * q + 1] = b[1]; pi[12 + 4 * q + 2] = b[2]; pi[12 + 4 * q + 3] = b[3];
+    }
+}
+__device__ __forceinline__ void edge_geometry(const float *__restrict__ pts_i, const float *__restrict__ fr,
+                                              const float (&pj)[12], int h, HG &g) {
+    float sl[40], pi[24];
+    load_pi(pts_i, h, pi);
 #pragma unroll
-        for (int i = 0; i < 8; i += 2) {
-            const f32x2v x = {sl[8 * S5 + i], sl[8 * S5 + i + 1]};
-            const h2v hh = __builtin_convertvector(x, h2v);
-            const f32x2v d = {fmaf((float)hh[0], -1.0f, x[0]), fmaf((float)hh[1], -1.0f, x[1])};
-            const h2v ll = __builtin_convertvector(d, h2v);
-            g.hi[S5][i] = hh[0]; g.hi[S5][i + 1] = hh[1];
-            g.lo[S5][i] = ll[0]; g.lo[S5][i + 1] = ll[1];
-        }
+    for (int q = 0; q < 4; q++) geo_point(q, pi, fr, pj, sl);
+#pragma unroll
+    for (int S5 = 0; S5 < 5; S5++) geo_pack(S5, sl, g);
 }
 
 // ACC names the accumulator array the stage's MFMAs chain on: the empty asm at the end uses one element of every chain,
@@ -320,7 +353,7 @@ __device__ __forceinline__ void edge_geometry(const float *__restrict__ pts_i, c
 #define WSTAGE(k, NCH, ACC, BODY)                                                                              \
     {                                                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
-        if constexpr ((k) + PP_WDEPTH < (NCH)) gload_A(wq, (k) + PP_WDEPTH, AR[((k) + PP_WDEPTH) % NRING]);    \
+        if constexpr ((k) + PP_WDEPTH < (NCH) && !PP_X_NOWLOAD_) gload_A(wq, (k) + PP_WDEPTH, AR[((k) + PP_WDEPTH) % NRING]);    \
         const AOp &AK = AR[(k) % NRING];                                                                       \
         BODY;                                                                                                  \
         _Pragma("unroll") for (int r_ = 0; r_ < R; r_++) asm volatile("" ::"v"(ACC[r_][0]));                   \
@@ -340,9 +373,13 @@ __device__ __forceinline__ void edge_geometry(const float *__restrict__ pts_i, c
         xbuf_put_h(xbuf + r * XBUF_FLOATS, wave, lane, ht);                       \
     }                                                                             \
     __syncthreads();
+#ifdef PP_X_NOFETCH      /* timing experiment: results are wrong */
+#define FETCH_X()
+#else
 #define FETCH_X()                                                                 \
     _Pragma("unroll") for (int r = 0; r < R; r++)                                 \
         _Pragma("unroll") for (int t = 0; t < 4; t++) xbuf_get_h(xbuf + r * XBUF_FLOATS, t, lane, x[r][t]);
+#endif
 
 // shared first layer: acc (tile `wave`) = PA_i + PC_j + W_B h_E + W_G geom, ReLU.  Chunks W_B x4 (absent when ST0:
 // layer 0's W_B h_E0 is timestep-invariant and arrives precomputed in acc), then W_G x3.  C0 = number of W_B chunks.
@@ -382,9 +419,15 @@ __device__ __forceinline__ void edge_geometry(const float *__restrict__ pts_i, c
 // node message: S[i] = (1/K) sum_j mask_ij relu(W_mid relu(W_in [..]) + b), msum[i] = (1/K) sum_j mask_ij
 // ---------------------------------------------------------------------------------------------
 // ONE workgroup per CU (one wave per SIMD), enforced by the LDS request (ring + R exchange buffers > 80 KB).
+#ifndef PP_NM_SLOTS
+#define PP_NM_SLOTS 5
+#endif
+#ifndef PP_EU_SLOTS
+#define PP_EU_SLOTS 4
+#endif
 
-template <int R, bool ST0>
-__global__ void __launch_bounds__(ET, PP_WGS)
+template <int S, int R, bool ST0>
+__global__ void __launch_bounds__(ET, PP_NM_WGS)
 k_node_message(EdgeArgs A) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *xbuf = smem;
@@ -415,7 +458,9 @@ k_node_message(EdgeArgs A) {
 #pragma unroll
     for (int r = 0; r < R; r++) {
         const int nbr = A.eidx[(size_t)n[r] * K + jj];
-        edge_geometry(A.pts + (size_t)n[r] * 48, A.frames + (size_t)n[r] * 12, A.pts + (size_t)nbr * 48, h, g[r]);
+        float pj[12];
+        load_pj(A.pts + (size_t)nbr * 48, h, pj);
+        edge_geometry(A.pts + (size_t)n[r] * 48, A.frames + (size_t)n[r] * 12, pj, h, g[r]);
         const float *hrow = A.hE_in + ((size_t)n[r] * K + jj) * 128;
         if constexpr (!ST0) {
 #pragma unroll
@@ -473,12 +518,12 @@ k_node_message(EdgeArgs A) {
         }                                                                                                    \
         mfma_h<R>(AK, hk[(t) & 1], out);                                                                     \
     })
-#define FFN_BLOCK(c)                                                                                         \
+#define FFN_BLOCK(c, E0, E1, E2, E3)                                                                                       \
     _Pragma("unroll") for (int r = 0; r < R; r++) load_tile(prm + P_FIB + 128 * (c) + 32 * wave, h, acc[r]); \
-    WSTAGE(C0 + 11 + 8 * (c) + 0, NCH, acc, (mfma_x<R, 0, false>(AK, x, acc)))                                   \
-    WSTAGE(C0 + 11 + 8 * (c) + 1, NCH, acc, (mfma_x<R, 1, false>(AK, x, acc)))                                   \
-    WSTAGE(C0 + 11 + 8 * (c) + 2, NCH, acc, (mfma_x<R, 2, false>(AK, x, acc)))                                   \
-    WSTAGE(C0 + 11 + 8 * (c) + 3, NCH, acc, (mfma_x<R, 3, false>(AK, x, acc)))                                   \
+    WSTAGE(C0 + 11 + 8 * (c) + 0, NCH, acc, { (mfma_x<R, 0, false>(AK, x, acc)); E0 })                                   \
+    WSTAGE(C0 + 11 + 8 * (c) + 1, NCH, acc, { (mfma_x<R, 1, false>(AK, x, acc)); E1 })                                   \
+    WSTAGE(C0 + 11 + 8 * (c) + 2, NCH, acc, { (mfma_x<R, 2, false>(AK, x, acc)); E2 })                                   \
+    WSTAGE(C0 + 11 + 8 * (c) + 3, NCH, acc, { (mfma_x<R, 3, false>(AK, x, acc)); E3 })                                   \
     __syncthreads();          /* every wave is done reading the previous exchange */                        \
     PUBLISH_RELU()                                                                                           \
     _Pragma("unroll") for (int r = 0; r < R; r++) xbuf_get_h(xbuf + r * XBUF_FLOATS, 0, lane, hk[0][r]);     \
@@ -487,8 +532,7 @@ k_node_message(EdgeArgs A) {
     FFN_W2(C0 + 11 + 8 * (c) + 6, 2)                                                                         \
     FFN_W2(C0 + 11 + 8 * (c) + 7, 3)
 
-// -DPP_X_TS: phase timestamps (s_memtime, core-clock cycles since kernel start) of wave 0 to dbg[n][24]
-// (tools/debug/phase_times.py)
+// -DPP_X_TS: phase timestamps (100 MHz s_memtime ticks since kernel start) of wave 0 to dbg[n][24] (tools/debug/phase_times.py)
 #ifdef PP_X_TS
 #define TS(i) { tsv[i] = (int)(__builtin_readcyclecounter() - ts0); }
 #else
@@ -497,7 +541,7 @@ k_node_message(EdgeArgs A) {
 // FUSE: the workgroup goes straight on to the NEXT layer's node message of its residues (same edges, whose new h_E it
 // holds; the node-level inputs PA2 / PC2 / pts2 were written by the node update that ran before this kernel): one
 // launch, one prologue and one read of h_E less per layer.
-template <int R, bool ST0, bool FUSE>
+template <int S, int R, bool ST0, bool FUSE>
 __global__ void __launch_bounds__(ET, PP_WGS)
 k_edge_update(EdgeArgs A) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -549,19 +593,56 @@ k_edge_update(EdgeArgs A) {
         const int i = min(tid + it * ET, PARAM_FLOATS / 4 - 1);
         *reinterpret_cast<f32x4v *>(prm + 4 * i) = *reinterpret_cast<const f32x4v *>(A.params + 4 * i);
     }
+    // every global input of the kernel is requested here, up front: the edge rows, the gathers through the neighbour
+    // index, the LayerNorm residual and (FUSE) the node-level inputs of the next node message -- nothing is fetched
+    // mid-kernel except the weight stream
+    f32x16 res[R];            // residual input of the first LayerNorm: this wave's tile of h_E
+    f32x16 acc2[R];           // FUSE: PA2_i + PC2_j, the accumulator init of the next node message
+    float pj2[R][12];         // FUSE: the neighbour's points for the next node message (this lane half's four)
+    float pi2[R][24];         // FUSE: this residue's points for the next node message (this lane half's four)
+    float sl2[R][40];         // FUSE: its geometry slots, computed a piece per stage of the first FFN block
+    {
+        f32x16 hraw[R][ST0 ? 1 : 4];
+        float pj[R][12];
 #pragma unroll
-    for (int r = 0; r < R; r++) {
-        nbr[r] = A.eidx[(size_t)n[r] * K + jj];
-        me[r] = A.mask_att[(size_t)n[r] * 32 + jj];            // (lanes j >= K mirror edge K - 1 throughout)
-        edge_geometry(A.pts + (size_t)n[r] * 48, A.frames + (size_t)n[r] * 12, A.pts + (size_t)nbr[r] * 48, h, g[r]);
-        const float *hrow = A.hE_in + ((size_t)n[r] * K + jj) * 128;
-        if constexpr (!ST0) {
+        for (int r = 0; r < R; r++) {
+            nbr[r] = A.eidx[(size_t)n[r] * K + jj];
+            me[r] = A.mask_att[(size_t)n[r] * 32 + jj];        // (lanes j >= K mirror edge K - 1 throughout)
+            const float *hrow = A.hE_in + ((size_t)n[r] * K + jj) * 128;
+            if constexpr (!ST0) {
 #pragma unroll
-            for (int t = 0; t < 4; t++) { load_tile(hrow + 32 * t, h, acc[r]); split_tile<false>(acc[r], x[r][t]); }
+                for (int t = 0; t < 4; t++) load_tile(hrow + 32 * t, h, hraw[r][t]);
+            } else {
+                load_tile(A.Z + ((size_t)n[r] * K + jj) * 128 + 32 * wave, h, hraw[r][0]);
+                load_tile(hrow + 32 * wave, h, res[r]);
+            }
+            load_tile(A.PA + (size_t)n[r] * 128 + 32 * wave, h, acc[r]);
+            if constexpr (FUSE) {
+                load_tile(A.PA2 + (size_t)n[r] * 128 + 32 * wave, h, acc2[r]);
+                load_pi(A.pts2 + (size_t)n[r] * 48, h, pi2[r]);
+            }
         }
-        load_tile(A.PA + (size_t)n[r] * 128 + 32 * wave, h, acc[r]);
-        add_tile(A.PC + (size_t)nbr[r] * 128 + 32 * wave, h, acc[r]);
-        if constexpr (ST0) add_tile(A.Z + ((size_t)n[r] * K + jj) * 128 + 32 * wave, h, acc[r]);
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            load_pj(A.pts + (size_t)nbr[r] * 48, h, pj[r]);
+            add_tile(A.PC + (size_t)nbr[r] * 128 + 32 * wave, h, acc[r]);
+            if constexpr (FUSE) {
+                load_pj(A.pts2 + (size_t)nbr[r] * 48, h, pj2[r]);
+                add_tile(A.PC2 + (size_t)nbr[r] * 128 + 32 * wave, h, acc2[r]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            edge_geometry(A.pts + (size_t)n[r] * 48, A.frames + (size_t)n[r] * 12, pj[r], h, g[r]);
+            if constexpr (!ST0) {
+#pragma unroll
+                for (int t = 0; t < 4; t++) split_tile<false>(hraw[r][t], x[r][t]);
+                res[r] = wave == 0 ? hraw[r][0] : wave == 1 ? hraw[r][1] : wave == 2 ? hraw[r][2] : hraw[r][ST0 ? 0 : 3];
+            } else {
+#pragma unroll
+                for (int q = 0; q < 16; q++) acc[r][q] += hraw[r][0][q];
+            }
+        }
     }
     TS(0)
     PROLOGUE_OPERANDS()
@@ -591,9 +672,8 @@ k_edge_update(EdgeArgs A) {
     // publish v = h_E + mask * m for the first LayerNorm (own tile: read, then overwritten in place)
 #pragma unroll
     for (int r = 0; r < R; r++) {
-        load_tile(A.hE_in + ((size_t)n[r] * K + jj) * 128 + 32 * wave, h, out[r]);   // residual (L2-resident re-read)
 #pragma unroll
-        for (int q = 0; q < 16; q++) out[r][q] = fmaf(acc[r][q], me[r], out[r][q]);
+        for (int q = 0; q < 16; q++) out[r][q] = fmaf(acc[r][q], me[r], res[r][q]);
     }
     __syncthreads();                            // every wave has its B operands of this layer
 #pragma unroll
@@ -617,13 +697,26 @@ k_edge_update(EdgeArgs A) {
     }
     TS(6)
     // ---- FFN 128 -> 512 -> 128 in four hidden blocks of 128 ------------------------------------------
-    FFN_BLOCK(0)
+    // (FUSE) the next node message's geometry rides along with the first block's W1 stages, a piece per stage
+#define GEO2_PTS(q0)                                                                                             \
+    if constexpr (FUSE) {                                                                                        \
+        _Pragma("unroll") for (int r = 0; r < R; r++) {                                                          \
+            geo_point(q0, pi2[r], A.frames + (size_t)n[r] * 12, pj2[r], sl2[r]);                                 \
+            geo_point(q0 + 1, pi2[r], A.frames + (size_t)n[r] * 12, pj2[r], sl2[r]);                             \
+        }                                                                                                        \
+    }
+#define GEO2_PACK(s0, s1)                                                                                        \
+    if constexpr (FUSE) {                                                                                        \
+        _Pragma("unroll") for (int r = 0; r < R; r++)                                                            \
+            _Pragma("unroll") for (int S5 = s0; S5 < s1; S5++) geo_pack(S5, sl2[r], g[r]);                       \
+    }
+    FFN_BLOCK(0, GEO2_PTS(0), GEO2_PTS(2), GEO2_PACK(0, 3), GEO2_PACK(3, 5))
     TS(7)
-    FFN_BLOCK(1)
+    FFN_BLOCK(1, , , , )
     TS(8)
-    FFN_BLOCK(2)
+    FFN_BLOCK(2, , , , )
     TS(9)
-    FFN_BLOCK(3)
+    FFN_BLOCK(3, , , , )
     TS(10)
     // ---- h_E = mask * LN3(x1 + ffn) ---------------------------------------------------------------------
     // residual: this wave's tile of x1, rebuilt from its split form (wave is scalar: uniform branches, static indices)
@@ -668,16 +761,10 @@ k_edge_update(EdgeArgs A) {
             split_tile<false>(out[r], ht);
             xbuf_put_h(xbuf + r * XBUF_FLOATS, wave, lane, ht);
         }
-        // `out` is dead from here; its inputs are fetched here and not earlier: offsets made opaque behind `out`
+        // (the geometry of the next message was computed during the first FFN block; its accumulator init was fetched
+        //  in the prologue)
 #pragma unroll
-        for (int r = 0; r < R; r++) {
-            int o_pts = n[r] * 48, o_fr = n[r] * 12, o_pa = n[r] * 128;
-            int o_ptsj = nbr[r] * 48, o_pc = nbr[r] * 128;
-            asm volatile("" : "+s"(o_pts), "+s"(o_fr), "+s"(o_pa), "+v"(o_ptsj), "+v"(o_pc) : "v"(out[r][0]) : "memory");
-            edge_geometry(A.pts2 + o_pts, A.frames + o_fr, A.pts2 + o_ptsj, h, g[r]);
-            load_tile(A.PA2 + o_pa + 32 * wave, h, acc[r]);
-            add_tile(A.PC2 + o_pc + 32 * wave, h, acc[r]);
-        }
+        for (int r = 0; r < R; r++) acc[r] = acc2[r];
         const float bmid = A.b_mid2[32 * wave + j];           // SWAP form: feature on the lane
         __syncthreads();
         FETCH_X()
@@ -737,6 +824,7 @@ k_edge_update(EdgeArgs A) {
 // once per complex: Z_nm = W_B(node message, layer 0) h_E0 and Z_em = W_B(edge message, layer 0) h_E0.  h_E0 never
 // changes during sampling, so the layer-0 kernels skip four of their stages and start from these tiles.
 // ---------------------------------------------------------------------------------------------
+template <int S>
 __global__ void __launch_bounds__(ET, 1)
 k_edge_static(EdgeArgs A) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -804,7 +892,9 @@ static EdgeArgs edge_args(pp_ctx *c, int layer, bool edge) {
 #else
 #define PP_FUSED true
 #endif
-#define PP_RMAX 2
+#ifndef PP_RMAX
+#define PP_RMAX 3
+#endif
 
 // one workgroup per CU: the request is padded beyond half of the CU's 160 KB (the kernels need R x 16 KB + 4.5 KB)
 #ifndef PP_LDS_PAD
@@ -812,24 +902,36 @@ static EdgeArgs edge_args(pp_ctx *c, int layer, bool edge) {
 #endif
 static size_t g_lds_pad = PP_LDS_PAD;     // pp_debug_set_lds_pad(): occupancy experiments
 extern "C" void pp_debug_set_lds_pad(int bytes) { g_lds_pad = (size_t)bytes; }
+static size_t env_pad(const char *name) {
+    const char *e = getenv(name);
+    return e ? (size_t)atoi(e) : g_lds_pad;
+}
 static size_t pad_smem(size_t b) { return b > g_lds_pad ? b : g_lds_pad; }
-static size_t nm_smem(int R) { return pad_smem(R * XBUF_FLOATS * sizeof(float)); }
-static size_t eu_smem(int R) { return pad_smem((R * XBUF_FLOATS + PARAM_FLOATS) * sizeof(float)); }
+static size_t nm_smem(int R) {
+    static const size_t pad = env_pad("PP_PAD_NM");
+    const size_t b = R * XBUF_FLOATS * sizeof(float), p = getenv("PP_PAD_NM") ? pad : g_lds_pad;
+    return b > p ? b : p;
+}
+static size_t eu_smem(int R) {
+    static const size_t pad = env_pad("PP_PAD_EU");
+    const size_t b = (R * XBUF_FLOATS + PARAM_FLOATS) * sizeof(float), p = getenv("PP_PAD_EU") ? pad : g_lds_pad;
+    return b > p ? b : p;
+}
 #define ST_SMEM pad_smem(0)
 #define MAX_SMEM (160 * 1024)
 
 typedef void (*edge_kernel_t)(EdgeArgs);
 template <int R> static edge_kernel_t nm_kernel(bool st0) {
-    return st0 ? k_node_message<R, true> : k_node_message<R, false>;
+    return st0 ? k_node_message<PP_NM_SLOTS, R, true> : k_node_message<PP_NM_SLOTS, R, false>;
 }
 template <int R> static edge_kernel_t eu_kernel(bool st0) {
-    return st0 ? k_edge_update<R, true, PP_FUSED> : k_edge_update<R, false, PP_FUSED>;
+    return st0 ? k_edge_update<PP_EU_SLOTS, R, true, PP_FUSED> : k_edge_update<PP_EU_SLOTS, R, false, PP_FUSED>;
 }
 static edge_kernel_t nm_kernel_r(int R, bool st0) {
-    return R == 1 ? nm_kernel<1>(st0) : nm_kernel<2>(st0);
+    return R == 1 ? nm_kernel<1>(st0) : R == 2 ? nm_kernel<2>(st0) : nm_kernel<3>(st0);
 }
 static edge_kernel_t eu_kernel_r(int R, bool st0) {
-    return R == 1 ? eu_kernel<1>(st0) : eu_kernel<2>(st0);
+    return R == 1 ? eu_kernel<1>(st0) : R == 2 ? eu_kernel<2>(st0) : eu_kernel<3>(st0);
 }
 
 static int g_num_cu = 0;
@@ -840,8 +942,8 @@ static bool edge_attrs() {
         auto set = [](const void *f, size_t bytes) {
             return hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess;
         };
-        ok = set(reinterpret_cast<const void *>(k_edge_static), MAX_SMEM);
-        for (int R = 1; R <= PP_RMAX && ok; R++)
+        ok = set(reinterpret_cast<const void *>(k_edge_static<PP_NM_SLOTS>), MAX_SMEM);
+        for (int R = 1; R <= 3 && ok; R++)
             for (int st0 = 0; st0 < 2 && ok; st0++)
                 ok = set(reinterpret_cast<const void *>(nm_kernel_r(R, st0)), MAX_SMEM) &&
                      set(reinterpret_cast<const void *>(eu_kernel_r(R, st0)), MAX_SMEM);
@@ -855,11 +957,9 @@ static bool edge_attrs() {
 }
 
 // Residues per workgroup.  One workgroup occupies a CU, so a launch takes ceil(ceil(N / R) / CUs) rounds of a workgroup's
-// duration; a two-residue workgroup takes 1.78 x a one-residue one (measured, T1124: 35.6 vs 20.1 us -- the two
-// accumulator chains interleave and the weight stream, barriers and prologue are shared, but a wave's VALU work and its
-// waits simply double).  Take the R with the least rounds x duration: T1124 (739 residues, 256 CUs) -> R = 1, 3 rounds;
-// S1500 -> R = 2, 3 rounds instead of 6; the C5 shard (9670 residues) -> R = 2.  R = 3 spills registers and was dropped.
-static int g_forced_R = -1;          // measurement / debugging: PP_EDGE_R=1..2 or pp_debug_set_edge_R()
+// duration, which grows by ~45 % per extra residue (measured: the weight stream, barriers and prologue are shared):
+// take the R with the least rounds x duration (T1124: 739 residues -> R = 3, 247 workgroups, one round on 256 CUs).
+static int g_forced_R = -1;          // measurement / debugging: PP_EDGE_R=1..3 or pp_debug_set_edge_R()
 extern "C" void pp_debug_set_edge_R(int R) { g_forced_R = R; }
 static int pick_R(int N) {
     if (g_forced_R < 0) {
@@ -867,7 +967,7 @@ static int pick_R(int N) {
         g_forced_R = e ? atoi(e) : 0;
     }
     if (g_forced_R >= 1 && g_forced_R <= PP_RMAX) return g_forced_R;
-    const float cost[3] = {0.f, 1.f, 1.78f};
+    const float cost[4] = {0.f, 1.f, 1.45f, 1.9f};
     int best = 1;
     float best_t = 1e30f;
     for (int R = 1; R <= PP_RMAX; R++) {
@@ -895,7 +995,7 @@ pp_status pp_launch_edge_static(pp_ctx *c, hipStream_t s) {
     EDGE_ATTR_CHECK()
     EdgeArgs A = edge_args(c, 0, false);
     A.wstream = c->plan->static_stream;
-    hipLaunchKernelGGL(k_edge_static, dim3(c->N), dim3(ET), ST_SMEM, s, A);
+    hipLaunchKernelGGL(k_edge_static<PP_NM_SLOTS>, dim3(c->N), dim3(ET), ST_SMEM, s, A);
     PP_HIP_CHECK(hipGetLastError());
     return PP_OK;
 }
