@@ -27,6 +27,7 @@ N_DIFFUSION_STEPS = 100
 EDGE_UPDATE_FLOP_PER_EDGE = 2 * (456 * 128 + 128 * 128 + 128 * 128) + 2 * (128 * 512 + 512 * 128)
 NODE_MSG_FLOP_PER_EDGE = 2 * (456 * 128 + 128 * 128 + 128 * 128)
 FP32_MFMA_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+F16_MFMA_PEAK_TFLOPS = 2500.0       # MI355X_MICROARCH.md, "Peak BF16/FP16 MFMA ~2.5 PF dense"
 
 
 def load_t1124():
@@ -220,7 +221,17 @@ def main():
     # layer 0's W_B h_E0 products are timestep-invariant and computed once per complex.
     fused_flop_per_edge = EDGE_UPDATE_FLOP_PER_EDGE + NODE_MSG_FLOP_PER_EDGE
     achieved = fused_flop_per_edge * n_edges / t_edge / 1e12
-    executed_mfma = (2960 + 656 - 128) * 4096.0 * residues        # average of the layer-0 and layer-1 launches
+    # which edge kernels the library was built with: 1 = split-f16 (default), 0 = exact fp32 (PACKPPI_EDGE=f32)
+    from packppi_amd import lib as _lib
+    split_f16 = _lib.load().pp_edge_variant() == 1
+    if split_f16:
+        # 342 (layer 1) / 318 (layer 0) v_mfma_f32_32x32x16_f16 per residue and launch, 32768 FLOP each: every fp32
+        # product is three f16 products (hi hi + hi lo + lo hi)
+        executed_mfma = 0.5 * (342 + 318) * 32768.0 * residues
+        peak, dtype = F16_MFMA_PEAK_TFLOPS, "f32 (dense layers as split-f16: two f16 per operand, three f16 MFMAs per product, fp32 accumulate)"
+    else:
+        executed_mfma = (2960 + 656 - 128) * 4096.0 * residues    # average of the layer-0 and layer-1 launches
+        peak, dtype = FP32_MFMA_PEAK_TFLOPS, "f32"
 
     if rank == 0:
         out = {
@@ -230,12 +241,17 @@ def main():
             "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic (seeded random weights; T1124 backbone fixture, seeded initial noise)"
+            "dtype": dtype, "data": "synthetic (seeded random weights; T1124 backbone fixture, seeded initial noise)"
             if args.workload == "t1124" else "synthetic",
             "config": {"workload": name, "diffusion_steps": N_DIFFUSION_STEPS, "proximal": bool(args.proximal),
                        "residues_per_gpu": residues, "mode": "ode"},
             "roofline": {"bound": "mfma", "kernel": "k_edge_update", "achieved": achieved,
-                         "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
+                         "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                         "peak_is": "dense F16 MFMA (the pipe the kernel runs on)" if split_f16 else "FP32 matrix",
+                         "achieved_is": "the reference's fp32 dense-layer arithmetic (2 FLOP per MAC) per second; the kernel "
+                                        "issues 3 f16 MFMAs per product, see executed_mfma_tflops",
+                         "achieved_over_fp32_matrix_peak": achieved / FP32_MFMA_PEAK_TFLOPS,
+                         "edge_kernels": "split-f16" if split_f16 else "fp32",
                          "traffic": pmc_traffic("k_edge_update") if args.workload == "t1124" else None,
                          "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate --pmc "
                                          "passes of this command; profiles/*_pmc_traffic.json)",

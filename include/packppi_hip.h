@@ -135,6 +135,11 @@ pp_status pp_time_kernel(pp_ctx *ctx, int which, int iters, float *avg_ms, void 
 pp_status pp_profile_kernel(pp_ctx *ctx, int which);
 pp_status pp_profile_read(pp_ctx *ctx, float *total_ms, int *launches);
 
+/* Which edge kernels the library was built with (no reference counterpart; bench.py prices the roofline with it):
+ * 1 = split-f16 MFMA with fp32-equivalent accuracy (default, csrc/pp_edge_f16.hip), 0 = exact-fp32 MFMA
+ * (PACKPPI_EDGE=f32, csrc/pp_edge.hip). */
+int pp_edge_variant(void);
+
 /* The library also exports a few undocumented pp_debug_* entry points (single-kernel launches and internal-buffer
  * copies) used only by tools/debug/ to test kernels for run-to-run reproducibility.  They are not part of the
  * drop-in boundary and may change. */

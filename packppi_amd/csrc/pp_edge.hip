@@ -681,6 +681,7 @@ void pp_edge_occupancy(int *node_msg, int *edge_upd) {
         return PP_ERR_HIP;                                                                                  \
     }
 
+extern "C" int pp_edge_variant(void) { return 0; }
 bool pp_edge_fused() { return true; }
 
 pp_status pp_launch_edge_static(pp_ctx *c, hipStream_t s) {

@@ -910,6 +910,7 @@ pp_status pp_launch_node_message(pp_ctx *c, int layer, hipStream_t s) {
 }
 
 // true when k_edge_update also computes the next layer's node message
+extern "C" int pp_edge_variant(void) { return 1; }
 bool pp_edge_fused() { return PP_FUSED; }
 
 // layers 0 and 1 only (the reference's layer-2 edge update is dead code)

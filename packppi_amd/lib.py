@@ -17,7 +17,7 @@ _lib = None
 
 SYMBOLS = ("pp_version", "pp_last_error", "pp_plan_create", "pp_plan_destroy", "pp_plan_set_clash_params",
            "pp_complex_prepare", "pp_ctx_destroy", "pp_ctx_get_graph", "pp_score", "pp_sample", "pp_atom14",
-           "pp_clash", "pp_proximal", "pp_time_kernel", "pp_profile_kernel", "pp_profile_read")
+           "pp_clash", "pp_proximal", "pp_time_kernel", "pp_profile_kernel", "pp_profile_read", "pp_edge_variant")
 
 
 class PPTables(C.Structure):
@@ -61,6 +61,8 @@ def load():
     lib.pp_time_kernel.argtypes = [vp, i, i, C.POINTER(C.c_float), vp]
     lib.pp_profile_kernel.argtypes = [vp, i]
     lib.pp_profile_read.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int)]
+    lib.pp_edge_variant.argtypes = []
+    lib.pp_edge_variant.restype = C.c_int
     _lib = lib
     return lib
 
