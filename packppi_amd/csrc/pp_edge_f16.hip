@@ -1,22 +1,19 @@
-// EXPERIMENTAL, opt-in (PACKPPI_EDGE=f16 python -m packppi_amd.build --force): the edge-level stages of
-// InvariantPointMessagePassing (layers.py:65-148) on the F16 matrix pipe with fp32-level accuracy.  The shipped kernels
-// are the exact-fp32 ones in pp_edge.hip; this file has the same structure and replaces the same launchers.
+// The edge-level stages of InvariantPointMessagePassing (layers.py:65-148) on the F16 matrix pipe with fp32-level
+// accuracy: the DEFAULT edge kernels (PACKPPI_EDGE=f32 builds the exact-fp32 ones of pp_edge.hip instead; same launchers,
+// results equal to ~1e-6).
 //
-// Same decomposition as pp_edge.hip: a workgroup of 4 waves owns R residues (R = 1..3, template) and their K<=32 edges each
-// -- every weight chunk a wave fetches is applied to R independent accumulator chains --, activations live in the
-// 32x32 MFMA accumulator layout (lane = (edge, half h); register r of tile t <-> feature 32 t + 8 (r >> 2) + 4 h + (r & 3))
-// so that a layer's outputs are the next layer's B operands, wave w computes output tile w of every layer (N-split)
-// and publishes it through a 16 KB LDS exchange buffer, weights arrive by wave-private LDS-DMA, the 456-wide first layer
-// is split by linearity.  What differs:
+// Same decomposition as pp_edge.hip: a workgroup of 4 waves owns R residues (R = 1 or 2, template) and their K<=32 edges
+// each, activations live in the 32x32 MFMA accumulator layout (lane = (edge, half h); register r of tile t <-> feature
+// 32 t + 8 (r >> 2) + 4 h + (r & 3)) so that a layer's outputs are the next layer's B operands, wave w computes output
+// tile w of every layer (N-split) and publishes it through a 16 KB LDS exchange buffer per residue, the 456-wide first
+// layer is split by linearity, the edge update goes straight on to the next layer's node message.  What differs:
 //   * arithmetic: every fp32 product is three v_mfma_f32_32x32x16_f16 on two-way f16 splits (below);
-//   * occupancy: ONE workgroup per CU.  With several waves interleaving on a SIMD these kernels produced rare wrong
-//     tiles that could not be fully explained ("Split-f16"); with one wave per SIMD they are bit-reproducible
-//     over millions of workgroup launches (tools/debug/soak.py).  The LDS request (96 / 84.5 KB) enforces it;
-//   * pipeline: since no other workgroup hides latency, the DMA ring is 4-5 slots deep (counted waits) and the A operands
-//     of stage k+1 are read into the next of three rotating register sets while stage k computes;
-//   * no fusion of the next node message into the edge update (the fused tail was the least reliable part).
-// Measured (MI355X, T1124, 100 steps): 30.0 k residues/s against 26.6 k for pp_edge.hip; single workgroups take 18 us
-// (edge update) / 7 us (node message), so small complexes gain most (L = 256: 19.8 us vs 43 us per edge update).
+//   * weights go global memory -> registers (no LDS-DMA ring), three stages ahead of their use;
+//   * occupancy: ONE workgroup per CU (one wave per SIMD), enforced by padding the LDS request to 84 KB.  With several
+//     waves on a SIMD these kernels produce wrong tiles -- with or without LDS-DMA, as separate workgroups or as wave
+//     quartets of one workgroup ("The occupancy hazard"); with one wave per SIMD they are
+//     bit-reproducible over millions of workgroup launches (tools/debug/soak.py).
+// Measured (MI355X, T1124, 100 steps): 36.9 k residues/s against 26.6 k for pp_edge.hip.
 #include "pp_internal.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
