@@ -235,3 +235,37 @@ def test_sampling_is_bit_reproducible(weights, L):
         again = ctx.sample(init, sched).cpu()
         assert torch.equal(again, ref), float((again - ref).abs().max())
     assert torch.isfinite(ref).all()
+
+
+def test_residues_per_workgroup_agree(weights):
+    """Split-f16 edge kernels (default build): one and two residues per workgroup are the same arithmetic per residue
+    (results equal to rounding), for an odd residue count (the last workgroup has a dead slot) and a padded batch."""
+    import ctypes as C
+    from packppi_amd import lib as L, synth
+    from packppi_amd.batch import collate
+    from packppi_amd.featurize import protein_to_batch, protein_to_data
+    from packppi_amd.module import TDiffusionModule
+    l = L.load()
+    if l.pp_edge_variant() != 1:
+        pytest.skip("exact-fp32 edge kernels are built (PACKPPI_EDGE=f32): one residue per workgroup only")
+    l.pp_debug_set_edge_R.argtypes = [C.c_int]
+    l.pp_debug_set_edge_R.restype = None
+    m = TDiffusionModule(weights, device=DEV)
+    single = protein_to_batch(synth.make_complex(301, 5)).to(DEV)
+    padded = collate([protein_to_data(synth.make_complex(n, 90 + n)) for n in (40, 52, 33)]).to(DEV)
+    try:
+        for b in (single, padded):
+            B, Lmax = b.SC_D.shape[:2]
+            g = torch.Generator().manual_seed(7)
+            init = ((torch.rand(B, Lmax, 4, generator=g) * 2 - 1) * 3.0 * b.SC_D_mask.cpu()).to(DEV)
+            ctx = m._context(b)
+            out = []
+            for R in (1, 2):
+                l.pp_debug_set_edge_R(R)
+                out.append(ctx.sample(init, torch.linspace(1, 0, 11)).cpu())
+            d = (out[0] - out[1]).abs()
+            d = torch.minimum(d, (2 * np.pi - d).abs())[b.SC_D_mask.cpu().bool()]
+            assert float(d.max()) < 2e-5, float(d.max())
+            assert torch.isfinite(out[1]).all()
+    finally:
+        l.pp_debug_set_edge_R(0)          # back to the automatic choice
