@@ -9,11 +9,10 @@
 // layer is split by linearity, the edge update goes straight on to the next layer's node message.  What differs:
 //   * arithmetic: every fp32 product is three v_mfma_f32_32x32x16_f16 on two-way f16 splits (below);
 //   * weights go global memory -> registers (no LDS-DMA ring), three stages ahead of their use;
-//   * occupancy: ONE workgroup per CU (one wave per SIMD), enforced by padding the LDS request to 84 KB.  With several
-//     waves on a SIMD these kernels produce wrong tiles -- with or without LDS-DMA, as separate workgroups or as wave
-//     quartets of one workgroup ("The occupancy hazard"); with one wave per SIMD they are
-//     bit-reproducible over millions of workgroup launches (tools/debug/soak.py).
-// Measured (MI355X, T1124, 100 steps): 36.9 k residues/s against 26.6 k for pp_edge.hip.
+//   * occupancy: two workgroups per CU (223 VGPRs, 20.5 KB of LDS each);
+//   * f32 -> f16 conversions go through v_cvt_pkrtz_f16_f32 (see cvt2 below: with gfx950's round-to-nearest conversion
+//     instructions the kernels were only correct with one wave per SIMD).
+// Measured (MI355X, T1124, 100 steps): 42.4 k residues/s against 26.6 k for pp_edge.hip.
 #include "pp_internal.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -39,6 +38,17 @@ struct HT {
 // so that hipcc emits v_cvt_pk_f16_f32 / v_pk_add_f32: 2.5 VALU instructions per value (3.5 with RELU).
 typedef float f32x2v __attribute__((ext_vector_type(2)));
 typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+// f32 pair -> packed f16 by v_cvt_pkrtz_f16_f32 (round toward zero), NOT by gfx950's v_cvt_pk_f16_f32 / v_cvt_f16_f32
+// (round to nearest even, what __builtin_convertvector and a plain cast emit): with the latter these kernels are only
+// correct while a wave has its SIMD to itself -- with two or more waves per SIMD, lanes 16-31 and 48-63 of some tiles come
+// out wrong, run-to-run different (the "occupancy hazard" of DESIGN.md section 4: not the LDS-DMA, not the MFMA chains,
+// not the exchange buffers -- replacing this one instruction made 2 workgroups per CU bit-reproducible).  The split does
+// not care which way hi is rounded: lo = x - hi is exact either way, and hi + lo still carries 21-22 bits of x.
+typedef __fp16 fp16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ h2v cvt2(f32x2v x) {
+    const fp16x2_t r = __builtin_amdgcn_cvt_pkrtz(x[0], x[1]);
+    return __builtin_bit_cast(h2v, r);
+}
 template <bool RELU>
 __device__ __forceinline__ void split_tile(const f32x16 &v, HT &o) {
 #pragma unroll
@@ -50,9 +60,9 @@ __device__ __forceinline__ void split_tile(const f32x16 &v, HT &o) {
                 x[0] = __builtin_amdgcn_fmed3f(x[0], 0.f, 65504.f);
                 x[1] = __builtin_amdgcn_fmed3f(x[1], 0.f, 65504.f);
             }
-            const h2v hh = __builtin_convertvector(x, h2v);
+            const h2v hh = cvt2(x);
             const f32x2v d = {fmaf((float)hh[0], -1.0f, x[0]), fmaf((float)hh[1], -1.0f, x[1])};
-            const h2v ll = __builtin_convertvector(d, h2v);
+            const h2v ll = cvt2(d);
             o.hi[s][i] = hh[0]; o.hi[s][i + 1] = hh[1];
             o.lo[s][i] = ll[0]; o.lo[s][i + 1] = ll[1];
         }
@@ -106,10 +116,10 @@ enum { P_BMID = 0, P_BOUT = 128, P_FOB = 256, P_G2 = 384, P_BE2 = 512, P_FIB = 6
 // The chunk offset is made opaque and every stage starts with a scheduling barrier, so each fetch is issued where it is
 // written (as read-only kernel arguments the compiler would otherwise hoist all of them to the top of the kernel).
 #ifndef PP_WDEPTH
-#define PP_WDEPTH 3
+#define PP_WDEPTH 2
 #endif
 #ifndef PP_WGS
-#define PP_WGS 1           // register budget = 512 / PP_WGS per lane; > 1 only for the occupancy experiments (tools/debug)
+#define PP_WGS 2           // register budget = 512 / PP_WGS per lane; > 1 only for the occupancy experiments (tools/debug)
 #endif
 #define NRING (PP_WDEPTH + 1)
 
@@ -303,9 +313,9 @@ __device__ __forceinline__ void edge_geometry(const float *__restrict__ pts_i, c
 #pragma unroll
         for (int i = 0; i < 8; i += 2) {
             const f32x2v x = {sl[8 * S5 + i], sl[8 * S5 + i + 1]};
-            const h2v hh = __builtin_convertvector(x, h2v);
+            const h2v hh = cvt2(x);
             const f32x2v d = {fmaf((float)hh[0], -1.0f, x[0]), fmaf((float)hh[1], -1.0f, x[1])};
-            const h2v ll = __builtin_convertvector(d, h2v);
+            const h2v ll = cvt2(d);
             g.hi[S5][i] = hh[0]; g.hi[S5][i + 1] = hh[1];
             g.lo[S5][i] = ll[0]; g.lo[S5][i + 1] = ll[1];
         }
@@ -381,7 +391,7 @@ __device__ __forceinline__ void edge_geometry(const float *__restrict__ pts_i, c
 // ONE workgroup per CU (one wave per SIMD), enforced by the LDS request (ring + R exchange buffers > 80 KB).
 
 template <int R, bool ST0>
-__global__ void __launch_bounds__(ET, PP_WGS)
+__global__ void __launch_bounds__(ET, R == 1 ? PP_WGS : 1)
 k_node_message(EdgeArgs A) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *xbuf = smem;
@@ -495,7 +505,7 @@ k_node_message(EdgeArgs A) {
 // holds; the node-level inputs PA2 / PC2 / pts2 were written by the node update that ran before this kernel): one
 // launch, one prologue and one read of h_E less per layer.
 template <int R, bool ST0, bool FUSE>
-__global__ void __launch_bounds__(ET, PP_WGS)
+__global__ void __launch_bounds__(ET, R == 1 ? PP_WGS : 1)
 k_edge_update(EdgeArgs A) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *xbuf = smem, *prm = xbuf + R * XBUF_FLOATS;
@@ -805,7 +815,7 @@ static EdgeArgs edge_args(pp_ctx *c, int layer, bool edge) {
 
 // one workgroup per CU: the request is padded beyond half of the CU's 160 KB (the kernels need R x 16 KB + 4.5 KB)
 #ifndef PP_LDS_PAD
-#define PP_LDS_PAD (84 * 1024)
+#define PP_LDS_PAD 0           // > 80 KB forces one workgroup per CU (occupancy experiments)
 #endif
 static size_t g_lds_pad = PP_LDS_PAD;     // pp_debug_set_lds_pad(): occupancy experiments
 extern "C" void pp_debug_set_lds_pad(int bytes) { g_lds_pad = (size_t)bytes; }
@@ -851,28 +861,20 @@ static bool edge_attrs() {
     return ok;
 }
 
-// Residues per workgroup.  One workgroup occupies a CU, so a launch takes ceil(ceil(N / R) / CUs) rounds of a workgroup's
-// duration; a two-residue workgroup takes 1.78 x a one-residue one (measured, T1124: 35.6 vs 20.1 us -- the two
-// accumulator chains interleave and the weight stream, barriers and prologue are shared, but a wave's VALU work and its
-// waits simply double).  Take the R with the least rounds x duration: T1124 (739 residues, 256 CUs) -> R = 1, 3 rounds;
-// S1500 -> R = 2, 3 rounds instead of 6; the C5 shard (9670 residues) -> R = 2.  R = 3 spills registers and was dropped.
-static int g_forced_R = -1;          // measurement / debugging: PP_EDGE_R=1..2 or pp_debug_set_edge_R()
+// Residues per workgroup: 1 (two such workgroups share a CU: 223 VGPRs).  R = 2 -- two interleaved accumulator chains per
+// weight fetch, 458 registers, one workgroup per CU -- is kept for the structural test (tests/test_hip_parity.py) and
+// measurements (PP_EDGE_R=2 / pp_debug_set_edge_R): it was the better choice for multi-round sizes while the kernels were
+// confined to one wave per SIMD, and lost to two co-resident R = 1 workgroups on every workload once they were not
+// (T1124 32.8 vs 42.4 k residues/s, S1500 41.5 vs 46.6, C5 shard 43.5 vs 51.0).
+static int g_forced_R = -1;
 extern "C" void pp_debug_set_edge_R(int R) { g_forced_R = R; }
 static int pick_R(int N) {
+    (void)N;
     if (g_forced_R < 0) {
         const char *e = getenv("PP_EDGE_R");
         g_forced_R = e ? atoi(e) : 0;
     }
-    if (g_forced_R >= 1 && g_forced_R <= PP_RMAX) return g_forced_R;
-    const float cost[3] = {0.f, 1.f, 1.78f};
-    int best = 1;
-    float best_t = 1e30f;
-    for (int R = 1; R <= PP_RMAX; R++) {
-        const int wgs = (N + R - 1) / R, rounds = (wgs + g_num_cu - 1) / g_num_cu;
-        const float t = rounds * cost[R];
-        if (t < best_t - 1e-6f) { best_t = t; best = R; }
-    }
-    return best;
+    return g_forced_R >= 1 && g_forced_R <= PP_RMAX ? g_forced_R : 1;
 }
 
 // resident workgroups per CU the runtime predicts for the two kernels (measurement aid)

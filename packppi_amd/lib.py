@@ -12,7 +12,7 @@ import torch
 from . import constants as rc
 from .weights import check_state_dict
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libpackppi_hip.so")
+_LIB_PATH = os.environ.get("PACKPPI_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libpackppi_hip.so")     # PACKPPI_LIB: A/B runs of build variants
 _lib = None
 
 SYMBOLS = ("pp_version", "pp_last_error", "pp_plan_create", "pp_plan_destroy", "pp_plan_set_clash_params",
