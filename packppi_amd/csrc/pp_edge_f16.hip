@@ -38,17 +38,31 @@ struct HT {
 // so that hipcc emits v_cvt_pk_f16_f32 / v_pk_add_f32: 2.5 VALU instructions per value (3.5 with RELU).
 typedef float f32x2v __attribute__((ext_vector_type(2)));
 typedef _Float16 h2v __attribute__((ext_vector_type(2)));
-// f32 pair -> packed f16 by v_cvt_pkrtz_f16_f32 (round toward zero), NOT by gfx950's v_cvt_pk_f16_f32 / v_cvt_f16_f32
-// (round to nearest even, what __builtin_convertvector and a plain cast emit): with the latter these kernels are only
-// correct while a wave has its SIMD to itself -- with two or more waves per SIMD, lanes 16-31 and 48-63 of some tiles come
-// out wrong, run-to-run different (the "occupancy hazard" of DESIGN.md section 4: not the LDS-DMA, not the MFMA chains,
-// not the exchange buffers -- replacing this one instruction made 2 workgroups per CU bit-reproducible).  The split does
-// not care which way hi is rounded: lo = x - hi is exact either way, and hi + lo still carries 21-22 bits of x.
+// f32 pair -> packed f16 by v_cvt_pkrtz_f16_f32 (round toward zero), NOT by gfx950's new v_cvt_pk_f16_f32 (round to nearest
+// even; what __builtin_convertvector and plain casts of a pair compile to).  With v_cvt_pk_f16_f32 these kernels are only
+// correct while a wave has its SIMD to itself: with two or more waves per SIMD, lanes 16-31 and 48-63 of some tiles come
+// out wrong, differently from run to run (the "occupancy hazard" of DESIGN.md section 4 -- not the LDS-DMA, not the MFMA
+// chains, not the exchange buffers).  Measured with tools/debug/soak.py at two workgroups per CU: -DPP_X_CVT_PK fails on
+// every size, this function and -DPP_X_CVT_SCALAR (the old v_cvt_f16_f32 twice + v_pack_b32_f16, round to nearest) are
+// bit-reproducible.  The split does not care which way hi is rounded: lo = x - hi is exact either way and hi + lo still
+// carries 21 bits of x; pkrtz is one instruction per pair.
 typedef __fp16 fp16x2_t __attribute__((ext_vector_type(2)));
+#if defined(PP_X_CVT_SCALAR)      /* experiment: round-to-nearest through the pre-gfx950 scalar conversion + pack */
+__device__ __forceinline__ h2v cvt2(f32x2v x) {
+    unsigned a, b, p;
+    asm("v_cvt_f16_f32 %0, %1" : "=v"(a) : "v"(x[0]));
+    asm("v_cvt_f16_f32 %0, %1" : "=v"(b) : "v"(x[1]));
+    asm("v_pack_b32_f16 %0, %1, %2" : "=v"(p) : "v"(a), "v"(b));
+    return __builtin_bit_cast(h2v, p);
+}
+#elif defined(PP_X_CVT_PK)        /* experiment: gfx950's packed round-to-nearest conversion (what a plain cast compiles to) */
+__device__ __forceinline__ h2v cvt2(f32x2v x) { return __builtin_convertvector(x, h2v); }
+#else
 __device__ __forceinline__ h2v cvt2(f32x2v x) {
     const fp16x2_t r = __builtin_amdgcn_cvt_pkrtz(x[0], x[1]);
     return __builtin_bit_cast(h2v, r);
 }
+#endif
 template <bool RELU>
 __device__ __forceinline__ void split_tile(const f32x16 &v, HT &o) {
 #pragma unroll
