@@ -9,12 +9,10 @@
 // layer is split by linearity, the edge update goes straight on to the next layer's node message.  What differs:
 //   * arithmetic: every fp32 product is three v_mfma_f32_32x32x16_f16 on two-way f16 splits (below);
 //   * weights go global memory -> registers (no LDS-DMA ring), three stages ahead of their use;
-//   * a layer's input is read from LDS tile by tile, a stage ahead of its use, never held as a whole vector in registers;
-//     LayerNorm statistics are reduced per wave and merged across the four waves (Chan): ~140 VGPRs, 38.4 KB of LDS ->
-//     three workgroups per CU;
-//   * f32 -> f16 conversions go through v_cvt_pkrtz_f16_f32 (see cvt2 below: with gfx950's v_cvt_pk_f16_f32 the kernels
-//     were only correct with one wave per SIMD).
-// Measured (MI355X, T1124, 100 steps): 45.5 k residues/s against 26.6 k for pp_edge.hip.
+//   * occupancy: two workgroups per CU (223 VGPRs, 20.5 KB of LDS each);
+//   * f32 -> f16 conversions go through v_cvt_pkrtz_f16_f32 (see cvt2 below: with gfx950's round-to-nearest conversion
+//     instructions the kernels were only correct with one wave per SIMD).
+// Measured (MI355X, T1124, 100 steps): 42.4 k residues/s against 26.6 k for pp_edge.hip.
 #include "pp_internal.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -135,7 +133,7 @@ enum { P_BMID = 0, P_BOUT = 128, P_FOB = 256, P_G2 = 384, P_BE2 = 512, P_FIB = 6
 #define PP_WDEPTH 2
 #endif
 #ifndef PP_WGS
-#define PP_WGS 3           // register budget = 512 / PP_WGS per lane: three workgroups per CU (the kernels need ~140 VGPRs, 38.4 KB of LDS)
+#define PP_WGS 2           // register budget = 512 / PP_WGS per lane; > 1 only for the occupancy experiments (tools/debug)
 #endif
 #define NRING (PP_WDEPTH + 1)
 
@@ -175,25 +173,16 @@ __device__ __forceinline__ void mfma_x(const AOp &a, const HT (&x)[R][4], f32x16
     }
 }
 // same with one tile per residue (the FFN's hidden tiles, read from the exchange buffer stage by stage)
-template <int R, bool SWAP = false>
+template <int R>
 __device__ __forceinline__ void mfma_h(const AOp &a, const HT (&x)[R], f32x16 (&acc)[R]) {
 #pragma unroll
     for (int s = 0; s < 2; s++) {
-        if (SWAP) {
 #pragma unroll
-            for (int r = 0; r < R; r++) acc[r] = MFMA16(x[r].hi[s], a.r[2 * s], acc[r]);
+        for (int r = 0; r < R; r++) acc[r] = MFMA16(a.r[2 * s], x[r].hi[s], acc[r]);
 #pragma unroll
-            for (int r = 0; r < R; r++) acc[r] = MFMA16(x[r].lo[s], a.r[2 * s], acc[r]);
+        for (int r = 0; r < R; r++) acc[r] = MFMA16(a.r[2 * s], x[r].lo[s], acc[r]);
 #pragma unroll
-            for (int r = 0; r < R; r++) acc[r] = MFMA16(x[r].hi[s], a.r[2 * s + 1], acc[r]);
-        } else {
-#pragma unroll
-            for (int r = 0; r < R; r++) acc[r] = MFMA16(a.r[2 * s], x[r].hi[s], acc[r]);
-#pragma unroll
-            for (int r = 0; r < R; r++) acc[r] = MFMA16(a.r[2 * s], x[r].lo[s], acc[r]);
-#pragma unroll
-            for (int r = 0; r < R; r++) acc[r] = MFMA16(a.r[2 * s + 1], x[r].hi[s], acc[r]);
-        }
+        for (int r = 0; r < R; r++) acc[r] = MFMA16(a.r[2 * s + 1], x[r].hi[s], acc[r]);
     }
 }
 // the 72 invariant-point features as operands: global k-step S = 0..4 carries features 16 S + 8 h + i (zero beyond 71);
@@ -358,31 +347,12 @@ __device__ __forceinline__ void edge_geometry(const float *__restrict__ pts_i, c
         _Pragma("unroll") for (int r_ = 0; r_ < R; r_++) asm volatile("" ::"v"(ACC[r_][0]));                   \
     }
 
-// ---- activations between layers -----------------------------------------------------------------------------------
-// A layer's input (B operands) is read from LDS tile by tile, one stage ahead of its use, into two rotating operand sets
-// `bt` -- never as a whole 128-feature vector in registers (64 VGPRs): that is what lets three workgroups share a CU
-// (<= 168 VGPRs).  Buffers per residue: xbuf (the exchange buffer every layer publishes into) and, in the edge update,
-// x1buf (the LayerNorm-2 output, which all four FFN blocks and nobody else read) -- 16 KB each, split-f16 tiles.
+// publish this wave's tile of every residue (ReLU, split) and meet the other waves
 #ifdef PP_X_DRAIN
 #define MFMA_DRAIN() asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory")
 #else
 #define MFMA_DRAIN()
 #endif
-#define BT_FETCH(BUF, t, set)                                                     \
-    _Pragma("unroll") for (int r = 0; r < R; r++) xbuf_get_h((BUF) + r * XBUF_FLOATS, t, lane, bt[set][r]);
-// stage k: B operand = tile T of BUF (tile T+1 is requested first), SWAP as in mfma_h
-#define XSTAGE(k, NCH, ACC, BUF, T, SWAP)                                         \
-    WSTAGE(k, NCH, ACC, {                                                         \
-        if constexpr ((T) < 3) { BT_FETCH(BUF, (T) + 1, ((T) + 1) & 1) }          \
-        (mfma_h<R, SWAP>(AK, bt[(T) & 1], ACC));                                  \
-    })
-#define XLAYER(k0, NCH, ACC, BUF, SWAP)                                           \
-    BT_FETCH(BUF, 0, 0)                                                           \
-    XSTAGE((k0) + 0, NCH, ACC, BUF, 0, SWAP)                                      \
-    XSTAGE((k0) + 1, NCH, ACC, BUF, 1, SWAP)                                      \
-    XSTAGE((k0) + 2, NCH, ACC, BUF, 2, SWAP)                                      \
-    XSTAGE((k0) + 3, NCH, ACC, BUF, 3, SWAP)
-// publish this wave's tile of every residue (ReLU, split) into xbuf and meet the other waves
 #define PUBLISH_RELU()                                                            \
     MFMA_DRAIN();                                                                 \
     _Pragma("unroll") for (int r = 0; r < R; r++) {                               \
@@ -391,24 +361,29 @@ __device__ __forceinline__ void edge_geometry(const float *__restrict__ pts_i, c
         xbuf_put_h(xbuf + r * XBUF_FLOATS, wave, lane, ht);                       \
     }                                                                             \
     __syncthreads();
+#define FETCH_X()                                                                 \
+    _Pragma("unroll") for (int r = 0; r < R; r++)                                 \
+        _Pragma("unroll") for (int t = 0; t < 4; t++) xbuf_get_h(xbuf + r * XBUF_FLOATS, t, lane, x[r][t]);
 
 // shared first layer: acc (tile `wave`) = PA_i + PC_j + W_B h_E + W_G geom, ReLU.  Chunks W_B x4 (absent when ST0:
 // layer 0's W_B h_E0 is timestep-invariant and arrives precomputed in acc), then W_G x3.  C0 = number of W_B chunks.
-// The h_E tiles were published into xbuf by the prologue (each wave its own tile).
 #define FIRST_LAYER(NCH)                                                          \
     if constexpr (!ST0) {                                                         \
-        XLAYER(0, NCH, acc, xbuf, false)                                          \
+        WSTAGE(0, NCH, acc, (mfma_x<R, 0, false>(AK, x, acc)))                         \
+        WSTAGE(1, NCH, acc, (mfma_x<R, 1, false>(AK, x, acc)))                         \
+        WSTAGE(2, NCH, acc, (mfma_x<R, 2, false>(AK, x, acc)))                         \
+        WSTAGE(3, NCH, acc, (mfma_x<R, 3, false>(AK, x, acc)))                         \
     }                                                                             \
-    WSTAGE(C0 + 0, NCH, acc, (mfma_geo<R, 0>(AK, g, acc)))                        \
-    WSTAGE(C0 + 1, NCH, acc, (mfma_geo<R, 1>(AK, g, acc)))                        \
-    WSTAGE(C0 + 2, NCH, acc, (mfma_geo<R, 2>(AK, g, acc)))                        \
-    if constexpr (!ST0) { __syncthreads(); }     /* every wave has read the h_E tiles */ \
+    WSTAGE(C0 + 0, NCH, acc, (mfma_geo<R, 0>(AK, g, acc)))                             \
+    WSTAGE(C0 + 1, NCH, acc, (mfma_geo<R, 1>(AK, g, acc)))                             \
+    WSTAGE(C0 + 2, NCH, acc, (mfma_geo<R, 2>(AK, g, acc)))                             \
     PUBLISH_RELU()
 
 #define PROLOGUE_PIPE(NCH)                                                                                     \
     const h8 *wq = reinterpret_cast<const h8 *>(A.wstream) + wave * 256 + lane;    /* this wave's quarter, this lane */ \
     AOp AR[NRING];                                                                                             \
     _Pragma("unroll") for (int pk = 0; pk < PP_WDEPTH && pk < (NCH); pk++) gload_A(wq, pk, AR[pk]);
+#define PROLOGUE_OPERANDS()
 
 // The R residues of workgroup b are rows b R .. b R + R - 1.  `live` = in range and not masked; a dead slot computes on
 // a live residue's inputs (no garbage enters the pipes) and stores nothing.  All of it is wave-uniform.
@@ -424,47 +399,11 @@ __device__ __forceinline__ void edge_geometry(const float *__restrict__ pts_i, c
         if (live[r] && first < 0) first = n[r];                                                \
     }
 
-// LayerNorm over the 128 features of an edge whose four 32-feature tiles sit in four different waves: every wave
-// reduces its own tile (mean and centred sum of squares of 32 values: 16 here, 16 in lane ^ 32), the four partials meet
-// in a 1 KB LDS block `st` ([wave][edge] float2) and are merged with the pairwise update of Chan et al. (equal counts),
-// which is as stable as the reference's two-pass variance.  ln_partial: before the barrier; ln_merge: after it.
-__device__ __forceinline__ void ln_partial(const f32x16 &v, float *st, int wave, int j, int h) {
-    float s = 0.f;
-#pragma unroll
-    for (int q = 0; q < 16; q++) s += v[q];
-    s += __shfl_xor(s, 32);
-    const float m = s * (1.f / 32.f);
-    float q2 = 0.f;
-#pragma unroll
-    for (int q = 0; q < 16; q++) {
-        const float d = v[q] - m;
-        q2 = fmaf(d, d, q2);
-    }
-    q2 += __shfl_xor(q2, 32);
-    if (h == 0) {
-        f32x2v o = {m, q2};
-        *reinterpret_cast<f32x2v *>(st + (wave * 32 + j) * 2) = o;
-    }
-}
-__device__ __forceinline__ float ln_merge(const float *st, int j, float &mean_out) {
-    f32x2v p[4];
-#pragma unroll
-    for (int w = 0; w < 4; w++) p[w] = *reinterpret_cast<const f32x2v *>(st + (w * 32 + j) * 2);
-    const float mean = 0.25f * ((p[0][0] + p[1][0]) + (p[2][0] + p[3][0]));
-    float m2 = (p[0][1] + p[1][1]) + (p[2][1] + p[3][1]);
-#pragma unroll
-    for (int w = 0; w < 4; w++) {
-        const float d = p[w][0] - mean;
-        m2 = fmaf(32.f * d, d, m2);
-    }
-    mean_out = mean;
-    return 1.f / sqrtf(m2 * (1.f / 128.f) + 1e-5f);
-}
-#define STAT_FLOATS 256
-
 // ---------------------------------------------------------------------------------------------
 // node message: S[i] = (1/K) sum_j mask_ij relu(W_mid relu(W_in [..]) + b), msum[i] = (1/K) sum_j mask_ij
 // ---------------------------------------------------------------------------------------------
+// ONE workgroup per CU (one wave per SIMD), enforced by the LDS request (ring + R exchange buffers > 80 KB).
+
 template <int R, bool ST0>
 __global__ void __launch_bounds__(ET, R == 1 ? PP_WGS : 1)
 k_node_message(EdgeArgs A) {
@@ -489,7 +428,7 @@ k_node_message(EdgeArgs A) {
     constexpr int NCH = C0 + 7;           // chunks: [W_B x4,] W_G x3, W_mid x4
     PROLOGUE_PIPE(NCH)
 
-    HT bt[2][R];
+    HT x[R][4];
     f32x16 acc[R];
     HG g[R];
     const int jj = j < K ? j : K - 1;
@@ -499,23 +438,25 @@ k_node_message(EdgeArgs A) {
         const int nbr = A.eidx[(size_t)n[r] * K + jj];
         edge_geometry(A.pts + (size_t)n[r] * 48, A.frames + (size_t)n[r] * 12, A.pts + (size_t)nbr * 48, h, g[r]);
         const float *hrow = A.hE_in + ((size_t)n[r] * K + jj) * 128;
-        if constexpr (!ST0) {             // this wave's tile of h_E -> split -> exchange buffer
-            HT ht;
-            load_tile(hrow + 32 * wave, h, acc[r]);
-            split_tile<false>(acc[r], ht);
-            xbuf_put_h(xbuf + r * XBUF_FLOATS, wave, lane, ht);
+        if constexpr (!ST0) {
+#pragma unroll
+            for (int t = 0; t < 4; t++) { load_tile(hrow + 32 * t, h, acc[r]); split_tile<false>(acc[r], x[r][t]); }
         }
         load_tile(A.PA + (size_t)n[r] * 128 + 32 * wave, h, acc[r]);
         add_tile(A.PC + (size_t)nbr * 128 + 32 * wave, h, acc[r]);
         if constexpr (ST0) add_tile(A.Z + ((size_t)n[r] * K + jj) * 128 + 32 * wave, h, acc[r]);
     }
-    if constexpr (!ST0) { __syncthreads(); }
+    PROLOGUE_OPERANDS()
     FIRST_LAYER(NCH)
+    FETCH_X()
 #pragma unroll
     for (int r = 0; r < R; r++)
 #pragma unroll
         for (int q = 0; q < 16; q++) acc[r][q] = bmid;
-    XLAYER(C0 + 3, NCH, acc, xbuf, true)
+    WSTAGE(C0 + 3, NCH, acc, (mfma_x<R, 0, true>(AK, x, acc)))
+    WSTAGE(C0 + 4, NCH, acc, (mfma_x<R, 1, true>(AK, x, acc)))
+    WSTAGE(C0 + 5, NCH, acc, (mfma_x<R, 2, true>(AK, x, acc)))
+    WSTAGE(C0 + 6, NCH, acc, (mfma_x<R, 3, true>(AK, x, acc)))
     MFMA_DRAIN();
 #pragma unroll
     for (int r = 0; r < R; r++) {
@@ -543,14 +484,38 @@ k_node_message(EdgeArgs A) {
 // ---------------------------------------------------------------------------------------------
 // edge update: h_E <- mask * LN3(x1 + FFN(x1)),  x1 = LN2(h_E + mask * MLP3([..]))
 // ---------------------------------------------------------------------------------------------
-// FFN hidden block c (chunks 15 + 8c ..): W1 s=0..3 (input: the x1 tiles) -> hidden tile 4c+wave -> exchange ->
-// W2 s'=0..3 accumulate into out
+// FFN hidden block c (chunks 15 + 8c ..): W1 s=0..3 -> hidden tile 4c+wave -> exchange -> W2 s'=0..3 accumulate into out
+// the hidden tile of stage t+1 is read from the exchange buffer while stage t computes (two operand sets);
+// -DPP_HK_SETS=1: read in the stage that uses it (16 registers less)
+#ifndef PP_HK_SETS
+#define PP_HK_SETS 2
+#endif
+#define FFN_W2(kk, t)                                                                                        \
+    WSTAGE(kk, NCH, out, {                                                                                   \
+        if constexpr (PP_HK_SETS == 2 && (t) < 3) {                                                          \
+            _Pragma("unroll") for (int r = 0; r < R; r++)                                                    \
+                xbuf_get_h(xbuf + r * XBUF_FLOATS, (t) + 1, lane, hk[((t) + 1) & 1][r]);                     \
+        }                                                                                                    \
+        if constexpr (PP_HK_SETS == 1) {                                                                     \
+            _Pragma("unroll") for (int r = 0; r < R; r++) xbuf_get_h(xbuf + r * XBUF_FLOATS, t, lane, hk[0][r]); \
+        }                                                                                                    \
+        mfma_h<R>(AK, hk[PP_HK_SETS == 2 ? (t) & 1 : 0], out);                                               \
+    })
 #define FFN_BLOCK(c)                                                                                         \
     _Pragma("unroll") for (int r = 0; r < R; r++) load_tile(prm + P_FIB + 128 * (c) + 32 * wave, h, acc[r]); \
-    XLAYER(C0 + 11 + 8 * (c), NCH, acc, x1buf, false)                                                        \
+    WSTAGE(C0 + 11 + 8 * (c) + 0, NCH, acc, (mfma_x<R, 0, false>(AK, x, acc)))                                   \
+    WSTAGE(C0 + 11 + 8 * (c) + 1, NCH, acc, (mfma_x<R, 1, false>(AK, x, acc)))                                   \
+    WSTAGE(C0 + 11 + 8 * (c) + 2, NCH, acc, (mfma_x<R, 2, false>(AK, x, acc)))                                   \
+    WSTAGE(C0 + 11 + 8 * (c) + 3, NCH, acc, (mfma_x<R, 3, false>(AK, x, acc)))                                   \
     __syncthreads();          /* every wave is done reading the previous exchange */                        \
     PUBLISH_RELU()                                                                                           \
-    XLAYER(C0 + 11 + 8 * (c) + 4, NCH, out, xbuf, false)
+    if constexpr (PP_HK_SETS == 2) {                                                                         \
+        _Pragma("unroll") for (int r = 0; r < R; r++) xbuf_get_h(xbuf + r * XBUF_FLOATS, 0, lane, hk[0][r]); \
+    }                                                                                                        \
+    FFN_W2(C0 + 11 + 8 * (c) + 4, 0)                                                                         \
+    FFN_W2(C0 + 11 + 8 * (c) + 5, 1)                                                                         \
+    FFN_W2(C0 + 11 + 8 * (c) + 6, 2)                                                                         \
+    FFN_W2(C0 + 11 + 8 * (c) + 7, 3)
 
 // -DPP_X_TS: phase timestamps (s_memtime, core-clock cycles since kernel start) of wave 0 to dbg[n][24]
 // (tools/debug/phase_times.py)
@@ -566,8 +531,7 @@ template <int R, bool ST0, bool FUSE>
 __global__ void __launch_bounds__(ET, R == 1 ? PP_WGS : 1)
 k_edge_update(EdgeArgs A) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *xbuf = smem, *x1buf = smem + R * XBUF_FLOATS, *stat = smem + 2 * R * XBUF_FLOATS,
-          *prm = stat + R * STAT_FLOATS;
+    float *xbuf = smem, *prm = xbuf + R * XBUF_FLOATS;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, h = lane >> 5;
@@ -602,12 +566,14 @@ k_edge_update(EdgeArgs A) {
 #endif
     PROLOGUE_PIPE(NCH)
 
-    HT bt[2][R];
+    HT x[R][4], hk[PP_HK_SETS][R];
     f32x16 acc[R], out[R];
     HG g[R];
     int nbr[R];
     float me[R];
     // the small per-layer vectors go to LDS once (published by the first exchange barrier)
+    // (no divergent control flow while a weight copy is in flight -- see HAZARD: the surplus threads of the second trip
+    //  rewrite the last float4 with the same value instead of being masked off)
 #pragma unroll
     for (int it = 0; it < (PARAM_FLOATS / 4 + ET - 1) / ET; it++) {
         const int i = min(tid + it * ET, PARAM_FLOATS / 4 - 1);
@@ -618,60 +584,67 @@ k_edge_update(EdgeArgs A) {
         nbr[r] = A.eidx[(size_t)n[r] * K + jj];
         me[r] = A.mask_att[(size_t)n[r] * 32 + jj];            // (lanes j >= K mirror edge K - 1 throughout)
         edge_geometry(A.pts + (size_t)n[r] * 48, A.frames + (size_t)n[r] * 12, A.pts + (size_t)nbr[r] * 48, h, g[r]);
-        // this wave's tile of h_E: the residual input of the first LayerNorm (kept in `out`) and, split, a quarter of
-        // the first layer's B operands (published; layer 0 needs no B operands: W_B h_E0 arrives in Z)
-        load_tile(A.hE_in + ((size_t)n[r] * K + jj) * 128 + 32 * wave, h, out[r]);
+        const float *hrow = A.hE_in + ((size_t)n[r] * K + jj) * 128;
         if constexpr (!ST0) {
-            HT ht;
-            split_tile<false>(out[r], ht);
-            xbuf_put_h(xbuf + r * XBUF_FLOATS, wave, lane, ht);
+#pragma unroll
+            for (int t = 0; t < 4; t++) { load_tile(hrow + 32 * t, h, acc[r]); split_tile<false>(acc[r], x[r][t]); }
         }
         load_tile(A.PA + (size_t)n[r] * 128 + 32 * wave, h, acc[r]);
         add_tile(A.PC + (size_t)nbr[r] * 128 + 32 * wave, h, acc[r]);
         if constexpr (ST0) add_tile(A.Z + ((size_t)n[r] * K + jj) * 128 + 32 * wave, h, acc[r]);
     }
-    if constexpr (!ST0) { __syncthreads(); }
     TS(0)
+    PROLOGUE_OPERANDS()
     FIRST_LAYER(NCH)
     TS(1)
     // ---- second layer (chunks 7..10) -------------------------------------------------------------
+    FETCH_X()
 #pragma unroll
     for (int r = 0; r < R; r++) load_tile(prm + P_BMID + 32 * wave, h, acc[r]);
-    XLAYER(C0 + 3, NCH, acc, xbuf, false)
+    WSTAGE(C0 + 3, NCH, acc, (mfma_x<R, 0, false>(AK, x, acc)))
+    WSTAGE(C0 + 4, NCH, acc, (mfma_x<R, 1, false>(AK, x, acc)))
+    WSTAGE(C0 + 5, NCH, acc, (mfma_x<R, 2, false>(AK, x, acc)))
+    WSTAGE(C0 + 6, NCH, acc, (mfma_x<R, 3, false>(AK, x, acc)))
     TS(2)
     __syncthreads();
     PUBLISH_RELU()
     TS(3)
     // ---- third layer (chunks 11..14) --------------------------------------------------------------
+    FETCH_X()
 #pragma unroll
     for (int r = 0; r < R; r++) load_tile(prm + P_BOUT + 32 * wave, h, acc[r]);
-    XLAYER(C0 + 7, NCH, acc, xbuf, false)
+    WSTAGE(C0 + 7, NCH, acc, (mfma_x<R, 0, false>(AK, x, acc)))
+    WSTAGE(C0 + 8, NCH, acc, (mfma_x<R, 1, false>(AK, x, acc)))
+    WSTAGE(C0 + 9, NCH, acc, (mfma_x<R, 2, false>(AK, x, acc)))
+    WSTAGE(C0 + 10, NCH, acc, (mfma_x<R, 3, false>(AK, x, acc)))
     TS(4)
-    // ---- x1 = LN2(h_E + mask * m): own tile only, statistics merged across the four waves ---------------
-    MFMA_DRAIN();
+    // publish v = h_E + mask * m for the first LayerNorm (own tile: read, then overwritten in place)
 #pragma unroll
     for (int r = 0; r < R; r++) {
+        load_tile(A.hE_in + ((size_t)n[r] * K + jj) * 128 + 32 * wave, h, out[r]);   // residual (L2-resident re-read)
 #pragma unroll
         for (int q = 0; q < 16; q++) out[r][q] = fmaf(acc[r][q], me[r], out[r][q]);
-        ln_partial(out[r], stat + r * STAT_FLOATS, wave, j, h);
     }
+    __syncthreads();                            // every wave has its B operands of this layer
+#pragma unroll
+    for (int r = 0; r < R; r++) xbuf_put(xbuf + r * XBUF_FLOATS, wave, lane, out[r]);
     __syncthreads();
     TS(5)
 #pragma unroll
     for (int r = 0; r < R; r++) {
-        float mean;
-        const float rstd = ln_merge(stat + r * STAT_FLOATS, j, mean);
+        // x1 = LN2(v): every wave normalises the full vector in fp32 (it needs all of x1 as B operands), then splits it
+        f32x16 v4[4];
 #pragma unroll
-        for (int q = 0; q < 16; q++) out[r][q] -= mean;
-        ln_affine_tile(out[r], rstd, prm + P_G2 + 32 * wave, prm + P_BE2 + 32 * wave, h);
-        HT ht;
-        split_tile<false>(out[r], ht);
-        xbuf_put_h(x1buf + r * XBUF_FLOATS, wave, lane, ht);
-        // `out` keeps x1 (this wave's tile, fp32) as the residual of the second LayerNorm and collects the FFN output
-        // on top of it: out = x1 + b + W2 relu(W1 x1 + b1)
-        add_tile(prm + P_FOB + 32 * wave, h, out[r]);
+        for (int t = 0; t < 4; t++) xbuf_get(xbuf + r * XBUF_FLOATS, t, lane, v4[t]);
+        float mean;
+        float rstd = ln_center(v4, mean);
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            ln_affine_tile(v4[t], rstd, prm + P_G2 + 32 * t, prm + P_BE2 + 32 * t, h);
+            split_tile<false>(v4[t], x[r][t]);
+        }
+        load_tile(prm + P_FOB + 32 * wave, h, out[r]);
     }
-    __syncthreads();
     TS(6)
     // ---- FFN 128 -> 512 -> 128 in four hidden blocks of 128 ------------------------------------------
     FFN_BLOCK(0)
@@ -683,15 +656,30 @@ k_edge_update(EdgeArgs A) {
     FFN_BLOCK(3)
     TS(10)
     // ---- h_E = mask * LN3(x1 + ffn) ---------------------------------------------------------------------
-    MFMA_DRAIN();
+    // residual: this wave's tile of x1, rebuilt from its split form (wave is scalar: uniform branches, static indices)
 #pragma unroll
-    for (int r = 0; r < R; r++) ln_partial(out[r], stat + r * STAT_FLOATS, wave, j, h);
+    for (int r = 0; r < R; r++) {
+        if (wave == 0) join_tile(x[r][0], acc[r]);
+        else if (wave == 1) join_tile(x[r][1], acc[r]);
+        else if (wave == 2) join_tile(x[r][2], acc[r]);
+        else join_tile(x[r][3], acc[r]);
+#pragma unroll
+        for (int q = 0; q < 16; q++) out[r][q] += acc[r][q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < R; r++) xbuf_put(xbuf + r * XBUF_FLOATS, wave, lane, out[r]);
     __syncthreads();
     TS(11)
 #pragma unroll
     for (int r = 0; r < R; r++) {
-        float mean3;
-        const float rstd = ln_merge(stat + r * STAT_FLOATS, j, mean3);
+        float mean3, rstd;
+        {
+            f32x16 v4[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) xbuf_get(xbuf + r * XBUF_FLOATS, t, lane, v4[t]);
+            rstd = ln_center(v4, mean3);
+        }
 #pragma unroll
         for (int q = 0; q < 16; q++) out[r][q] -= mean3;
         ln_affine_tile(out[r], rstd, A.g3 + 32 * wave, A.be3 + 32 * wave, h);
@@ -703,42 +691,57 @@ k_edge_update(EdgeArgs A) {
     TS(12)
     if constexpr (FUSE) {
         // ---- next layer's node message on the fresh edges ------------------------------------------------
-        // (xbuf was last read by the W2 stages of the last FFN block: every wave has passed the LayerNorm barrier since)
+        __syncthreads();                                      // every wave has read the LayerNorm exchange
 #pragma unroll
         for (int r = 0; r < R; r++) {
             HT ht;
             split_tile<false>(out[r], ht);
             xbuf_put_h(xbuf + r * XBUF_FLOATS, wave, lane, ht);
-            edge_geometry(A.pts2 + (size_t)n[r] * 48, A.frames + (size_t)n[r] * 12, A.pts2 + (size_t)nbr[r] * 48, h, g[r]);
-            load_tile(A.PA2 + (size_t)n[r] * 128 + 32 * wave, h, acc[r]);
-            add_tile(A.PC2 + (size_t)nbr[r] * 128 + 32 * wave, h, acc[r]);
+        }
+        // `out` is dead from here; its inputs are fetched here and not earlier: offsets made opaque behind `out`
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            int o_pts = n[r] * 48, o_fr = n[r] * 12, o_pa = n[r] * 128;
+            int o_ptsj = nbr[r] * 48, o_pc = nbr[r] * 128;
+            asm volatile("" : "+s"(o_pts), "+s"(o_fr), "+s"(o_pa), "+v"(o_ptsj), "+v"(o_pc) : "v"(out[r][0]) : "memory");
+            edge_geometry(A.pts2 + o_pts, A.frames + o_fr, A.pts2 + o_ptsj, h, g[r]);
+            load_tile(A.PA2 + o_pa + 32 * wave, h, acc[r]);
+            add_tile(A.PC2 + o_pc + 32 * wave, h, acc[r]);
         }
         const float bmid = A.b_mid2[32 * wave + j];           // SWAP form: feature on the lane
         __syncthreads();
+        FETCH_X()
         TS(13)
-        XLAYER(NEU + 0, NCH, acc, xbuf, false)
+        WSTAGE(NEU + 0, NCH, acc, (mfma_x<R, 0, false>(AK, x, acc)))
+        WSTAGE(NEU + 1, NCH, acc, (mfma_x<R, 1, false>(AK, x, acc)))
+        WSTAGE(NEU + 2, NCH, acc, (mfma_x<R, 2, false>(AK, x, acc)))
+        WSTAGE(NEU + 3, NCH, acc, (mfma_x<R, 3, false>(AK, x, acc)))
         WSTAGE(NEU + 4, NCH, acc, (mfma_geo<R, 0>(AK, g, acc)))
         WSTAGE(NEU + 5, NCH, acc, (mfma_geo<R, 1>(AK, g, acc)))
         WSTAGE(NEU + 6, NCH, acc, (mfma_geo<R, 2>(AK, g, acc)))
         TS(14)
         __syncthreads();
         PUBLISH_RELU()
+        FETCH_X()
 #pragma unroll
         for (int r = 0; r < R; r++)
 #pragma unroll
             for (int q = 0; q < 16; q++) acc[r][q] = bmid;
         TS(15)
-        XLAYER(NEU + 7, NCH, acc, xbuf, true)
+        WSTAGE(NEU + 7, NCH, acc, (mfma_x<R, 0, true>(AK, x, acc)))
+        WSTAGE(NEU + 8, NCH, acc, (mfma_x<R, 1, true>(AK, x, acc)))
+        WSTAGE(NEU + 9, NCH, acc, (mfma_x<R, 2, true>(AK, x, acc)))
+        WSTAGE(NEU + 10, NCH, acc, (mfma_x<R, 3, true>(AK, x, acc)))
         TS(16)
-        MFMA_DRAIN();
 #pragma unroll
         for (int r = 0; r < R; r++) {
             // rows (registers) are edges e = 8 (r>>2) + 4 h + (r&3); mask and reduce over them
-            const float *mrow = A.mask_att + (size_t)n[r] * 32 + 4 * h;
+            int o_m = n[r] * 32 + 4 * h;
+            asm volatile("" : "+v"(o_m) : "v"(acc[r][0]));
             float sacc = 0.f, ms = 0.f;
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                const f32x4v mm = *reinterpret_cast<const f32x4v *>(mrow + 8 * q);
+                const f32x4v mm = *reinterpret_cast<const f32x4v *>(A.mask_att + o_m + 8 * q);
 #pragma unroll
                 for (int pq = 0; pq < 4; pq++) {
                     sacc = fmaf(fmaxf(acc[r][4 * q + pq], 0.f), mm[pq], sacc);
@@ -784,6 +787,7 @@ k_edge_static(EdgeArgs A) {
     for (int t = 0; t < 4; t++) { load_tile(hrow + 32 * t, h, acc[0]); split_tile<false>(acc[0], x[0][t]); }
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[0][r] = 0.f;
+    PROLOGUE_OPERANDS()
     WSTAGE(0, NCH, acc, (mfma_x<1, 0, false>(AK, x, acc)))
     WSTAGE(1, NCH, acc, (mfma_x<1, 1, false>(AK, x, acc)))
     WSTAGE(2, NCH, acc, (mfma_x<1, 2, false>(AK, x, acc)))
@@ -840,7 +844,7 @@ static size_t g_lds_pad = PP_LDS_PAD;     // pp_debug_set_lds_pad(): occupancy e
 extern "C" void pp_debug_set_lds_pad(int bytes) { g_lds_pad = (size_t)bytes; }
 static size_t pad_smem(size_t b) { return b > g_lds_pad ? b : g_lds_pad; }
 static size_t nm_smem(int R) { return pad_smem(R * XBUF_FLOATS * sizeof(float)); }
-static size_t eu_smem(int R) { return pad_smem((2 * R * XBUF_FLOATS + R * STAT_FLOATS + PARAM_FLOATS) * sizeof(float)); }
+static size_t eu_smem(int R) { return pad_smem((R * XBUF_FLOATS + PARAM_FLOATS) * sizeof(float)); }
 #define ST_SMEM pad_smem(0)
 #define MAX_SMEM (160 * 1024)
 
