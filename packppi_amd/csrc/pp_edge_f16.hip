@@ -93,7 +93,8 @@ __device__ __forceinline__ void join_tile(const HT &t, f32x16 &v) {
 #define ET 256
 #define CH32 (128 * 32)                 // floats per packed weight chunk (16 KB); a wave's quarter is 1024 floats
 #define XBUF_FLOATS (4 * 4 * 64 * 4)    // exchange buffer: [tile][quad][lane] float4
-#define PARAM_FLOATS 1152               // edge kernel: small per-layer vectors staged once
+#define PARAM_FLOATS 1152               // edge kernel: small per-layer vectors, packed by pp_api.hip put_edge_params
+#define PARAM_LDS 640                   // ... of which b_mid | b_out | ffn_out_b | g2 | be2 are staged to LDS (ffn_in_b is read in place)
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
@@ -133,6 +134,9 @@ enum { P_BMID = 0, P_BOUT = 128, P_FOB = 256, P_G2 = 384, P_BE2 = 512, P_FIB = 6
 // written (as read-only kernel arguments the compiler would otherwise hoist all of them to the top of the kernel).
 #ifndef PP_WDEPTH
 #define PP_WDEPTH 2
+#endif
+#ifndef PP_WGS2
+#define PP_WGS2 2          // same for the two-residue instances
 #endif
 #ifndef PP_WGS
 #define PP_WGS 3           // register budget = 512 / PP_WGS per lane: three workgroups per CU (the kernels need ~140 VGPRs, 38.4 KB of LDS)
@@ -382,9 +386,15 @@ __device__ __forceinline__ void edge_geometry(const float *__restrict__ pts_i, c
     XSTAGE((k0) + 1, NCH, ACC, BUF, 1, SWAP)                                      \
     XSTAGE((k0) + 2, NCH, ACC, BUF, 2, SWAP)                                      \
     XSTAGE((k0) + 3, NCH, ACC, BUF, 3, SWAP)
-// publish this wave's tile of every residue (ReLU, split) into xbuf and meet the other waves
+// publish this wave's tile of every residue (ReLU, split) into the exchange buffer and meet the other waves.  With one
+// residue per workgroup there are TWO exchange buffers used alternately (NEXT_XBUF): a buffer is rewritten only after every
+// wave has passed the barrier of the publication in between, so no barrier is needed before writing.  With two residues
+// (LDS is short) there is one, and PRE_PUBLISH is a barrier: every wave must have read the previous exchange.
+#define NEXT_XBUF()   { if constexpr (NXB == 2) xbuf = xbuf == xb0 ? xb0 + R * XBUF_FLOATS : xb0; }
+#define PRE_PUBLISH() { if constexpr (NXB == 1) __syncthreads(); NEXT_XBUF() }
 #define PUBLISH_RELU()                                                            \
     MFMA_DRAIN();                                                                 \
+    PRE_PUBLISH()                                                                 \
     _Pragma("unroll") for (int r = 0; r < R; r++) {                               \
         HT ht;                                                                    \
         split_tile<true>(acc[r], ht);                                             \
@@ -402,7 +412,6 @@ __device__ __forceinline__ void edge_geometry(const float *__restrict__ pts_i, c
     WSTAGE(C0 + 0, NCH, acc, (mfma_geo<R, 0>(AK, g, acc)))                        \
     WSTAGE(C0 + 1, NCH, acc, (mfma_geo<R, 1>(AK, g, acc)))                        \
     WSTAGE(C0 + 2, NCH, acc, (mfma_geo<R, 2>(AK, g, acc)))                        \
-    if constexpr (!ST0) { __syncthreads(); }     /* every wave has read the h_E tiles */ \
     PUBLISH_RELU()
 
 #define PROLOGUE_PIPE(NCH)                                                                                     \
@@ -466,10 +475,12 @@ __device__ __forceinline__ float ln_merge(const float *st, int j, float &mean_ou
 // node message: S[i] = (1/K) sum_j mask_ij relu(W_mid relu(W_in [..]) + b), msum[i] = (1/K) sum_j mask_ij
 // ---------------------------------------------------------------------------------------------
 template <int R, bool ST0>
-__global__ void __launch_bounds__(ET, R == 1 ? PP_WGS : 1)
+__global__ void __launch_bounds__(ET, R == 1 ? PP_WGS : PP_WGS2)
 k_node_message(EdgeArgs A) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *xbuf = smem;
+    constexpr int NXB = R == 1 ? 2 : 1;
+    float *const xb0 = smem;
+    float *xbuf = xb0;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, h = lane >> 5;
@@ -546,9 +557,8 @@ k_node_message(EdgeArgs A) {
 // FFN hidden block c (chunks 15 + 8c ..): W1 s=0..3 (input: the x1 tiles) -> hidden tile 4c+wave -> exchange ->
 // W2 s'=0..3 accumulate into out
 #define FFN_BLOCK(c)                                                                                         \
-    _Pragma("unroll") for (int r = 0; r < R; r++) load_tile(prm + P_FIB + 128 * (c) + 32 * wave, h, acc[r]); \
+    _Pragma("unroll") for (int r = 0; r < R; r++) load_tile(A.params + P_FIB + 128 * (c) + 32 * wave, h, acc[r]); \
     XLAYER(C0 + 11 + 8 * (c), NCH, acc, x1buf, false)                                                        \
-    __syncthreads();          /* every wave is done reading the previous exchange */                        \
     PUBLISH_RELU()                                                                                           \
     XLAYER(C0 + 11 + 8 * (c) + 4, NCH, out, xbuf, false)
 
@@ -563,10 +573,12 @@ k_node_message(EdgeArgs A) {
 // holds; the node-level inputs PA2 / PC2 / pts2 were written by the node update that ran before this kernel): one
 // launch, one prologue and one read of h_E less per layer.
 template <int R, bool ST0, bool FUSE>
-__global__ void __launch_bounds__(ET, R == 1 ? PP_WGS : 1)
+__global__ void __launch_bounds__(ET, R == 1 ? PP_WGS : PP_WGS2)
 k_edge_update(EdgeArgs A) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *xbuf = smem, *x1buf = smem + R * XBUF_FLOATS, *stat = smem + 2 * R * XBUF_FLOATS,
+    constexpr int NXB = R == 1 ? 2 : 1;
+    float *const xb0 = smem;
+    float *xbuf = xb0, *x1buf = smem + NXB * R * XBUF_FLOATS, *stat = x1buf + R * XBUF_FLOATS,
           *prm = stat + R * STAT_FLOATS;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -609,8 +621,8 @@ k_edge_update(EdgeArgs A) {
     float me[R];
     // the small per-layer vectors go to LDS once (published by the first exchange barrier)
 #pragma unroll
-    for (int it = 0; it < (PARAM_FLOATS / 4 + ET - 1) / ET; it++) {
-        const int i = min(tid + it * ET, PARAM_FLOATS / 4 - 1);
+    for (int it = 0; it < (PARAM_LDS / 4 + ET - 1) / ET; it++) {
+        const int i = min(tid + it * ET, PARAM_LDS / 4 - 1);
         *reinterpret_cast<f32x4v *>(prm + 4 * i) = *reinterpret_cast<const f32x4v *>(A.params + 4 * i);
     }
 #pragma unroll
@@ -639,7 +651,6 @@ k_edge_update(EdgeArgs A) {
     for (int r = 0; r < R; r++) load_tile(prm + P_BMID + 32 * wave, h, acc[r]);
     XLAYER(C0 + 3, NCH, acc, xbuf, false)
     TS(2)
-    __syncthreads();
     PUBLISH_RELU()
     TS(3)
     // ---- third layer (chunks 11..14) --------------------------------------------------------------
@@ -703,7 +714,9 @@ k_edge_update(EdgeArgs A) {
     TS(12)
     if constexpr (FUSE) {
         // ---- next layer's node message on the fresh edges ------------------------------------------------
-        // (xbuf was last read by the W2 stages of the last FFN block: every wave has passed the LayerNorm barrier since)
+        // (the buffer written here was last read by the W2 stages of an FFN block: every wave has passed the LayerNorm
+        //  barrier since)
+        NEXT_XBUF()
 #pragma unroll
         for (int r = 0; r < R; r++) {
             HT ht;
@@ -721,7 +734,6 @@ k_edge_update(EdgeArgs A) {
         WSTAGE(NEU + 5, NCH, acc, (mfma_geo<R, 1>(AK, g, acc)))
         WSTAGE(NEU + 6, NCH, acc, (mfma_geo<R, 2>(AK, g, acc)))
         TS(14)
-        __syncthreads();
         PUBLISH_RELU()
 #pragma unroll
         for (int r = 0; r < R; r++)
@@ -839,8 +851,10 @@ static EdgeArgs edge_args(pp_ctx *c, int layer, bool edge) {
 static size_t g_lds_pad = PP_LDS_PAD;     // pp_debug_set_lds_pad(): occupancy experiments
 extern "C" void pp_debug_set_lds_pad(int bytes) { g_lds_pad = (size_t)bytes; }
 static size_t pad_smem(size_t b) { return b > g_lds_pad ? b : g_lds_pad; }
-static size_t nm_smem(int R) { return pad_smem(R * XBUF_FLOATS * sizeof(float)); }
-static size_t eu_smem(int R) { return pad_smem((2 * R * XBUF_FLOATS + R * STAT_FLOATS + PARAM_FLOATS) * sizeof(float)); }
+static size_t nm_smem(int R) { return pad_smem((R == 1 ? 2 : 1) * R * XBUF_FLOATS * sizeof(float)); }
+static size_t eu_smem(int R) {
+    return pad_smem((((R == 1 ? 2 : 1) + 1) * R * XBUF_FLOATS + R * STAT_FLOATS + PARAM_LDS) * sizeof(float));
+}
 #define ST_SMEM pad_smem(0)
 #define MAX_SMEM (160 * 1024)
 
@@ -888,12 +902,12 @@ static bool edge_attrs() {
 static int g_forced_R = -1;
 extern "C" void pp_debug_set_edge_R(int R) { g_forced_R = R; }
 static int pick_R(int N) {
-    (void)N;
     if (g_forced_R < 0) {
         const char *e = getenv("PP_EDGE_R");
         g_forced_R = e ? atoi(e) : 0;
     }
-    return g_forced_R >= 1 && g_forced_R <= PP_RMAX ? g_forced_R : 1;
+    if (g_forced_R >= 1 && g_forced_R <= PP_RMAX) return g_forced_R;
+    return N > PP_WGS * g_num_cu ? 2 : 1;
 }
 
 // resident workgroups per CU the runtime predicts for the two kernels (measurement aid)
