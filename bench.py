@@ -159,8 +159,12 @@ def main():
         init_d = init.to(dev)
     ctx = model._context(gb)
 
+    # One timed pass = what TDiffusionModule.sampling() costs on a batch it has not seen: the per-complex preparation
+    # (kNN graph, frames, edge embedding, layer-0 static products: pp_complex_prepare, a fresh context) + 100 evaluations.
+    from packppi_amd.lib import Context
+
     def one_pass():
-        chi = ctx.sample(init_d, model.schedule)
+        chi = Context(model._plan, gb).sample(init_d, model.schedule)
         if args.proximal:
             from packppi_amd.functional import proximal_optimizer
             chis, losses = proximal_optimizer(gb, chi, 12.0, 0.5, 1.0, 50)
@@ -210,7 +214,7 @@ def main():
     insitu = {}
     for which, kname in ((1, "k_edge_update"), (0, "k_node_message"), (2, "k_node_update")):
         ctx.profile_kernel(which)
-        one_pass()
+        ctx.sample(init_d, model.schedule)
         insitu[kname] = ctx.profile_read()
     t_edge = insitu["k_edge_update"][0] * 1e-3
     t_node = insitu["k_node_message"][0] * 1e-3

@@ -243,7 +243,6 @@ extern "C" pp_status pp_plan_create(const float *weights, size_t n_weights, cons
 
     pp_plan *p = new (std::nothrow) pp_plan();
     if (!p) FAIL(PP_ERR_INVALID, "out of host memory");
-    memset(p, 0, sizeof(*p));
     p->device = device;
     p->off = off;
     p->has_network = has_net;
@@ -312,6 +311,10 @@ extern "C" void pp_plan_destroy(pp_plan *p) {
     void *ptrs[] = {p->w, p->wT, p->default_frames, p->atom14_to_group, p->atom14_mask, p->lit_positions,
                     p->between_radius, p->bounds_lower, p->bounds_upper};
     for (void *q : ptrs) if (q) (void)hipFree(q);
+    for (const ArenaSlot &sl : p->arena_pool) {
+        (void)hipFree(sl.p);
+        if (sl.steps_host) (void)hipHostFree(sl.steps_host);
+    }
     delete p;
 }
 
@@ -328,18 +331,21 @@ extern "C" pp_status pp_plan_set_clash_params(pp_plan *p, float tol, const float
 }
 
 // ---------------------------------------------------------------------------------------------
-template <typename T>
-static pp_status dalloc(T **p, size_t n) {
-    PP_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(p), (n ? n : 1) * sizeof(T)));
-    return PP_OK;
-}
-
 extern "C" void pp_ctx_destroy(pp_ctx *c) {
     if (!c) return;
-    void *ptrs[] = {c->rec, c->Znm, c->Zem, c->eidx, c->mask_att, c->frames, c->bbpos, c->hE0, c->hE, c->hV, c->S, c->msum, c->ptsN, c->PAn,
-                    c->PCn, c->ptsE, c->PAe, c->PCe, c->score, c->chi_tmp, c->steps, c->xyz, c->axes, c->brad,
-                    c->per_res, c->dchi, c->px, c->pm, c->pv, c->pz, c->pxeff, c->pmask, c->scal};
-    for (void *q : ptrs) if (q) (void)hipFree(q);
+    if (c->arena) {                                   // every workspace pointer lives in this one allocation
+        // hand it to the plan's pool instead of hipFree (which synchronises the device): a context per batch is created
+        // and destroyed on the sampling path.  Work already enqueued on last_stream may still be using the memory; the
+        // next owner either runs on the same stream (ordered after it) or waits for that stream first.
+        pp_plan *p = c->plan;
+        std::lock_guard<std::mutex> g(p->pool_mutex);
+        if (p->arena_pool.size() < 4) {
+            p->arena_pool.push_back({c->arena, c->arena_bytes, c->steps_host, c->last_stream});
+            c->steps_host = nullptr;
+        } else {
+            (void)hipFree(c->arena);
+        }
+    }
     if (c->steps_host) (void)hipHostFree(c->steps_host);
     for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
     delete c;
@@ -364,7 +370,13 @@ extern "C" pp_status pp_complex_prepare(pp_plan *plan, const pp_batch *b, void *
     c->K = b->L < PP_TOP_K ? b->L : PP_TOP_K;
     const size_t N = c->N, K = c->K;
     pp_status st = PP_OK;
-#define ALLOC(field, n) if (st == PP_OK) st = dalloc(&c->field, (n))
+    // one arena for all workspaces (a context per batch is created and destroyed on the sampling path: ~35 hipMalloc /
+    // hipFree pairs cost 1.5 ms per context, one pair 0.1 ms): sizes first, then one hipMalloc, then the pointers
+    struct Slot { void **p; size_t bytes; };
+    std::vector<Slot> slots;
+    size_t total = 0;
+#define ALLOC(field, n) { const size_t bytes_ = (((n) ? (n) : 1) * sizeof(*c->field) + 255) & ~size_t(255);          \
+                          slots.push_back({reinterpret_cast<void **>(&c->field), bytes_}); total += bytes_; }
     if (net) {
     ALLOC(eidx, N * K); ALLOC(mask_att, N * 32); ALLOC(frames, N * 12); ALLOC(bbpos, N * 15);
     ALLOC(hE0, N * K * 128); ALLOC(hE, N * K * 128); ALLOC(Znm, N * K * 128); ALLOC(Zem, N * K * 128); ALLOC(hV, N * 128); ALLOC(S, N * 128); ALLOC(msum, N);
@@ -378,7 +390,31 @@ extern "C" pp_status pp_complex_prepare(pp_plan *plan, const pp_batch *b, void *
     c->max_steps = 1024;
     if (net) { ALLOC(steps, (size_t)c->max_steps); }
 #undef ALLOC
-    if (net && st == PP_OK && hipHostMalloc(reinterpret_cast<void **>(&c->steps_host), c->max_steps * sizeof(StepParams)) != hipSuccess) {
+    c->last_stream = static_cast<hipStream_t>(stream);
+    {
+        std::lock_guard<std::mutex> g(plan->pool_mutex);
+        int best = -1;
+        for (int i = 0; i < (int)plan->arena_pool.size(); i++)
+            if (plan->arena_pool[i].bytes >= total && (best < 0 || plan->arena_pool[i].bytes < plan->arena_pool[best].bytes)) best = i;
+        if (best >= 0) {
+            const ArenaSlot sl = plan->arena_pool[best];
+            plan->arena_pool.erase(plan->arena_pool.begin() + best);
+            if (sl.stream != c->last_stream) (void)hipStreamSynchronize(sl.stream);
+            c->arena = sl.p;
+            c->arena_bytes = sl.bytes;
+            c->steps_host = sl.steps_host;
+        }
+    }
+    if (!c->arena && hipMalloc(&c->arena, total) != hipSuccess) {
+        pp_set_error("hipMalloc of the context workspace failed");
+        c->arena = nullptr;
+        st = PP_ERR_HIP;
+    } else {
+        if (!c->arena_bytes) c->arena_bytes = total;
+        char *base = static_cast<char *>(c->arena);
+        for (const Slot &sl : slots) { *sl.p = base; base += sl.bytes; }
+    }
+    if (net && st == PP_OK && !c->steps_host && hipHostMalloc(reinterpret_cast<void **>(&c->steps_host), c->max_steps * sizeof(StepParams)) != hipSuccess) {
         pp_set_error("hipHostMalloc failed");
         st = PP_ERR_HIP;
     }
@@ -478,6 +514,7 @@ static pp_status run_network(pp_ctx *c, hipStream_t s, int step, int last_mode, 
 }
 
 extern "C" pp_status pp_score(pp_ctx *c, const float *chi, float t, float *score, float *hV, void *stream) {
+    if (c) c->last_stream = static_cast<hipStream_t>(stream);
     if (!c || !chi || !score) FAIL(PP_ERR_INVALID, "pp_score: null argument");
     if (!c->plan->has_network) FAIL(PP_ERR_INVALID, "pp_score: plan was created without network weights");
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -496,6 +533,7 @@ extern "C" pp_status pp_score(pp_ctx *c, const float *chi, float t, float *score
 
 extern "C" pp_status pp_sample(pp_ctx *c, float *chi, const float *schedule, int n_schedule, int mode,
                                const float *sde_noise, void *stream) {
+    if (c) c->last_stream = static_cast<hipStream_t>(stream);
     if (!c || !chi || !schedule) FAIL(PP_ERR_INVALID, "pp_sample: null argument");
     if (!c->plan->has_network) FAIL(PP_ERR_INVALID, "pp_sample: plan was created without network weights");
     if (n_schedule < 2) FAIL(PP_ERR_INVALID, "pp_sample: schedule needs at least 2 times");
@@ -525,12 +563,14 @@ extern "C" pp_status pp_sample(pp_ctx *c, float *chi, const float *schedule, int
 }
 
 extern "C" pp_status pp_atom14(pp_ctx *c, const float *chi, float *xyz, void *stream) {
+    if (c) c->last_stream = static_cast<hipStream_t>(stream);
     if (!c || !chi || !xyz) FAIL(PP_ERR_INVALID, "pp_atom14: null argument");
     PP_HIP_CHECK(hipSetDevice(c->plan->device));
     return pp_launch_atom14(c, chi, xyz, static_cast<hipStream_t>(stream));
 }
 
 extern "C" pp_status pp_clash(pp_ctx *c, const float *chi, float *per_res, float *dchi, void *stream) {
+    if (c) c->last_stream = static_cast<hipStream_t>(stream);
     if (!c || !chi || !per_res) FAIL(PP_ERR_INVALID, "pp_clash: null argument");
     if (!c->plan->clash_params_set) FAIL(PP_ERR_INVALID, "pp_clash: call pp_plan_set_clash_params first");
     if (!c->b.atom_mask || !c->b.residue_index) FAIL(PP_ERR_INVALID, "pp_clash: batch lacks atom_mask / residue_index");
@@ -543,6 +583,7 @@ extern "C" pp_status pp_clash(pp_ctx *c, const float *chi, float *per_res, float
 
 extern "C" pp_status pp_proximal(pp_ctx *c, const float *chi, float lamda, int num_steps, float *chi_traj,
                                  float *chi_last, float *losses, void *stream) {
+    if (c) c->last_stream = static_cast<hipStream_t>(stream);
     if (!c || !chi || !losses) FAIL(PP_ERR_INVALID, "pp_proximal: null argument");
     if (c->B != 1) FAIL(PP_ERR_INVALID, "pp_proximal: batch.num_proteins must be 1 (optimize.py:27)");
     if (num_steps < 1) FAIL(PP_ERR_INVALID, "pp_proximal: num_steps must be >= 1");

@@ -142,6 +142,11 @@ enum { P_BMID = 0, P_BOUT = 128, P_FOB = 256, P_G2 = 384, P_BE2 = 512, P_FIB = 6
 #define PP_WGS 3           // register budget = 512 / PP_WGS per lane: three workgroups per CU (the kernels need ~140 VGPRs, 38.4 KB of LDS)
 #endif
 #define NRING (PP_WDEPTH + 1)
+#ifdef PP_X_NOWLOAD      /* timing experiment (results are wrong): no weight fetches after the prologue */
+#define PP_X_NOWLOAD_ true
+#else
+#define PP_X_NOWLOAD_ false
+#endif
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
 
@@ -356,7 +361,8 @@ __device__ __forceinline__ void edge_geometry(const float *__restrict__ pts_i, c
 #define WSTAGE(k, NCH, ACC, BODY)                                                                              \
     {                                                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
-        if constexpr ((k) + PP_WDEPTH < (NCH)) gload_A(wq, (k) + PP_WDEPTH, AR[((k) + PP_WDEPTH) % NRING]);    \
+        if constexpr ((k) + PP_WDEPTH < (NCH) && !PP_X_NOWLOAD_)                                               \
+            gload_A(wq, (k) + PP_WDEPTH, AR[((k) + PP_WDEPTH) % NRING]);                                       \
         const AOp &AK = AR[(k) % NRING];                                                                       \
         BODY;                                                                                                  \
         _Pragma("unroll") for (int r_ = 0; r_ < R; r_++) asm volatile("" ::"v"(ACC[r_][0]));                   \

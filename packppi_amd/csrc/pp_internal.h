@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <vector>
+#include <mutex>
 #include <stdint.h>
 #include <string>
 
@@ -42,8 +43,17 @@ struct LayerT {
     const float *em_params;                          // edge kernel small vectors, one block
 };
 
+struct StepParams;
+struct ArenaSlot {
+    void *p;
+    size_t bytes;
+    StepParams *steps_host;  // the pinned staging buffer travels with the arena (hipHostMalloc / hipHostFree are slow)
+    hipStream_t stream;      // work on this stream may still be using the memory
+};
 struct pp_plan {
     int device;
+    std::vector<ArenaSlot> arena_pool;   // workspaces of destroyed contexts, reused by the next pp_complex_prepare
+    std::mutex pool_mutex;
     bool has_network;         // false: geometry-only plan (atom14 / clash / proximal)
     float *w;                 // device copy of all weights, original layouts
     WeightOff off;
@@ -96,6 +106,9 @@ struct pp_ctx {
     float *chi_tmp;           // [N][4]
     StepParams *steps;        // device [max_steps]
     StepParams *steps_host;   // pinned host staging
+    void *arena = nullptr;          // ONE device allocation behind every workspace pointer above (one hipMalloc / hipFree per ctx)
+    size_t arena_bytes = 0;
+    hipStream_t last_stream = nullptr;   // the stream of the most recent call on this context (arena hand-over)
     int max_steps;
     // clash / proximal workspaces
     float *xyz;               // [N][14][3]
