@@ -205,22 +205,28 @@ __device__ __forceinline__ void mfma_h(const AOp &a, const HT (&x)[R], f32x16 (&
         }
     }
 }
-// the 72 invariant-point features as operands: global k-step S = 0..4 carries features 16 S + 8 h + i (zero beyond 71);
-// geometry chunk C holds k-steps 2C and 2C+1 (the last one is all padding and skipped)
-struct HG {
-    h8 hi[5], lo[5];
-};
+// the 72 invariant-point features as operands: lane half h carries the features of points 4h .. 4h+3 in 40 slots
+// (geometry_share below), k-step S5 = 0..4 holds slots 8 S5 .. 8 S5 + 7; geometry chunk C holds k-steps 2C and 2C+1 (the
+// last one is all padding and skipped).  The operands live in a 10 KB LDS block per residue, [k-step][hi | lo][lane] h8.
+#define GBUF_FLOATS (5 * 2 * 64 * 4)
 template <int R, int C>
-__device__ __forceinline__ void mfma_geo(const AOp &a, const HG (&g)[R], f32x16 (&acc)[R]) {
+__device__ __forceinline__ void mfma_geo(const AOp &a, const float *gbuf, int lane, f32x16 (&acc)[R]) {
 #pragma unroll
     for (int s = 0; s < 2; s++) {
         if (2 * C + s < 5) {
+            h8 ghi[R], glo[R];
 #pragma unroll
-            for (int r = 0; r < R; r++) acc[r] = MFMA16(a.r[2 * s], g[r].hi[2 * C + s], acc[r]);
+            for (int r = 0; r < R; r++) {
+                const h8 *gp = reinterpret_cast<const h8 *>(gbuf + r * GBUF_FLOATS) + (2 * (2 * C + s)) * 64 + lane;
+                ghi[r] = gp[0];
+                glo[r] = gp[64];
+            }
 #pragma unroll
-            for (int r = 0; r < R; r++) acc[r] = MFMA16(a.r[2 * s], g[r].lo[2 * C + s], acc[r]);
+            for (int r = 0; r < R; r++) acc[r] = MFMA16(a.r[2 * s], ghi[r], acc[r]);
 #pragma unroll
-            for (int r = 0; r < R; r++) acc[r] = MFMA16(a.r[2 * s + 1], g[r].hi[2 * C + s], acc[r]);
+            for (int r = 0; r < R; r++) acc[r] = MFMA16(a.r[2 * s], glo[r], acc[r]);
+#pragma unroll
+            for (int r = 0; r < R; r++) acc[r] = MFMA16(a.r[2 * s + 1], ghi[r], acc[r]);
         }
     }
 }
@@ -312,47 +318,53 @@ __device__ __forceinline__ void ln_affine_tile(f32x16 &v, float rstd, const floa
     }
 }
 
-// 72 invariant point features of edge (i, j), split and laid out as MFMA operands (HG).  Lane half h carries the
-// features of points 4h .. 4h+3 (pp_api.hip put_geo_chunk permutes W_G's columns to match): 40 slots =
+// 72 invariant point features of edge (i, j) as split-f16 MFMA operands in LDS.  Lane half h carries the features of
+// points 4h .. 4h+3 (pp_api.hip put_geo_chunk permutes W_G's columns to match): 40 slots =
 // p_loc xyz x4 | |p_loc| x4 | R_i^T (p_glob_j - t_i) xyz x4 | its norm x4 | |p_glob_i - p_glob_j| x4 | 0 x4.
-__device__ __forceinline__ void edge_geometry(const float *__restrict__ pts_i, const float *__restrict__ fr,
-                                              const float *__restrict__ pts_j, int h, HG &g) {
-    float sl[40];
-    float R[9], tr[3];
+// All four waves need all of it as B operand, so they SHARE the work: wave w computes point 4h + w of its lanes (nine
+// values), splits them and scatters the f16 pairs into the operand block; a workgroup barrier follows at the call site.
+__device__ __forceinline__ void geometry_share(const float *__restrict__ pts_i, const float *__restrict__ fr,
+                                               const float *__restrict__ pts_j, int h, int wave, int lane, float *gbuf) {
+    const int q = wave;
+    const float *pl = pts_i + 12 * h + 3 * q, *pg = pts_i + 24 + 12 * h + 3 * q, *pj = pts_j + 24 + 12 * h + 3 * q;
+    const float lx = pl[0], ly = pl[1], lz = pl[2];
+    const float gx = pg[0], gy = pg[1], gz = pg[2];
+    const float jx = pj[0], jy = pj[1], jz = pj[2];
+    float v[10];
+    v[0] = lx; v[1] = ly; v[2] = lz;
+    v[3] = sqrtf(lx * lx + ly * ly + lz * lz + 1e-8f);
+    const float dx = jx - fr[9], dy = jy - fr[10], dz = jz - fr[11];
+    const float nx = fr[0] * dx + fr[3] * dy + fr[6] * dz;
+    const float ny = fr[1] * dx + fr[4] * dy + fr[7] * dz;
+    const float nz = fr[2] * dx + fr[5] * dy + fr[8] * dz;
+    v[4] = nx; v[5] = ny; v[6] = nz;
+    v[7] = sqrtf(nx * nx + ny * ny + nz * nz + 1e-8f);
+    const float ex = gx - jx, ey = gy - jy, ez = gz - jz;
+    v[8] = sqrtf(ex * ex + ey * ey + ez * ez + 1e-8f);
+    v[9] = 0.f;
+    const int slot[9] = {3 * q, 3 * q + 1, 3 * q + 2, 12 + q, 16 + 3 * q, 16 + 3 * q + 1, 16 + 3 * q + 2, 28 + q, 32 + q};
+    _Float16 *gh = reinterpret_cast<_Float16 *>(gbuf);
 #pragma unroll
-    for (int k = 0; k < 9; k++) R[k] = fr[k];
+    for (int i = 0; i < 10; i += 2) {
+        const f32x2v x = {v[i], v[i + 1]};
+        const h2v hh = cvt2(x);
+        const f32x2v d = {fmaf((float)hh[0], -1.0f, x[0]), fmaf((float)hh[1], -1.0f, x[1])};
+        const h2v ll = cvt2(d);
 #pragma unroll
-    for (int k = 0; k < 3; k++) tr[k] = fr[9 + k];
-    const float *pl = pts_i + 12 * h, *pg = pts_i + 24 + 12 * h, *pj = pts_j + 24 + 12 * h;
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        float lx = pl[3 * q], ly = pl[3 * q + 1], lz = pl[3 * q + 2];
-        float gx = pg[3 * q], gy = pg[3 * q + 1], gz = pg[3 * q + 2];
-        float jx = pj[3 * q], jy = pj[3 * q + 1], jz = pj[3 * q + 2];
-        sl[3 * q] = lx; sl[3 * q + 1] = ly; sl[3 * q + 2] = lz;
-        sl[12 + q] = sqrtf(lx * lx + ly * ly + lz * lz + 1e-8f);
-        float dx = jx - tr[0], dy = jy - tr[1], dz = jz - tr[2];
-        float nx = R[0] * dx + R[3] * dy + R[6] * dz;
-        float ny = R[1] * dx + R[4] * dy + R[7] * dz;
-        float nz = R[2] * dx + R[5] * dy + R[8] * dz;
-        sl[16 + 3 * q] = nx; sl[16 + 3 * q + 1] = ny; sl[16 + 3 * q + 2] = nz;
-        sl[28 + q] = sqrtf(nx * nx + ny * ny + nz * nz + 1e-8f);
-        float ex = gx - jx, ey = gy - jy, ez = gz - jz;
-        sl[32 + q] = sqrtf(ex * ex + ey * ey + ez * ez + 1e-8f);
-    }
-#pragma unroll
-    for (int k = 36; k < 40; k++) sl[k] = 0.f;
-#pragma unroll
-    for (int S5 = 0; S5 < 5; S5++)
-#pragma unroll
-        for (int i = 0; i < 8; i += 2) {
-            const f32x2v x = {sl[8 * S5 + i], sl[8 * S5 + i + 1]};
-            const h2v hh = cvt2(x);
-            const f32x2v d = {fmaf((float)hh[0], -1.0f, x[0]), fmaf((float)hh[1], -1.0f, x[1])};
-            const h2v ll = cvt2(d);
-            g.hi[S5][i] = hh[0]; g.hi[S5][i + 1] = hh[1];
-            g.lo[S5][i] = ll[0]; g.lo[S5][i + 1] = ll[1];
+        for (int e = 0; e < 2; e++) {
+            if (i + e < 9) {
+                const int sidx = slot[i + e];
+                const int at = ((2 * (sidx >> 3)) * 64 + lane) * 8 + (sidx & 7);       // hi block of k-step sidx / 8
+                gh[at] = hh[e];
+                gh[at + 64 * 8] = ll[e];                                              // lo block
+            }
         }
+    }
+    if (wave == 0) {          // padding slots 36..39 (k-step 4, elements 4..7), hi and lo
+        const f32x2v z = {0.f, 0.f};
+        *reinterpret_cast<f32x2v *>(gh + ((2 * 4) * 64 + lane) * 8 + 4) = z;
+        *reinterpret_cast<f32x2v *>(gh + ((2 * 4 + 1) * 64 + lane) * 8 + 4) = z;
+    }
 }
 
 // ACC names the accumulator array the stage's MFMAs chain on: the empty asm at the end uses one element of every chain,
@@ -415,9 +427,9 @@ __device__ __forceinline__ void edge_geometry(const float *__restrict__ pts_i, c
     if constexpr (!ST0) {                                                         \
         XLAYER(0, NCH, acc, xbuf, false)                                          \
     }                                                                             \
-    WSTAGE(C0 + 0, NCH, acc, (mfma_geo<R, 0>(AK, g, acc)))                        \
-    WSTAGE(C0 + 1, NCH, acc, (mfma_geo<R, 1>(AK, g, acc)))                        \
-    WSTAGE(C0 + 2, NCH, acc, (mfma_geo<R, 2>(AK, g, acc)))                        \
+    WSTAGE(C0 + 0, NCH, acc, (mfma_geo<R, 0>(AK, gbuf, lane, acc)))                        \
+    WSTAGE(C0 + 1, NCH, acc, (mfma_geo<R, 1>(AK, gbuf, lane, acc)))                        \
+    WSTAGE(C0 + 2, NCH, acc, (mfma_geo<R, 2>(AK, gbuf, lane, acc)))                        \
     PUBLISH_RELU()
 
 #define PROLOGUE_PIPE(NCH)                                                                                     \
@@ -508,13 +520,14 @@ k_node_message(EdgeArgs A) {
 
     HT bt[2][R];
     f32x16 acc[R];
-    HG g[R];
+    float *gbuf = smem + NXB * R * XBUF_FLOATS;
     const int jj = j < K ? j : K - 1;
     const float bmid = A.b_mid[32 * wave + j];            // SWAP form: feature on the lane
 #pragma unroll
     for (int r = 0; r < R; r++) {
         const int nbr = A.eidx[(size_t)n[r] * K + jj];
-        edge_geometry(A.pts + (size_t)n[r] * 48, A.frames + (size_t)n[r] * 12, A.pts + (size_t)nbr * 48, h, g[r]);
+        geometry_share(A.pts + (size_t)n[r] * 48, A.frames + (size_t)n[r] * 12, A.pts + (size_t)nbr * 48, h, wave, lane,
+                       gbuf + r * GBUF_FLOATS);
         const float *hrow = A.hE_in + ((size_t)n[r] * K + jj) * 128;
         if constexpr (!ST0) {             // this wave's tile of h_E -> split -> exchange buffer
             HT ht;
@@ -526,7 +539,7 @@ k_node_message(EdgeArgs A) {
         add_tile(A.PC + (size_t)nbr * 128 + 32 * wave, h, acc[r]);
         if constexpr (ST0) add_tile(A.Z + ((size_t)n[r] * K + jj) * 128 + 32 * wave, h, acc[r]);
     }
-    if constexpr (!ST0) { __syncthreads(); }
+    __syncthreads();                      // geometry operands (and the h_E tiles) are in LDS
     FIRST_LAYER(NCH)
 #pragma unroll
     for (int r = 0; r < R; r++)
@@ -622,7 +635,7 @@ k_edge_update(EdgeArgs A) {
 
     HT bt[2][R];
     f32x16 acc[R], out[R];
-    HG g[R];
+    float *gbuf = x1buf;      // the geometry operands borrow the x1 buffer: dead until LayerNorm 2 and again after the FFN
     int nbr[R];
     float me[R];
     // the small per-layer vectors go to LDS once (published by the first exchange barrier)
@@ -635,7 +648,8 @@ k_edge_update(EdgeArgs A) {
     for (int r = 0; r < R; r++) {
         nbr[r] = A.eidx[(size_t)n[r] * K + jj];
         me[r] = A.mask_att[(size_t)n[r] * 32 + jj];            // (lanes j >= K mirror edge K - 1 throughout)
-        edge_geometry(A.pts + (size_t)n[r] * 48, A.frames + (size_t)n[r] * 12, A.pts + (size_t)nbr[r] * 48, h, g[r]);
+        geometry_share(A.pts + (size_t)n[r] * 48, A.frames + (size_t)n[r] * 12, A.pts + (size_t)nbr[r] * 48, h, wave, lane,
+                       gbuf + r * GBUF_FLOATS);
         // this wave's tile of h_E: the residual input of the first LayerNorm (kept in `out`) and, split, a quarter of
         // the first layer's B operands (published; layer 0 needs no B operands: W_B h_E0 arrives in Z)
         load_tile(A.hE_in + ((size_t)n[r] * K + jj) * 128 + 32 * wave, h, out[r]);
@@ -648,7 +662,7 @@ k_edge_update(EdgeArgs A) {
         add_tile(A.PC + (size_t)nbr[r] * 128 + 32 * wave, h, acc[r]);
         if constexpr (ST0) add_tile(A.Z + ((size_t)n[r] * K + jj) * 128 + 32 * wave, h, acc[r]);
     }
-    if constexpr (!ST0) { __syncthreads(); }
+    __syncthreads();                      // geometry operands (and the h_E tiles) are in LDS
     TS(0)
     FIRST_LAYER(NCH)
     TS(1)
@@ -728,7 +742,8 @@ k_edge_update(EdgeArgs A) {
             HT ht;
             split_tile<false>(out[r], ht);
             xbuf_put_h(xbuf + r * XBUF_FLOATS, wave, lane, ht);
-            edge_geometry(A.pts2 + (size_t)n[r] * 48, A.frames + (size_t)n[r] * 12, A.pts2 + (size_t)nbr[r] * 48, h, g[r]);
+            geometry_share(A.pts2 + (size_t)n[r] * 48, A.frames + (size_t)n[r] * 12, A.pts2 + (size_t)nbr[r] * 48, h, wave,
+                           lane, gbuf + r * GBUF_FLOATS);
             load_tile(A.PA2 + (size_t)n[r] * 128 + 32 * wave, h, acc[r]);
             add_tile(A.PC2 + (size_t)nbr[r] * 128 + 32 * wave, h, acc[r]);
         }
@@ -736,9 +751,9 @@ k_edge_update(EdgeArgs A) {
         __syncthreads();
         TS(13)
         XLAYER(NEU + 0, NCH, acc, xbuf, false)
-        WSTAGE(NEU + 4, NCH, acc, (mfma_geo<R, 0>(AK, g, acc)))
-        WSTAGE(NEU + 5, NCH, acc, (mfma_geo<R, 1>(AK, g, acc)))
-        WSTAGE(NEU + 6, NCH, acc, (mfma_geo<R, 2>(AK, g, acc)))
+        WSTAGE(NEU + 4, NCH, acc, (mfma_geo<R, 0>(AK, gbuf, lane, acc)))
+        WSTAGE(NEU + 5, NCH, acc, (mfma_geo<R, 1>(AK, gbuf, lane, acc)))
+        WSTAGE(NEU + 6, NCH, acc, (mfma_geo<R, 2>(AK, gbuf, lane, acc)))
         TS(14)
         PUBLISH_RELU()
 #pragma unroll
@@ -857,7 +872,7 @@ static EdgeArgs edge_args(pp_ctx *c, int layer, bool edge) {
 static size_t g_lds_pad = PP_LDS_PAD;     // pp_debug_set_lds_pad(): occupancy experiments
 extern "C" void pp_debug_set_lds_pad(int bytes) { g_lds_pad = (size_t)bytes; }
 static size_t pad_smem(size_t b) { return b > g_lds_pad ? b : g_lds_pad; }
-static size_t nm_smem(int R) { return pad_smem((R == 1 ? 2 : 1) * R * XBUF_FLOATS * sizeof(float)); }
+static size_t nm_smem(int R) { return pad_smem(((R == 1 ? 2 : 1) * R * XBUF_FLOATS + R * GBUF_FLOATS) * sizeof(float)); }
 static size_t eu_smem(int R) {
     return pad_smem((((R == 1 ? 2 : 1) + 1) * R * XBUF_FLOATS + R * STAT_FLOATS + PARAM_LDS) * sizeof(float));
 }
