@@ -62,7 +62,7 @@ struct Smem {
     VN a[512];                 // wide activation vector (FFN hidden, decoder scratch)
     VN h[128];                 // current node vector
     VN p[48];                  // local points / small inputs
-    VN red[2][8];              // LayerNorm partials, ping-pong
+    VN red[2][16];             // LayerNorm partials (8 wave means, 8 wave sums of squares), ping-pong
 };
 
 __device__ __forceinline__ f4v f4(float v) { return f4v{v, v, v, v}; }
@@ -143,21 +143,23 @@ __device__ __forceinline__ VN wave_sum(VN v) {
 }
 
 // LayerNorm over 128 features (one per thread of a ks-group = 2 waves), NB residues at once, eps 1e-5, two-pass
+// LayerNorm over the 128 features held by a pair of waves (grp, grp + 1): each wave reduces its own 64 features to
+// (mean, centred sum of squares), the pair meets ONCE in LDS and merges with Chan's update for equal counts --
+// one barrier per LayerNorm instead of two (mean, then variance), and as stable as the two-pass form.
 __device__ __forceinline__ VN layernorm(Smem &sm, int &rflip, const VN &v, float g, float b) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, grp = wid & ~1;
-    VN s = wave_sum(v);
+    const VN mw = vscale(wave_sum(v), 1.f / 64.f);
+    const VN dw = vsub(v, mw);
+    const VN qw = wave_sum(vmul(dw, dw));
     VN *r = sm.red[rflip];
     rflip ^= 1;
-    if (lane == 0) r[wid] = s;
+    if (lane == 0) { r[wid] = mw; r[8 + wid] = qw; }
     __syncthreads();
-    const VN mean = vscale(vadd(r[grp], r[grp + 1]), 1.f / 128.f);
+    const VN ma = r[grp], mb = r[grp + 1];
+    const VN mean = vscale(vadd(ma, mb), 0.5f);
+    const VN dm = vsub(ma, mb);
+    const VN var = vscale(vadd(vadd(r[8 + grp], r[8 + grp + 1]), vscale(vmul(dm, dm), 32.f)), 1.f / 128.f);
     const VN d = vsub(v, mean);
-    VN q = wave_sum(vmul(d, d));
-    r = sm.red[rflip];
-    rflip ^= 1;
-    if (lane == 0) r[wid] = q;
-    __syncthreads();
-    const VN var = vscale(vadd(r[grp], r[grp + 1]), 1.f / 128.f);
     VN o;
     VN_FOR o.g[gi] = f4v{d.g[gi].x * (1.f / sqrtf(var.g[gi].x + 1e-5f)) * g + b,
                                  d.g[gi].y * (1.f / sqrtf(var.g[gi].y + 1e-5f)) * g + b,
