@@ -269,3 +269,30 @@ def test_residues_per_workgroup_agree(weights):
             assert torch.isfinite(out[1]).all()
     finally:
         l.pp_debug_set_edge_R(0)          # back to the automatic choice
+
+
+def test_context_workspace_reuse(weights):
+    """Contexts hand their device workspace back to the plan's pool (no hipMalloc / hipFree on the sampling path): a
+    smaller, an equal and a larger complex after a destroyed context must give what a fresh module gives."""
+    from packppi_amd import synth
+    from packppi_amd.featurize import protein_to_batch
+    from packppi_amd.lib import Context
+    from packppi_amd.module import TDiffusionModule
+    m = TDiffusionModule(weights, device=DEV)
+    sched = torch.linspace(1, 0, 6)
+
+    def run(model, L, fresh_ctx):
+        b = protein_to_batch(synth.make_complex(L, 40 + L)).to(DEV)
+        g = torch.Generator().manual_seed(L)
+        init = ((torch.rand(1, L, 4, generator=g) * 2 - 1) * 3.0 * b.SC_D_mask.cpu()).to(DEV)
+        ctx = Context(model._plan, b) if fresh_ctx else model._context(b)
+        out = ctx.sample(init, sched).cpu()
+        del ctx
+        return out
+
+    m._context(protein_to_batch(synth.make_complex(8, 1)).to(DEV))      # creates the plan
+    seq = [200, 64, 200, 333, 64]
+    got = [run(m, L, True) for L in seq]                                 # each context is destroyed before the next
+    ref = {L: run(TDiffusionModule(weights, device=DEV), L, False) for L in set(seq)}
+    for L, o in zip(seq, got):
+        assert torch.equal(o, ref[L]), (L, float((o - ref[L]).abs().max()))
