@@ -272,6 +272,17 @@ extern "C" pp_status pp_plan_create(const float *weights, size_t n_weights, cons
         o_l[l][11] = put_edge_params(arena, weights, L);
     }
     size_t o_static = put_static_stream(arena, weights, off.layer[0]);
+#ifdef PP_EDGE_F16
+    // edge embedding, RBF block (input columns 65..464 of encoder.edge_embedding.weight): 13 chunks of two 16-deep k-steps,
+    // k-step S = atom pair S, lane half h = RBFs 8h .. 8h+7 of that pair
+    size_t o_embed = (arena.size() + 3) & ~size_t(3);
+    arena.resize(o_embed);
+    for (int cch = 0; cch < 13; cch++)
+        put_chunk_f16(arena, weights + off.edge_emb_w, 468, 0, [cch](int s2, int h, int i) {
+            const int k = 32 * cch + 16 * s2 + 8 * h + i;
+            return k < 400 ? 65 + k : -1;
+        });
+#endif
     size_t o_d0i = put_T4(arena, weights + off.d0_in_w, 64, 128, 0, 128);
     size_t o_d0o = put_T4(arena, weights + off.d0_out_w, 32, 64, 0, 64);
     size_t o_d2i = put_T4(arena, weights + off.d2_in_w, 16, 32, 0, 32);
@@ -290,6 +301,9 @@ extern "C" pp_status pp_plan_create(const float *weights, size_t n_weights, cons
         t.em_params = p->wT + o_l[l][11];
     }
     p->static_stream = p->wT + o_static;
+#ifdef PP_EDGE_F16
+    p->embed_stream = p->wT + o_embed;
+#endif
     p->d0_in_T = p->wT + o_d0i; p->d0_out_T = p->wT + o_d0o;
     p->d2_in_T = p->wT + o_d2i; p->d2_out_T = p->wT + o_d2o;
     }

@@ -831,6 +831,186 @@ k_edge_static(EdgeArgs A) {
     store_tile(A.Zem + ((size_t)n * K + jj) * 128 + 32 * wave, h, acc[0]);
 }
 
+// ---------------------------------------------------------------------------------------------
+// once per complex: edge features + embedding, h_E0 = LayerNorm(Linear(468 -> 128)(e_ij))  (encoder.py:105-246) -- the MFMA
+// form of pp_prepare.hip's k_edge_embed (which the exact-fp32 build keeps): 0.25 ms -> see DESIGN.md.  One workgroup per
+// residue.  The 400 RBF inputs (25 backbone atom pairs x 16 Gaussians) are written to LDS directly as split-f16 B operands
+// -- k-step S = atom pair S, lane half h = Gaussians 8h .. 8h+7 -- and contracted on the matrix pipe against the packed RBF
+// block of the weight (plan->embed_stream); the other 68 inputs (one-hot relative position = a column select, chain flag,
+// two pair dihedrals) and the bias initialise the accumulator; LayerNorm as in the edge update.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float dist_eps_nc(const float *a, const float *b, float eps) {
+#pragma clang fp contract(off)      // rounds like the reference's separate mul / add / sqrt (as in pp_prepare.hip)
+    float dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2];
+    float s = dx * dx;
+    s = s + dy * dy;
+    s = s + dz * dz;
+    return sqrtf(s + eps);
+}
+__device__ __forceinline__ void cross3_nc(const float *a, const float *b, float *o) {
+#pragma clang fp contract(off)
+    o[0] = a[1] * b[2] - a[2] * b[1];
+    o[1] = a[2] * b[0] - a[0] * b[2];
+    o[2] = a[0] * b[1] - a[1] * b[0];
+}
+__device__ __forceinline__ void unit_nan0_nc(float *v) {
+#pragma clang fp contract(off)
+    float n = sqrtf((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]);
+    for (int k = 0; k < 3; k++) {
+        float q = v[k] / n;
+        v[k] = (q != q) ? 0.f : q;
+    }
+}
+// sign * arccos(n1 . n2) with NaN -> 0 (encoder.py:164-174)
+__device__ float pair_dihedral_nc(const float *p0, const float *p1, const float *p2, const float *p3) {
+#pragma clang fp contract(off)
+    float u0[3], u1[3], u2[3], n1[3], n2[3], c12[3];
+    for (int k = 0; k < 3; k++) { u0[k] = p2[k] - p1[k]; u1[k] = p0[k] - p1[k]; u2[k] = p3[k] - p2[k]; }
+    cross3_nc(u0, u1, n1); unit_nan0_nc(n1);
+    cross3_nc(u0, u2, n2); unit_nan0_nc(n2);
+    cross3_nc(u1, u2, c12);
+    float sg = (c12[0] * u0[0] + c12[1] * u0[1]) + c12[2] * u0[2];
+    float sgn = (sg > 0.f) ? 1.f : ((sg < 0.f) ? -1.f : 0.f);
+    float dt = (n1[0] * n2[0] + n1[1] * n2[1]) + n1[2] * n2[2];
+    float ang = sgn * acosf(dt);
+    return (ang != ang) ? 0.f : ang;
+}
+
+// chunk C of the RBF block: k-steps (atom pairs) 2C and 2C+1 (the 26th is padding and skipped)
+template <int C>
+__device__ __forceinline__ void emb_step(const AOp &a, const float *gb, int lane, f32x16 &acc) {
+#pragma unroll
+    for (int s2 = 0; s2 < 2; s2++) {
+        if (2 * C + s2 < 25) {
+            const h8 *gp = reinterpret_cast<const h8 *>(gb) + (2 * (2 * C + s2)) * 64 + lane;
+            const h8 bh = gp[0];
+            const h8 bl = gp[64];
+            acc = MFMA16(a.r[2 * s2], bh, acc);
+            acc = MFMA16(a.r[2 * s2], bl, acc);
+            acc = MFMA16(a.r[2 * s2 + 1], bh, acc);
+        }
+    }
+}
+
+struct EmbedArgs {
+    int N, K;
+    const float *bbpos;            // [N][15]  N, CA, C, O, virtual CB
+    const int32_t *eidx;           // [N][K]
+    const int64_t *res_index, *chain;
+    const float *WT;               // [468][128] transposed weight (one-hot / flag / dihedral columns)
+    const float *bias, *ln_g, *ln_b;
+    const float *wstream;          // packed RBF block, 13 chunks
+    float *hE0;                    // [N][K][128]
+};
+#define EMB_GB_FLOATS (25 * 2 * 64 * 4)      // 50 KB: [pair][hi | lo][lane] h8
+__global__ void __launch_bounds__(ET, 2)
+k_edge_embed_f16(EmbedArgs A) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *gb = smem, *stat = smem + EMB_GB_FLOATS;
+    __shared__ float s_pos[33][15];                             // slot 32 = centre residue
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    const int n = blockIdx.x, K = A.K;
+    const int jj = j < K ? j : K - 1;
+    constexpr int R = 1;
+    constexpr int NCH = 13;
+    PROLOGUE_PIPE(NCH)
+    for (int t = tid; t < 15; t += ET) s_pos[32][t] = A.bbpos[(size_t)n * 15 + t];
+    for (int t = tid; t < 32 * 15; t += ET) {
+        int e = t / 15, c = t - e * 15;
+        int ee = e < K ? e : K - 1;                              // slots >= K mirror edge K - 1
+        s_pos[e][c] = A.bbpos[(size_t)A.eidx[(size_t)n * K + ee] * 15 + c];
+    }
+    __syncthreads();
+    // 25 atom-pair distances -> 16 Gaussians each (centre atom a major, neighbour atom b minor), as operands
+    for (int item = tid; item < 32 * 25 * 2; item += ET) {
+        const int hh = item & 1, e = (item >> 1) & 31, pr = item >> 6;
+        const int a = pr / 5, bq = pr - a * 5;
+        const float dd = dist_eps_nc(&s_pos[32][3 * a], &s_pos[e][3 * bq], 1e-6f);
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            // torch.linspace(0, 20, 16): ascending from the start below the midpoint, descending from the end above it
+            const float step = 20.0f / 15.0f;
+            const int r = 8 * hh + i;
+            const float mu = (r < 8) ? step * (float)r : 20.0f - step * (float)(15 - r);
+            const float z = (dd - mu) / 1.25f;
+            v[i] = expf(-(z * z));
+        }
+        h8 vh, vl;
+#pragma unroll
+        for (int i = 0; i < 8; i += 2) {
+            const f32x2v x = {v[i], v[i + 1]};
+            const h2v hi2 = cvt2(x);
+            const f32x2v d = {fmaf((float)hi2[0], -1.0f, x[0]), fmaf((float)hi2[1], -1.0f, x[1])};
+            const h2v lo2 = cvt2(d);
+            vh[i] = hi2[0]; vh[i + 1] = hi2[1];
+            vl[i] = lo2[0]; vl[i + 1] = lo2[1];
+        }
+        h8 *gp = reinterpret_cast<h8 *>(gb) + (2 * pr) * 64 + e + 32 * hh;
+        gp[0] = vh;
+        gp[64] = vl;
+    }
+    // accumulator init: bias + the 68 non-RBF inputs of this lane's edge
+    f32x16 acc[1];
+    {
+        const int jn = A.eidx[(size_t)n * K + jj];
+        long off = (long)(A.res_index[n] - A.res_index[jn]) + 32;
+        off = off < 0 ? 0 : (off > 64 ? 64 : off);
+        const float etype = (A.chain[n] == A.chain[jn]) ? 2.f : 1.f;
+        float phi = 0.f, psi = 0.f;
+        if (jn != n) {     // the j == i edge is 0 by construction (self-edge dihedrals)
+            phi = pair_dihedral_nc(&s_pos[32][6], &s_pos[j][0], &s_pos[j][3], &s_pos[j][6]);
+            psi = pair_dihedral_nc(&s_pos[32][0], &s_pos[32][3], &s_pos[32][6], &s_pos[j][0]);
+        }
+        load_tile(A.bias + 32 * wave, h, acc[0]);
+        add_tile(A.WT + (size_t)off * 128 + 32 * wave, h, acc[0]);
+        f32x16 w;
+        load_tile(A.WT + (size_t)465 * 128 + 32 * wave, h, w);
+#pragma unroll
+        for (int q = 0; q < 16; q++) acc[0][q] = fmaf(w[q], etype, acc[0][q]);
+        load_tile(A.WT + (size_t)466 * 128 + 32 * wave, h, w);
+#pragma unroll
+        for (int q = 0; q < 16; q++) acc[0][q] = fmaf(w[q], phi, acc[0][q]);
+        load_tile(A.WT + (size_t)467 * 128 + 32 * wave, h, w);
+#pragma unroll
+        for (int q = 0; q < 16; q++) acc[0][q] = fmaf(w[q], psi, acc[0][q]);
+    }
+    __syncthreads();
+#define EMB_STAGE(c) WSTAGE(c, NCH, acc, (emb_step<c>(AK, gb, lane, acc[0])))
+    EMB_STAGE(0) EMB_STAGE(1) EMB_STAGE(2) EMB_STAGE(3) EMB_STAGE(4) EMB_STAGE(5) EMB_STAGE(6)
+    EMB_STAGE(7) EMB_STAGE(8) EMB_STAGE(9) EMB_STAGE(10) EMB_STAGE(11) EMB_STAGE(12)
+#undef EMB_STAGE
+    ln_partial(acc[0], stat, wave, j, h);
+    __syncthreads();
+    float mean;
+    const float rstd = ln_merge(stat, j, mean);
+#pragma unroll
+    for (int q = 0; q < 16; q++) acc[0][q] -= mean;
+    ln_affine_tile(acc[0], rstd, A.ln_g + 32 * wave, A.ln_b + 32 * wave, h);
+    store_tile(A.hE0 + ((size_t)n * K + jj) * 128 + 32 * wave, h, acc[0]);       // lanes j >= K mirror edge K - 1
+}
+static const size_t EMB_SMEM = (EMB_GB_FLOATS + STAT_FLOATS) * sizeof(float);
+pp_status pp_launch_edge_embed_f16(pp_ctx *c, hipStream_t s) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_edge_embed_f16),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)EMB_SMEM));
+        attr_done = true;
+    }
+    const pp_plan *p = c->plan;
+    EmbedArgs A;
+    A.N = c->N; A.K = c->K;
+    A.bbpos = c->bbpos; A.eidx = c->eidx; A.res_index = c->b.residue_index; A.chain = c->b.chain_indices;
+    A.WT = p->edge_emb_T; A.bias = p->w + p->off.edge_emb_b;
+    A.ln_g = p->w + p->off.norm_edges_g; A.ln_b = p->w + p->off.norm_edges_b;
+    A.wstream = p->embed_stream; A.hE0 = c->hE0;
+    hipLaunchKernelGGL(k_edge_embed_f16, dim3(c->N), dim3(ET), EMB_SMEM, s, A);
+    PP_HIP_CHECK(hipGetLastError());
+    return PP_OK;
+}
+
 static float *g_dbg = nullptr;
 extern "C" void pp_debug_set_dbg(float *p) { g_dbg = p; }
 static EdgeArgs edge_args(pp_ctx *c, int layer, bool edge) {

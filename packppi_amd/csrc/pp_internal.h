@@ -63,6 +63,7 @@ struct pp_plan {
     const float *edge_emb_T;  // [468][128]
     const float *d0_in_T, *d0_out_T, *d2_in_T, *d2_out_T;   // [128][64] [64][32] [32][16] [16][4]
     const float *static_stream;                             // k_edge_static: W_B chunks of layer 0 (node, edge message)
+    const float *embed_stream;                              // split-f16 build: the 400 RBF columns of the edge embedding, 13 chunks
     // chemistry tables (device)
     float *default_frames;    // [21][8][16]
     int32_t *atom14_to_group; // [21][14]
@@ -144,6 +145,9 @@ pp_status pp_launch_node_embed(pp_ctx *c, const float *chi, int step, hipStream_
 pp_status pp_launch_node_update(pp_ctx *c, int layer, int last_mode, float *chi, int step, int mode,
                                 const float *noise, bool embed_next, hipStream_t s);
 pp_status pp_launch_edge_static(pp_ctx *c, hipStream_t s);
+#ifdef PP_EDGE_F16
+pp_status pp_launch_edge_embed_f16(pp_ctx *c, hipStream_t s);   // pp_edge_f16.hip: MFMA form of k_edge_embed
+#endif
 pp_status pp_launch_node_message(pp_ctx *c, int layer, hipStream_t s);
 bool pp_edge_fused();            // does pp_launch_edge_update also compute the next layer's node message?
 pp_status pp_launch_edge_update(pp_ctx *c, int layer, hipStream_t s);   // + node message of layer + 1

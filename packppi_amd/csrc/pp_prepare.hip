@@ -262,6 +262,9 @@ pp_status pp_launch_prepare(pp_ctx *c, hipStream_t s) {
     }
     hipLaunchKernelGGL(k_knn, dim3(N), dim3(KNN_THREADS), smem, s, c->b.X, c->b.residue_mask, c->L, c->K,
                        c->eidx, c->mask_att);
+#ifdef PP_EDGE_F16
+    return pp_launch_edge_embed_f16(c, s);      // MFMA form (pp_edge_f16.hip); k_edge_embed below is the fp32 build's
+#else
     const pp_plan *p = c->plan;
     size_t smem2 = (size_t)32 * EF_STRIDE * sizeof(float);
     hipLaunchKernelGGL(k_edge_embed, dim3(N), dim3(EF_THREADS), smem2, s, c->bbpos, c->eidx, c->b.residue_index,
@@ -269,4 +272,5 @@ pp_status pp_launch_prepare(pp_ctx *c, hipStream_t s) {
                        p->w + p->off.norm_edges_g, p->w + p->off.norm_edges_b, c->hE0);
     PP_HIP_CHECK(hipGetLastError());
     return PP_OK;
+#endif
 }
