@@ -158,7 +158,12 @@ __device__ __forceinline__ void gload_A(const h8 *__restrict__ wq, int chunk, AO
     int off = chunk * 1024;                  // h8 units per 16 KB chunk
     asm volatile("" : "+s"(off));
     const h8 *p = wq + off;
+#ifdef PP_X_WNT          /* experiment: non-temporal weight loads */
+    a.r[0] = __builtin_nontemporal_load(p); a.r[1] = __builtin_nontemporal_load(p + 64);
+    a.r[2] = __builtin_nontemporal_load(p + 128); a.r[3] = __builtin_nontemporal_load(p + 192);
+#else
     a.r[0] = p[0]; a.r[1] = p[64]; a.r[2] = p[128]; a.r[3] = p[192];
+#endif
 }
 // R residues share the A operands (weights) of a stage: R independent accumulator chains, issued interleaved so that a
 // wave alone on its SIMD never waits on its own previous MFMA.  x[r][T] = input tile T of residue r.
