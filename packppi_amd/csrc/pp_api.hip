@@ -141,19 +141,24 @@ static void put_chunk(std::vector<float> &arena, const float *W, int ld, int row
     put_chunk_f16(arena, W, ld, row0, [col0](int s, int h, int i) { return col0 + 8 * (2 * s + (i >> 2)) + 4 * h + (i & 3); });
 }
 // geometry chunk C of a message MLP's first layer: features f = 16 (2 C + s) + 8 h + i of the 72 (columns 384 + f)
-// Lane half h of the geometry operand carries the features of points 4h .. 4h+3 only (so a lane computes four points,
-// not eight), 40 slots per half: p_loc xyz x4 | |p_loc| x4 | local neighbour xyz x4 | its norm x4 | distance x4 | 0 x4;
-// k-step S = 2 C + s holds slots 8 S .. 8 S + 7.
+// Lane half h of the geometry operand carries the features of points 4h .. 4h+3 only (so the four waves of a workgroup
+// compute one point each), point-major: k-step q = 0..3 holds point 4h + q as
+// p_loc xyz | |p_loc| | local neighbour xyz | its norm; k-step 4 holds the four distances | 0 x4.  k-step S = 2 C + s.
 static void put_geo_chunk(std::vector<float> &arena, const float *W, int C) {
     put_chunk_f16(arena, W, 456, 0, [C](int s, int h, int i) {
-        const int slot = 8 * (2 * C + s) + i;
+        const int S5 = 2 * C + s;
         int f;
-        if (slot < 12) f = 3 * (4 * h + slot / 3) + slot % 3;
-        else if (slot < 16) f = 24 + 4 * h + (slot - 12);
-        else if (slot < 28) f = 32 + 3 * (4 * h + (slot - 16) / 3) + (slot - 16) % 3;
-        else if (slot < 32) f = 56 + 4 * h + (slot - 28);
-        else if (slot < 36) f = 64 + 4 * h + (slot - 32);
-        else return -1;
+        if (S5 < 4) {
+            const int pt = 4 * h + S5;
+            if (i < 3) f = 3 * pt + i;
+            else if (i == 3) f = 24 + pt;
+            else if (i < 7) f = 32 + 3 * pt + (i - 4);
+            else f = 56 + pt;
+        } else if (S5 == 4 && i < 4) {
+            f = 64 + 4 * h + i;
+        } else {
+            return -1;
+        }
         return 384 + f;
     });
 }

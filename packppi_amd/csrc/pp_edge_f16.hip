@@ -210,9 +210,9 @@ __device__ __forceinline__ void mfma_h(const AOp &a, const HT (&x)[R], f32x16 (&
         }
     }
 }
-// the 72 invariant-point features as operands: lane half h carries the features of points 4h .. 4h+3 in 40 slots
-// (geometry_share below), k-step S5 = 0..4 holds slots 8 S5 .. 8 S5 + 7; geometry chunk C holds k-steps 2C and 2C+1 (the
-// last one is all padding and skipped).  The operands live in a 10 KB LDS block per residue, [k-step][hi | lo][lane] h8.
+// the 72 invariant-point features as operands: lane half h carries the features of points 4h .. 4h+3, one point per
+// k-step S5 = 0..3 and the four distances in k-step 4 (geometry_share below); geometry chunk C holds k-steps 2C and 2C+1
+// (the last one is all padding and skipped).  The operands live in a 10 KB LDS block per residue, [k-step][hi | lo][lane] h8.
 #define GBUF_FLOATS (5 * 2 * 64 * 4)
 template <int R, int C>
 __device__ __forceinline__ void mfma_geo(const AOp &a, const float *gbuf, int lane, f32x16 (&acc)[R]) {
@@ -324,10 +324,11 @@ __device__ __forceinline__ void ln_affine_tile(f32x16 &v, float rstd, const floa
 }
 
 // 72 invariant point features of edge (i, j) as split-f16 MFMA operands in LDS.  Lane half h carries the features of
-// points 4h .. 4h+3 (pp_api.hip put_geo_chunk permutes W_G's columns to match): 40 slots =
-// p_loc xyz x4 | |p_loc| x4 | R_i^T (p_glob_j - t_i) xyz x4 | its norm x4 | |p_glob_i - p_glob_j| x4 | 0 x4.
-// All four waves need all of it as B operand, so they SHARE the work: wave w computes point 4h + w of its lanes (nine
-// values), splits them and scatters the f16 pairs into the operand block; a workgroup barrier follows at the call site.
+// points 4h .. 4h+3 (pp_api.hip put_geo_chunk permutes W_G's columns to match), point-major: k-step q = 0..3 holds point
+// 4h + q as  p_loc xyz | |p_loc| | R_i^T (p_glob_j - t_i) xyz | its norm;  k-step 4 holds |p_glob_i - p_glob_j| of the four
+// points | 0 x4.  All four waves need all of it as B operand, so they SHARE the work: wave w computes point 4h + w of its
+// lanes, splits its eight values into ONE operand vector (hi, lo: two lane-linear 16-byte LDS writes) and drops its
+// distance into k-step 4; a workgroup barrier follows at the call site.
 __device__ __forceinline__ void geometry_share(const float *__restrict__ pts_i, const float *__restrict__ fr,
                                                const float *__restrict__ pts_j, int h, int wave, int lane, float *gbuf) {
     const int q = wave;
@@ -347,25 +348,24 @@ __device__ __forceinline__ void geometry_share(const float *__restrict__ pts_i, 
     const float ex = gx - jx, ey = gy - jy, ez = gz - jz;
     v[8] = sqrtf(ex * ex + ey * ey + ez * ez + 1e-8f);
     v[9] = 0.f;
-    const int slot[9] = {3 * q, 3 * q + 1, 3 * q + 2, 12 + q, 16 + 3 * q, 16 + 3 * q + 1, 16 + 3 * q + 2, 28 + q, 32 + q};
-    _Float16 *gh = reinterpret_cast<_Float16 *>(gbuf);
+    h8 vh, vl;
+    h2v dh, dl;
 #pragma unroll
     for (int i = 0; i < 10; i += 2) {
         const f32x2v x = {v[i], v[i + 1]};
         const h2v hh = cvt2(x);
         const f32x2v d = {fmaf((float)hh[0], -1.0f, x[0]), fmaf((float)hh[1], -1.0f, x[1])};
         const h2v ll = cvt2(d);
-#pragma unroll
-        for (int e = 0; e < 2; e++) {
-            if (i + e < 9) {
-                const int sidx = slot[i + e];
-                const int at = ((2 * (sidx >> 3)) * 64 + lane) * 8 + (sidx & 7);       // hi block of k-step sidx / 8
-                gh[at] = hh[e];
-                gh[at + 64 * 8] = ll[e];                                              // lo block
-            }
-        }
+        if (i < 8) { vh[i] = hh[0]; vh[i + 1] = hh[1]; vl[i] = ll[0]; vl[i + 1] = ll[1]; }
+        else { dh = hh; dl = ll; }
     }
-    if (wave == 0) {          // padding slots 36..39 (k-step 4, elements 4..7), hi and lo
+    h8 *gv = reinterpret_cast<h8 *>(gbuf);
+    gv[(2 * q) * 64 + lane] = vh;                       // k-step q, hi
+    gv[(2 * q + 1) * 64 + lane] = vl;                   // k-step q, lo
+    _Float16 *gh = reinterpret_cast<_Float16 *>(gbuf);
+    gh[((2 * 4) * 64 + lane) * 8 + q] = dh[0];          // k-step 4, element q: this point's distance
+    gh[((2 * 4 + 1) * 64 + lane) * 8 + q] = dl[0];
+    if (wave == 0) {          // padding elements 4..7 of k-step 4, hi and lo
         const f32x2v z = {0.f, 0.f};
         *reinterpret_cast<f32x2v *>(gh + ((2 * 4) * 64 + lane) * 8 + 4) = z;
         *reinterpret_cast<f32x2v *>(gh + ((2 * 4 + 1) * 64 + lane) * 8 + 4) = z;
