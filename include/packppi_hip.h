@@ -88,7 +88,12 @@ pp_status pp_plan_set_clash_params(pp_plan *plan, float overlap_tolerance, const
 
 /* Replaces the timestep-invariant part of ProteinEncoder.forward (encoder.py:198-246):
  * kNN graph, 468-d edge features, edge embedding + LayerNorm, backbone frames.  The batch
- * pointers must stay valid for the lifetime of the ctx. */
+ * pointers must stay valid for the lifetime of the ctx.
+ * A ctx keeps all its device workspaces in one allocation that pp_ctx_destroy hands back to the plan
+ * (a pool of up to four) instead of freeing it: creating a ctx per batch costs no hipMalloc/hipFree.
+ * pp_ctx_destroy does not wait for work already enqueued on the ctx's stream; the next ctx that takes
+ * the workspace over either runs on that same stream (ordered behind it) or synchronises with it first.
+ * pp_plan_destroy frees the pool: destroy the plan's contexts, and let their work finish, before it. */
 pp_status pp_complex_prepare(pp_plan *plan, const pp_batch *batch, void *stream, pp_ctx **ctx);
 void pp_ctx_destroy(pp_ctx *ctx);
 
