@@ -135,6 +135,9 @@ enum { P_BMID = 0, P_BOUT = 128, P_FOB = 256, P_G2 = 384, P_BE2 = 512, P_FIB = 6
 #ifndef PP_WDEPTH
 #define PP_WDEPTH 2
 #endif
+#ifndef PP_NXB_R1
+#define PP_NXB_R1 2        // exchange buffers of the one-residue instances (1: 35.5 KB of LDS, four workgroups per CU fit)
+#endif
 #ifndef PP_WGS2
 #define PP_WGS2 2          // same for the two-residue instances
 #endif
@@ -501,7 +504,7 @@ template <int R, bool ST0>
 __global__ void __launch_bounds__(ET, R == 1 ? PP_WGS : PP_WGS2)
 k_node_message(EdgeArgs A) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int NXB = R == 1 ? 2 : 1;
+    constexpr int NXB = R == 1 ? PP_NXB_R1 : 1;
     float *const xb0 = smem;
     float *xbuf = xb0;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -600,7 +603,7 @@ template <int R, bool ST0, bool FUSE>
 __global__ void __launch_bounds__(ET, R == 1 ? PP_WGS : PP_WGS2)
 k_edge_update(EdgeArgs A) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int NXB = R == 1 ? 2 : 1;
+    constexpr int NXB = R == 1 ? PP_NXB_R1 : 1;
     float *const xb0 = smem;
     float *xbuf = xb0, *x1buf = smem + NXB * R * XBUF_FLOATS, *stat = x1buf + R * XBUF_FLOATS,
           *prm = stat + R * STAT_FLOATS;
@@ -1057,9 +1060,9 @@ static EdgeArgs edge_args(pp_ctx *c, int layer, bool edge) {
 static size_t g_lds_pad = PP_LDS_PAD;     // pp_debug_set_lds_pad(): occupancy experiments
 extern "C" void pp_debug_set_lds_pad(int bytes) { g_lds_pad = (size_t)bytes; }
 static size_t pad_smem(size_t b) { return b > g_lds_pad ? b : g_lds_pad; }
-static size_t nm_smem(int R) { return pad_smem(((R == 1 ? 2 : 1) * R * XBUF_FLOATS + R * GBUF_FLOATS) * sizeof(float)); }
+static size_t nm_smem(int R) { return pad_smem(((R == 1 ? PP_NXB_R1 : 1) * R * XBUF_FLOATS + R * GBUF_FLOATS) * sizeof(float)); }
 static size_t eu_smem(int R) {
-    return pad_smem((((R == 1 ? 2 : 1) + 1) * R * XBUF_FLOATS + R * STAT_FLOATS + PARAM_LDS) * sizeof(float));
+    return pad_smem((((R == 1 ? PP_NXB_R1 : 1) + 1) * R * XBUF_FLOATS + R * STAT_FLOATS + PARAM_LDS) * sizeof(float));
 }
 #define ST_SMEM pad_smem(0)
 #define MAX_SMEM (160 * 1024)
