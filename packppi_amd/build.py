@@ -30,23 +30,25 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_library(force=False, verbose=True, extra_flags=()):
-    if not force and not needs_build():
+def build_library(force=False, verbose=True, extra_flags=(), tag=""):
+    """Build the library; with ``tag`` a variant ``libpackppi_hip.<tag>.so`` (selected at run time by PACKPPI_LIB)."""
+    lib_path = LIB if not tag else LIB.replace(".so", f".{tag}.so")
+    if not tag and not force and not needs_build():
         return LIB
     hipcc = _hipcc()
     objs = []
     for src in SOURCES:
-        obj = os.path.join(CSRC, src.replace(".hip", ".o"))
+        obj = os.path.join(CSRC, src.replace(".hip", f".{tag}.o" if tag else ".o"))
         cmd = [hipcc, *FLAGS, *extra_flags, "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
         objs.append(obj)
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib_path, *objs]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
-    return LIB
+    return lib_path
 
 
 def compile_alternate(verbose=True):
@@ -64,4 +66,7 @@ def compile_alternate(verbose=True):
 
 
 if __name__ == "__main__":
-    build_library(force="--force" in sys.argv)
+    # python -m packppi_amd.build [--force] [--tag NAME -DFLAG ...]   (a tagged build is a variant library for experiments)
+    argv = sys.argv[1:]
+    tag = argv[argv.index("--tag") + 1] if "--tag" in argv else ""
+    build_library(force="--force" in argv, extra_flags=[a for a in argv if a.startswith("-D")], tag=tag)

@@ -81,7 +81,6 @@ static size_t put_T4(std::vector<float> &arena, const float *W, int rows, int ld
     return at;
 }
 
-#ifdef PP_EDGE_F16      // experimental split-f16 edge kernels (pp_edge_f16.hip): PACKPPI_EDGE=f16 python -m packppi_amd.build
 // fp32 -> IEEE binary16 bits, round to nearest even (subnormals kept: the MFMA honours them)
 static uint16_t f2h(float f) {
     uint32_t x;
@@ -112,6 +111,7 @@ static float h2f(uint16_t h) {
     return v;
 }
 
+#ifdef PP_EDGE_F16      // experimental split-f16 edge kernels (pp_edge_f16.hip): PACKPPI_EDGE=f16 python -m packppi_amd.build
 // Append one weight chunk (a K = 32 slice of a 128-row layer) packed for the edge kernels' wave-private LDS-DMA pipeline
 // and split-f16 arithmetic (pp_edge.hip): [wave 4][k-step s 2][part hi|lo 2][lane 64][i 8] halves = 16 KB, where lane =
 // (row & 31, half h) of wave row >> 5 holds the A-operand of v_mfma_f32_32x32x16_f16 for k-step s: input column
@@ -202,6 +202,90 @@ static size_t put_stream(std::vector<float> &arena, const float *w, const LayerO
     }
     return at;
 }
+// ---- k_node_update (pp_node.hip) ------------------------------------------------------------------------------
+// One slot: rows row0 .. row0+15 (those < nrows are real) of W (row stride ld), columns col0 .. col0+31 (those < col0 + ncols
+// real), as the A operand of v_mfma_f32_16x16x32_f16: lane l holds W[row0 + (l & 15)][col0 + 8 (l >> 4) + j], j = 0..7;
+// hi = f16(w), lo = f16((w - hi) * 2^11) (the scaling keeps lo out of the f16 subnormal range; the kernel accumulates the
+// lo products separately and folds them in with 2^-11).
+static void put_node_slot(uint16_t *d, const float *W, int ld, int row0, int nrows, int col0, int ncols) {
+    for (int lane = 0; lane < 64; lane++)
+        for (int j = 0; j < 8; j++) {
+            const int r = lane & 15, k = 8 * (lane >> 4) + j;
+            const float w = (W && r < nrows && k < ncols) ? W[(size_t)(row0 + r) * ld + col0 + k] : 0.f;
+            const uint16_t hi = f2h(w);
+            d[lane * 8 + j] = hi;
+            d[512 + lane * 8 + j] = f2h((w - h2f(hi)) * PP_NU_LO_SCALE);
+        }
+}
+// the slot list of layer l (see pp_internal.h): [wave][slot]
+static size_t put_node_stream(std::vector<float> &arena, const float *w, const WeightOff &off, int l) {
+    const LayerOff &L = off.layer[l];
+    const bool last = l == 2;
+    const int nslots = last ? PP_NU_SLOTS_LAST : PP_NU_SLOTS_MID;
+    size_t at = (arena.size() + 3) & ~size_t(3);
+    arena.resize(at + (size_t)PP_NU_WAVES * nslots * PP_NU_SLOT_FLOATS, 0.f);
+    for (int wv = 0; wv < PP_NU_WAVES; wv++) {
+        uint16_t *base = reinterpret_cast<uint16_t *>(arena.data() + at + (size_t)wv * nslots * PP_NU_SLOT_FLOATS);
+        int s = 0;
+        auto put = [&](const float *W, int ld, int row0, int nrows, int col0, int ncols) {
+            put_node_slot(base + (size_t)s * 1024, W, ld, row0, nrows, col0, ncols);
+            s++;
+        };
+        for (int ks = 0; ks < 4; ks++) put(w + L.nm_out_w, 128, 16 * wv, 16, 32 * ks, 32);
+        for (int c = 0; c < 4; c++)
+            for (int ks = 0; ks < 4; ks++) put(w + L.nd_in_w, 128, 16 * (4 * wv + c), 16, 32 * ks, 32);
+        for (int ks = 0; ks < 16; ks++) put(w + L.nd_out_w, 512, 16 * wv, 16, 32 * ks, 32);
+        if (!last) {
+            const LayerOff &Nx = off.layer[l + 1];
+            for (int ks = 0; ks < 4; ks++) put(w + L.em_in_w, 456, 16 * wv, 16, 32 * ks, 32);
+            for (int ks = 0; ks < 4; ks++) put(w + L.em_in_w, 456, 16 * wv, 16, 256 + 32 * ks, 32);
+            for (int ks = 0; ks < 4; ks++) put(w + Nx.nm_in_w, 456, 16 * wv, 16, 32 * ks, 32);
+            for (int ks = 0; ks < 4; ks++) put(w + Nx.nm_in_w, 456, 16 * wv, 16, 256 + 32 * ks, 32);
+            // the 48 point features: rows 0..23 = this layer's points_fn_edge, 24..47 = the next layer's points_fn_node
+            std::vector<float> pw(48 * 128);
+            memcpy(pw.data(), w + L.pts_edge_w, 24 * 128 * sizeof(float));
+            memcpy(pw.data() + 24 * 128, w + Nx.pts_node_w, 24 * 128 * sizeof(float));
+            for (int ks = 0; ks < 4; ks++) put(wv < 3 ? pw.data() : nullptr, 128, 16 * wv, 16, 32 * ks, 32);
+        } else {
+            const LayerOff &L0 = off.layer[0];
+            for (int ks = 0; ks < 4; ks++) put(wv < 4 ? w + off.d0_in_w : nullptr, 128, 16 * wv, 16, 32 * ks, 32);
+            for (int t = 0; t < 2; t++)
+                for (int ks = 0; ks < 2; ks++) put(wv == 0 ? w + off.d0_out_w : nullptr, 64, 16 * t, 16, 32 * ks, 32);
+            put(wv == 0 ? w + off.d2_in_w : nullptr, 32, 0, 16, 0, 32);
+            put(wv == 0 ? w + off.d2_out_w : nullptr, 16, 0, 4, 0, 16);
+            for (int ks = 0; ks < 4; ks++) put(w + L0.nm_in_w, 456, 16 * wv, 16, 32 * ks, 32);
+            for (int ks = 0; ks < 4; ks++) put(w + L0.nm_in_w, 456, 16 * wv, 16, 256 + 32 * ks, 32);
+            for (int ks = 0; ks < 4; ks++) put(wv < 2 ? w + L0.pts_node_w : nullptr, 128, 16 * wv, wv == 0 ? 16 : 8, 32 * ks, 32);
+        }
+        if (s != nslots) abort();
+    }
+    return at;
+}
+static size_t put_node_params(std::vector<float> &arena, const float *w, const WeightOff &off, int l) {
+    const LayerOff &L = off.layer[l];
+    const bool last = l == 2;
+    size_t at = (arena.size() + 3) & ~size_t(3);
+    arena.resize(at + (last ? NU_P_LAST_TOTAL : NU_P_MID_TOTAL), 0.f);
+    float *d = arena.data() + at;
+    auto cp = [&](int dst, size_t src, int n) { memcpy(d + dst, w + src, n * sizeof(float)); };
+    cp(NU_P_OUTB, L.nm_out_b, 128); cp(NU_P_G0, L.norm_g[0], 128); cp(NU_P_B0, L.norm_b[0], 128);
+    cp(NU_P_FIB, L.nd_in_b, 512); cp(NU_P_FOB, L.nd_out_b, 128); cp(NU_P_G1, L.norm_g[1], 128); cp(NU_P_B1, L.norm_b[1], 128);
+    if (!last) {
+        const LayerOff &Nx = off.layer[l + 1];
+        cp(NU_P_PAE_B, L.em_in_b, 128); cp(NU_P_PAN_B, Nx.nm_in_b, 128);
+        cp(NU_P_PTS_B, L.pts_edge_b, 24); cp(NU_P_PTS_B + 24, Nx.pts_node_b, 24);
+    } else {
+        const LayerOff &L0 = off.layer[0];
+        cp(NU_P_DB0, off.d0_in_b, 64); cp(NU_P_DB1, off.d0_out_b, 32); cp(NU_P_DB2, off.d2_in_b, 16); cp(NU_P_DB3, off.d2_out_b, 4);
+        cp(NU_P_PAN0_B, L0.nm_in_b, 128); cp(NU_P_PTS0_B, L0.pts_node_b, 24);
+        cp(NU_P_EMB_B, off.node_emb_b, 128); cp(NU_P_EMB_G, off.norm_nodes_g, 128); cp(NU_P_EMB_BETA, off.norm_nodes_b, 128);
+        // node_embedding.weight [128][51], input columns 21..50 (6 backbone sin/cos, 8 chi sin/cos, 16 time), transposed
+        for (int k = 0; k < 30; k++)
+            for (int f = 0; f < 128; f++) d[NU_P_EMBT + k * 128 + f] = w[off.node_emb_w + (size_t)f * 51 + 21 + k];
+    }
+    return at;
+}
+
 // k_edge_static's stream: the W_B chunks of layer 0's node message, then of its edge message
 static size_t put_static_stream(std::vector<float> &arena, const float *w, const LayerOff &L) {
     size_t at = (arena.size() + 3) & ~size_t(3);
@@ -259,7 +343,7 @@ extern "C" pp_status pp_plan_create(const float *weights, size_t n_weights, cons
     arena.reserve(3u << 20);
     size_t o_node_emb = put_T(arena, weights + off.node_emb_w, 128, 51, 0, 51);
     size_t o_edge_emb = put_T(arena, weights + off.edge_emb_w, 128, 468, 0, 468);
-    size_t o_l[3][12];
+    size_t o_l[3][14];
     for (int l = 0; l < 3; l++) {
         const LayerOff &L = off.layer[l];
         o_l[l][0] = put_T4(arena, weights + L.pts_node_w, 24, 128, 0, 128);
@@ -275,6 +359,8 @@ extern "C" pp_status pp_plan_create(const float *weights, size_t n_weights, cons
         o_l[l][10] = put_stream(arena, weights, L, true, l == 0);
         if (l < 2) put_stream(arena, weights, off.layer[l + 1], false, false);   // fused kernel: next layer's node message follows
         o_l[l][11] = put_edge_params(arena, weights, L);
+        o_l[l][12] = put_node_stream(arena, weights, off, l);
+        o_l[l][13] = put_node_params(arena, weights, off, l);
     }
     size_t o_static = put_static_stream(arena, weights, off.layer[0]);
 #ifdef PP_EDGE_F16
@@ -304,6 +390,7 @@ extern "C" pp_status pp_plan_create(const float *weights, size_t n_weights, cons
         t.nd_in_T = p->wT + o_l[l][7]; t.nd_out_T = p->wT + o_l[l][8];
         t.nm_stream = p->wT + o_l[l][9]; t.em_stream = p->wT + o_l[l][10];
         t.em_params = p->wT + o_l[l][11];
+        t.nu_stream = p->wT + o_l[l][12]; t.nu_params = p->wT + o_l[l][13];
     }
     p->static_stream = p->wT + o_static;
 #ifdef PP_EDGE_F16

@@ -41,6 +41,27 @@ struct LayerT {
     const float *nd_out_T;                           // [512][128]
     const float *nm_stream, *em_stream;              // MFMA weight chunks packed in consumption order (pp_edge.hip)
     const float *em_params;                          // edge kernel small vectors, one block
+    const float *nu_stream;                          // k_node_update: split-f16 weight slots, [wave][slot] (pp_api.hip put_node_stream)
+    const float *nu_params;                          // k_node_update: small per-layer vectors, one block (NU_P_* offsets)
+};
+
+// ---- k_node_update (pp_node.hip): packed weight stream and parameter block ---------------------------------------
+// One slot = the A operand of one (16-feature tile, 32-deep k-step) of v_mfma_f32_16x16x32_f16 as split f16:
+// [hi | lo * 2^11][lane 64][8 halves] = 2 KB; a wave's slots are contiguous in the order it consumes them.
+// Layers 0 and 1 use the MID list (next = this layer's edge message + the next layer's node message), layer 2 the LAST
+// list (decoder + the layer-0 node-message inputs of the next step).
+#define PP_NU_WAVES 8
+#define PP_NU_SLOT_FLOATS 512
+#define PP_NU_SLOTS_MID 56     // W_out 4 | FFN-in 16 | FFN-out 16 | PAe 4 | PCe 4 | PAn 4 | PCn 4 | pts 4 (waves 0-2)
+#define PP_NU_SLOTS_LAST 58    // W_out 4 | FFN-in 16 | FFN-out 16 | D1 4 (waves 0-3) | D2 4, D3 1, D4 1 (wave 0) | PAn 4 | PCn 4 | pts 4 (waves 0-1)
+#define PP_NU_LO_SCALE 2048.0f
+enum {
+    NU_P_OUTB = 0, NU_P_G0 = 128, NU_P_B0 = 256, NU_P_FIB = 384, NU_P_FOB = 896, NU_P_G1 = 1024, NU_P_B1 = 1152,
+    // MID
+    NU_P_PAE_B = 1280, NU_P_PAN_B = 1408, NU_P_PTS_B = 1536, NU_P_MID_TOTAL = 1600,
+    // LAST
+    NU_P_DB0 = 1280, NU_P_DB1 = 1344, NU_P_DB2 = 1376, NU_P_DB3 = 1392, NU_P_PAN0_B = 1408, NU_P_PTS0_B = 1536,
+    NU_P_EMB_B = 1568, NU_P_EMB_G = 1696, NU_P_EMB_BETA = 1824, NU_P_EMBT = 1952, NU_P_LAST_TOTAL = 1952 + 30 * 128
 };
 
 struct StepParams;

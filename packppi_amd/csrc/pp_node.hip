@@ -43,13 +43,6 @@ struct PreW {            // weights feeding one message function
     const float *AT, *CT, *in_b;    // [128][128] x2, [128]
 };
 
-struct UpdW {
-    const float *outT, *out_b;      // node_message_fn.W_out^T [128][128], bias
-    const float *g0, *b0, *g1, *b1; // norm.0 / norm.1
-    const float *ffn_inT, *ffn_in_b, *ffn_outT, *ffn_out_b;   // [128][512],[512],[512][128],[128]
-    PreW pre_edge, pre_next;
-    const float *d0_inT, *d0_in_b, *d0_outT, *d0_out_b, *d2_inT, *d2_in_b, *d2_outT, *d2_out_b;
-};
 
 // one feature's values for the NB residues of the block (ext vector: fma on it selects v_pk_fma_f32)
 typedef float f4v __attribute__((ext_vector_type(4)));
@@ -276,367 +269,477 @@ __device__ __forceinline__ float wrap_pi(float x) {
     return r - PIf;
 }
 
-// small dense layer used by the decoder: width <= 128 outputs, K split over the four ks-groups
-template <int KIN>
-__device__ __forceinline__ VN dense_small(Smem &sm, int &flip, const float *WT, int width, const VN *act,
-                                          const float *bias) {
-    const int f = threadIdx.x & 127, ks = threadIdx.x >> 7;
-    VN p = f < width ? dense_slice<KIN>(WT, width, f, act, ks) : vn(0.f);
-    VN r = meet(sm, flip, p, 128, f, ks);
-    return f < width ? vadd(r, vn(bias[f])) : vn(0.f);
-}
+// ==================================================================================================================
+// k_node_update on the matrix pipe (split-f16 MFMA, fp32-level accuracy)
+//
+// A 512-thread workgroup owns a tile of 16 consecutive residues for the whole chain
+//     S -> W_out -> LN(h_V + .) -> FFN 128 -> 512 -> 128 -> LN -> mask -> {W_A, W_C, points} x 2        (layers 0, 1)
+//                                                             ... -> decoder -> reverse step -> embedding -> {W_A, W_C, points}   (layer 2)
+// computed transposed, Y^T[feature][residue] = W[feature][k] X^T[k][residue], with v_mfma_f32_16x16x32_f16: wave w owns
+// output-feature tile w (16 features) of every 128-wide layer and reads only its own weight rows (A operand, straight from
+// global memory into registers) but all input features (B operand) from an LDS image [residue][feature] of the previous
+// layer's output, stored as split f16 (hi, lo * 2^11) in two planes whose row stride (features + 16 halves) makes the
+// 16-byte operand reads bank-conflict free.  D: lane (r = lane & 15, g = lane >> 4), register i <-> feature 16 w + 4 g + i
+// of residue r.
+//
+// Arithmetic: x = hi + lo with hi = f16(x) (round to nearest) and lo' = f16((x - hi) * 2^11); a product is three MFMAs,
+// Wh xh into one accumulator and Wh xl' + Wl' xh into a second one that is folded in with 2^-11 at the end.  The scaling keeps
+// lo' a normal f16 number for every |x| >= 2^-25 (unscaled, lo is subnormal below |x| = 2^-3 and carries an absolute error
+// of 3e-8); the dropped Wl xl term is 2^-22 relative.
+//
+// What bounds the kernel: every workgroup needs the layer's whole weight set (0.88 MB) through its CU's vector memory
+// path (64 B/clk); N/16 workgroups run, so for one complex most CUs idle and the launch takes as long as ONE CU needs to
+// stream 0.88 MB.  The stream is therefore decoupled from the dependent chain: each wave's slots are contiguous in global
+// memory in consumption order and are fetched PP_NU_DEPTH stages ahead into a register ring, through barriers and
+// LayerNorms (the compiler counts these ordinary loads; __syncthreads() waits for LDS traffic only), so the loads never
+// stop while the chain (about 2 us of MFMA + LDS latency) runs underneath.
+// ==================================================================================================================
+typedef _Float16 nh8 __attribute__((ext_vector_type(8)));
+typedef float nf4 __attribute__((ext_vector_type(4)));
+typedef float nf2 __attribute__((ext_vector_type(2)));
+typedef unsigned nu2 __attribute__((ext_vector_type(2)));
 
-// ---- k_node_update: the same arithmetic as the helpers above, software-pipelined -------------------------------
-// Measured (tools/debug/time_vs_n.py): the kernel takes the same 24 us for 16 and for 256 blocks -- it is one block's
-// dependent chain of ~30 L2 round trips (every dense phase used to fetch its 32-128 weights per thread right before
-// using them).  Weights do not depend on activations, so here every phase's weights are fetched into registers one or
-// two phases ahead (five register sets of 32), and the per-feature vectors (biases, LayerNorm gains) at kernel start.
-struct WSet {
-    float v[32];
-};
-// rows k0 .. k0+KL of column col of a transposed weight [in][ldo]
-// `after`: a value the previous user of this register set produced.  The weights are read-only kernel arguments, so
-// the compiler would otherwise hoist every fetch of the kernel to its top (and spill ~1900 registers); making the
-// offset opaque behind an empty asm that consumes `after` pins the fetch between that value and its first use.
-template <int KL, int DST0 = 0>
-__device__ __forceinline__ void wload(WSet &w, const float *__restrict__ WT, int ldo, int col, int k0, float after) {
-    int off = (k0 >> 2) * ldo + col;          // in float4 units of the k-quad interleaved layout (put_T4)
-    asm volatile("" : "+v"(off) : "v"(after));
-    const float4 *w4 = reinterpret_cast<const float4 *>(WT);
-#pragma unroll
-    for (int i = 0; i < KL / 4; i++) {
-        const float4 q = w4[off + i * ldo];
-        w.v[DST0 + 4 * i] = q.x; w.v[DST0 + 4 * i + 1] = q.y; w.v[DST0 + 4 * i + 2] = q.z; w.v[DST0 + 4 * i + 3] = q.w;
-    }
-}
-template <int KL, int SRC0 = 0>
-__device__ __forceinline__ VN wdot(const WSet &w, const VN *act, VN acc) {
-#pragma unroll
-    for (int i = 0; i < KL; i++) {
-#ifdef PP_X_NOACT             // timing-only ablation: no activation reads from LDS
-        acc = vfma(w.v[SRC0 + i], acc, acc);
-#else
-        acc = vfma(w.v[SRC0 + i], act[i], acc);
+#ifndef PP_NU_DEPTH
+#define PP_NU_DEPTH 8
 #endif
-        // keep the scheduler from running the x/y chains of a whole slice ahead of the z/w chains (it then parks
-        // half of every activation read in scratch)
-        if ((i & 7) == 7) VN_FOR asm volatile("" : "+v"(acc.g[gi].x), "+v"(acc.g[gi].y), "+v"(acc.g[gi].z), "+v"(acc.g[gi].w));
-    }
-    return acc;
+#define NU_ND PP_NU_DEPTH
+#define NU_NRING (NU_ND + 1)
+#define NU_S128 144        // halves per residue row of a 128-feature operand image
+#define NU_S512 528        // ... of the 512-feature one
+#define NU_INV_LO (1.0f / PP_NU_LO_SCALE)
+
+struct AOpN {
+    nh8 hi, lo;
+};
+
+struct SmemU {
+    _Float16 a_hi[16 * NU_S128], a_lo[16 * NU_S128];     // S, later h2
+    _Float16 b_hi[16 * NU_S128], b_lo[16 * NU_S128];     // h1, later the next step's embedded h_V
+    _Float16 c_hi[16 * NU_S512], c_lo[16 * NU_S512];     // FFN hidden; decoder activations in columns 0..127
+    float stats[3][8][16][2];                            // LayerNorm partials (per wave: mean, centred sum of squares)
+    float pts[16][48];                                   // local points of the tile
+    float sc[16][8];                                     // layer 2: masked sin / cos of the stepped chi
+    float par[NU_P_LAST_TOTAL];                          // parameter block (layers 0, 1 use the first NU_P_MID_TOTAL)
+};
+
+struct NUpdArgs {
+    int N;
+    const float *rmask;          // [N]
+    const int64_t *rtype;        // [N]
+    const float *bb_sincos;      // [N][6]
+    const float *sc_mask;        // [N][4]
+    const uint8_t *m1pi, *m2pi;  // [N][4]
+    const float *frames;         // [N][12]
+    const StepParams *steps;
+    const float *embT;           // [51][128]
+    const float *wstream, *params;
+    float *hV;
+    const float *S, *msum;
+    float *ptsN, *PAn, *PCn, *ptsE, *PAe, *PCe, *score;
+};
+
+template <bool LAST>
+__device__ constexpr int nu_slot_waves(int s) {       // how many waves (0 .. n-1) own slot s; see pp_internal.h
+    if (!LAST) return s < 52 ? 8 : 3;
+    return s < 36 ? 8 : s < 40 ? 4 : s < 46 ? 1 : s < 54 ? 8 : 2;
 }
 
-// four dot products over the same activation slice in one pass (one LDS read feeds four outputs)
-#define ACC_PIN(a) VN_FOR asm volatile("" : "+v"(a.g[gi].x), "+v"(a.g[gi].y), "+v"(a.g[gi].z), "+v"(a.g[gi].w))
-__device__ __forceinline__ void wdot4(const WSet &w0, const WSet &w1, const WSet &w2, const WSet &w3, const VN *act,
-                                      VN &a0, VN &a1, VN &a2, VN &a3) {
+__device__ __forceinline__ void gload_N(const nh8 *__restrict__ wq, int slot, AOpN &a) {
+    int off = slot * 128;                     // nh8 units per 2 KB slot
+    asm volatile("" : "+s"(off));             // opaque: the fetch is issued where it is written, not hoisted to the top
+    const nh8 *p = wq + off;
+    a.hi = p[0];
+    a.lo = p[64];
+}
+#define MFMA_N(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
+__device__ __forceinline__ void mm3(const AOpN &a, const nh8 &bh, const nh8 &bl, nf4 &cH, nf4 &cL) {
+    cH = MFMA_N(a.hi, bh, cH);
+    cL = MFMA_N(a.hi, bl, cL);
+    cL = MFMA_N(a.lo, bh, cL);
+}
+__device__ __forceinline__ nf4 fold(const nf4 &cH, const nf4 &cL) {
+    return nf4{fmaf(cL[0], NU_INV_LO, cH[0]), fmaf(cL[1], NU_INV_LO, cH[1]), fmaf(cL[2], NU_INV_LO, cH[2]), fmaf(cL[3], NU_INV_LO, cH[3])};
+}
+// B operand of k-step ks: features 32 ks + 8 g .. + 7 of residue r
+__device__ __forceinline__ void ldB(const _Float16 *hi, const _Float16 *lo, int rowoff, int ks, nh8 &bh, nh8 &bl) {
+    bh = *reinterpret_cast<const nh8 *>(hi + rowoff + 32 * ks);
+    bl = *reinterpret_cast<const nh8 *>(lo + rowoff + 32 * ks);
+}
+// two fp32 values -> packed (hi, hi), (lo', lo').  Scalar round-to-nearest conversions + v_pack: gfx950's packed
+// v_cvt_pk_f16_f32 (what a plain cast of a pair compiles to) is the instruction DESIGN.md section 4 found unreliable with more
+// than one wave per SIMD.
+__device__ __forceinline__ void split2(float x0, float x1, unsigned &hp, unsigned &lp) {
+    unsigned a, b, c, d;
+    float fa, fb;
+    asm("v_cvt_f16_f32 %0, %1" : "=v"(a) : "v"(x0));
+    asm("v_cvt_f16_f32 %0, %1" : "=v"(b) : "v"(x1));
+    asm("v_cvt_f32_f16 %0, %1" : "=v"(fa) : "v"(a));
+    asm("v_cvt_f32_f16 %0, %1" : "=v"(fb) : "v"(b));
+    const float d0 = (x0 - fa) * PP_NU_LO_SCALE, d1 = (x1 - fb) * PP_NU_LO_SCALE;
+    asm("v_cvt_f16_f32 %0, %1" : "=v"(c) : "v"(d0));
+    asm("v_cvt_f16_f32 %0, %1" : "=v"(d) : "v"(d1));
+    asm("v_pack_b32_f16 %0, %1, %2" : "=v"(hp) : "v"(a), "v"(b));
+    asm("v_pack_b32_f16 %0, %1, %2" : "=v"(lp) : "v"(c), "v"(d));
+}
+// four consecutive features of one residue into an operand image
+__device__ __forceinline__ void publish4(_Float16 *hi, _Float16 *lo, int off, const nf4 &v) {
+    nu2 h, l;
+    unsigned h0, l0, h1, l1;
+    split2(v[0], v[1], h0, l0);
+    split2(v[2], v[3], h1, l1);
+    h[0] = h0; h[1] = h1; l[0] = l0; l[1] = l1;
+    *reinterpret_cast<nu2 *>(hi + off) = h;
+    *reinterpret_cast<nu2 *>(lo + off) = l;
+}
+// hidden activations: ReLU, saturated at the f16 maximum (one v_med3)
+__device__ __forceinline__ nf4 relu_sat(const nf4 &v) {
+    return nf4{__builtin_amdgcn_fmed3f(v[0], 0.f, 65504.f), __builtin_amdgcn_fmed3f(v[1], 0.f, 65504.f),
+               __builtin_amdgcn_fmed3f(v[2], 0.f, 65504.f), __builtin_amdgcn_fmed3f(v[3], 0.f, 65504.f)};
+}
+__device__ __forceinline__ float xsum_g(float v) {       // sum over the four lane groups g (lanes r, r+16, r+32, r+48)
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+// LayerNorm over the 128 features of residue r (16 here in 4 lanes x 4 registers, the rest in the other waves): per-wave
+// mean and centred sum of squares, the eight partials meet once in LDS and merge with Chan's update for equal counts.
+__device__ __forceinline__ nf4 ln128(float (*st)[16][2], int wv, int r, int g, const nf4 &x, const nf4 &gain, const nf4 &beta) {
+    const float mw = xsum_g((x[0] + x[1]) + (x[2] + x[3])) * (1.f / 16.f);
+    const nf4 d = x - mw;
+    const float qw = xsum_g(fmaf(d[0], d[0], d[1] * d[1]) + fmaf(d[2], d[2], d[3] * d[3]));
+    if (g == 0) *reinterpret_cast<nf2 *>(st[wv][r]) = nf2{mw, qw};
+    __syncthreads();
+    float m8[8], msum = 0.f, qsum = 0.f;
 #pragma unroll
-    for (int i = 0; i < 32; i++) {
-        const VN x = act[i];
-        a0 = vfma(w0.v[i], x, a0);
-        a1 = vfma(w1.v[i], x, a1);
-        a2 = vfma(w2.v[i], x, a2);
-        a3 = vfma(w3.v[i], x, a3);
-        if ((i & 3) == 3) { ACC_PIN(a0); ACC_PIN(a1); ACC_PIN(a2); ACC_PIN(a3); }
+    for (int v = 0; v < 8; v++) {
+        const nf2 t = *reinterpret_cast<const nf2 *>(st[v][r]);
+        m8[v] = t[0];
+        msum += t[0];
+        qsum += t[1];
     }
+    const float mean = msum * 0.125f;
+    float dm = 0.f;
+#pragma unroll
+    for (int v = 0; v < 8; v++) dm = fmaf(m8[v] - mean, m8[v] - mean, dm);
+    const float var = fmaf(16.f, dm, qsum) * (1.f / 128.f);
+    const float rstd = 1.f / sqrtf(var + 1e-5f);
+    return (x - mean) * rstd * gain + beta;
 }
 
-// message_inputs with the weights already in registers (wA, wC: this thread's K-quarter of column f; wP: of column f < 24).
-// refill_ptsT, if not null: the point weights of the NEXT call, fetched into wP as soon as it has been consumed.
-__device__ __forceinline__ void message_inputs_pre(Smem &sm, int &flip, const WSet &wA, const WSet &wC, WSet &wP,
-                                                   const float *refill_ptsT, float in_b, float pts_b, const float *frames,
-                                                   int n0, int N, float *pts, float *PA, float *PC) {
-    const int f = threadIdx.x & 127, ks = threadIdx.x >> 7;
-    const VN *h = sm.h + ks * 32;
-    VN *buf = sm.part[flip];
-    flip ^= 1;
-    buf[ks * 384 + f] = wdot<32>(wA, h, vn(0.f));
-    buf[ks * 384 + 128 + f] = wdot<32>(wC, h, vn(0.f));
-    if (f < 24) {
-        const VN up = wdot<32>(wP, h, vn(0.f));
-        buf[ks * 384 + 256 + f] = up;
-        if (refill_ptsT) wload<32>(wP, refill_ptsT, 24, f, ks * 32, up.g[0].x);
+// stage k: fetch slot k + NU_ND (if this wave owns it), then BODY on the operands of slot k (AK).  The scheduling barrier
+// keeps fetches and MFMAs in their stage; the empty asm on the accumulator keeps the (pure) MFMAs from sinking.
+#define NSTAGE_IF(k, OWN, ACCV, BODY)                                                                                  \
+    {                                                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        if constexpr ((k) + NU_ND < NLOAD) {                                                                           \
+            constexpr int nw_ = nu_slot_waves<LAST>((k) + NU_ND);                                                      \
+            if ((nw_ == 8 || wv < nw_) && ((k) + NU_ND < 46 || !LAST || embed_next || NU_X_NOPRED))                    \
+                gload_N(wq, (k) + NU_ND, AR[((k) + NU_ND) % NU_NRING]);                                                \
+        }                                                                                                              \
+        if (OWN) {                                                                                                     \
+            const AOpN &AK = AR[(k) % NU_NRING];                                                                       \
+            BODY;                                                                                                      \
+            asm volatile("" ::"v"(ACCV[0]));                                                                           \
+        }                                                                                                              \
     }
-    __syncthreads();
-    if (ks == 0) {
-        VN a = vadd(vadd(buf[f], buf[384 + f]), vadd(buf[768 + f], buf[1152 + f]));
-        store_rows(PA, 128, n0, N, f, vadd(a, vn(in_b)));
-    } else if (ks == 1) {
-        VN c = vadd(vadd(buf[128 + f], buf[512 + f]), vadd(buf[896 + f], buf[1280 + f]));
-        store_rows(PC, 128, n0, N, f, c);
-    } else if (ks == 2 && f < 24) {
-        VN p = vadd(vadd(buf[256 + f], buf[640 + f]), vadd(buf[1024 + f], buf[1408 + f]));
-        p = vadd(p, vn(pts_b));
-        sm.p[f] = p;
-        store_rows(pts, 48, n0, N, f, p);
-    }
-    __syncthreads();
-    if (threadIdx.x < 8 * NB) {            // (point q, residue i): p_glob = R p_loc + t
-        int q = threadIdx.x / NB, i = threadIdx.x % NB;
-        int n = n0 + i;
-        if (n < N) {
-            const float *fr = frames + (size_t)n * 12;
-            float x = vcomp(sm.p[3 * q], i), y = vcomp(sm.p[3 * q + 1], i), z = vcomp(sm.p[3 * q + 2], i);
-            for (int r = 0; r < 3; r++)
-                pts[(size_t)n * 48 + 24 + 3 * q + r] = (fr[3 * r] * x + fr[3 * r + 1] * y + fr[3 * r + 2] * z) + fr[9 + r];
+#define NSTAGE(k, ACCV, BODY) NSTAGE_IF(k, true, ACCV, BODY)
+// four stages = one 16-feature tile over a 128-deep input held in bh / bl
+#define NTILE4_IF(k0, OWN, cH, cL)                                     \
+    NSTAGE_IF((k0) + 0, OWN, cH, mm3(AK, bh[0], bl[0], cH, cL))        \
+    NSTAGE_IF((k0) + 1, OWN, cH, mm3(AK, bh[1], bl[1], cH, cL))        \
+    NSTAGE_IF((k0) + 2, OWN, cH, mm3(AK, bh[2], bl[2], cH, cL))        \
+    NSTAGE_IF((k0) + 3, OWN, cH, mm3(AK, bh[3], bl[3], cH, cL))
+#define NTILE4(k0, cH, cL) NTILE4_IF(k0, true, cH, cL)
+#define LDB4(HI, LO)                                                                  \
+    _Pragma("unroll") for (int ks_ = 0; ks_ < 4; ks_++) ldB(HI, LO, r * NU_S128 + 8 * g, ks_, bh[ks_], bl[ks_]);
+// FFN-out stage s: B operand of k-step s + 1 is requested first
+#define FOSTAGE(s)                                                                                   \
+    NSTAGE(20 + (s), cH, {                                                                           \
+        if constexpr ((s) + 1 < 16) ldB(sm.c_hi, sm.c_lo, r * NU_S512 + 8 * g, (s) + 1, fh[((s) + 1) & 1], fl[((s) + 1) & 1]); \
+        mm3(AK, fh[(s) & 1], fl[(s) & 1], cH, cL);                                                   \
+    })
+
+#ifdef PP_X_NU_NOPRED
+#define NU_X_NOPRED true
+#else
+#define NU_X_NOPRED false
+#endif
+template <int MODE>
+__global__ void __launch_bounds__(512)
+k_node_update(NUpdArgs A, float *chi, int step, int sde, const float *noise, int embed_next) {
+    constexpr bool LAST = MODE != PP_NU_MID;
+    constexpr int NSLOT = LAST ? PP_NU_SLOTS_LAST : PP_NU_SLOTS_MID;
+    constexpr int NLOAD = MODE == PP_NU_SCORE ? 46 : NSLOT;       // slots this instance ever fetches
+    constexpr int NPAR = LAST ? NU_P_LAST_TOTAL : NU_P_MID_TOTAL;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    SmemU &sm = *reinterpret_cast<SmemU *>(smem_raw);
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, g = lane >> 4, N = A.N, n0 = blockIdx.x * 16;
+    const int n = n0 + r, nc = n < N ? n : N - 1;
+    const bool live = n < N;
+    const int fc = 16 * wv + 4 * g;            // first of this lane's four features in a 128-wide vector
+    const float *par = sm.par;
+
+    // ---- inputs first: they are waited for before the weight stream's loads (vmcnt retires in order) ------------
+    const int srow = tid >> 5, scol = (tid & 31) * 4, sn = n0 + srow < N ? n0 + srow : N - 1;
+    const nf4 s4 = *reinterpret_cast<const nf4 *>(A.S + (size_t)sn * 128 + scol);
+    const nf4 hv4 = *reinterpret_cast<const nf4 *>(A.hV + (size_t)nc * 128 + fc);
+    const float ms = A.msum[nc], rm = A.rmask[nc];
+    nf4 chi4 = {0.f, 0.f, 0.f, 0.f}, scm4 = chi4, nz1 = chi4, nz2 = chi4;
+    unsigned m1 = 0, m2 = 0;
+    int rt = 0;
+    float bb[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    nf4 spv = chi4;                            // c_ode, w, c_drift, c_diff of this step
+    if constexpr (MODE == PP_NU_STEP) {
+        if (wv == 0 && g == 0) {
+            spv = *reinterpret_cast<const nf4 *>(&A.steps[step].c_ode);
+            chi4 = *reinterpret_cast<const nf4 *>(chi + (size_t)nc * 4);
+            scm4 = *reinterpret_cast<const nf4 *>(A.sc_mask + (size_t)nc * 4);
+            m1 = *reinterpret_cast<const unsigned *>(A.m1pi + (size_t)nc * 4);
+            m2 = *reinterpret_cast<const unsigned *>(A.m2pi + (size_t)nc * 4);
+            if (sde) {
+                const size_t NN = (size_t)N * 4;
+                const float *nz = noise + (size_t)step * 2 * NN + (size_t)nc * 4;
+                nz1 = *reinterpret_cast<const nf4 *>(nz);
+                nz2 = *reinterpret_cast<const nf4 *>(nz + NN);
+            }
+        }
+        if (embed_next) {
+            rt = (int)A.rtype[nc];
+            const nf2 *bp = reinterpret_cast<const nf2 *>(A.bb_sincos + (size_t)nc * 6);
+            const nf2 b0 = bp[0], b1 = bp[1], b2 = bp[2];
+            bb[0] = b0[0]; bb[1] = b0[1]; bb[2] = b1[0]; bb[3] = b1[1]; bb[4] = b2[0]; bb[5] = b2[1];
         }
     }
+    constexpr int NPV = (NPAR / 4 + 511) / 512;
+    nf4 pv[NPV];
+#pragma unroll
+    for (int i = 0; i < NPV; i++) {
+        const int q = tid + 512 * i;
+        pv[i] = reinterpret_cast<const nf4 *>(A.params)[q < NPAR / 4 ? q : 0];
+    }
+    // ---- start the weight stream ---------------------------------------------------------------------------------
+    const nh8 *wq = reinterpret_cast<const nh8 *>(A.wstream) + (size_t)wv * NSLOT * 128 + lane;
+    AOpN AR[NU_NRING];
+#pragma unroll
+    for (int k = 0; k < NU_ND; k++) gload_N(wq, k, AR[k]);
+    __builtin_amdgcn_sched_barrier(0);       // the stream is on its way before anything waits for the inputs
+#pragma unroll
+    for (int i = 0; i < NPV; i++) {
+        const int q = tid + 512 * i;
+        if (q < NPAR / 4) reinterpret_cast<nf4 *>(sm.par)[q] = pv[i];
+    }
+    publish4(sm.a_hi, sm.a_lo, srow * NU_S128 + scol, s4);
     __syncthreads();
-}
 
-// LAST_MODE is a template parameter so that the middle-layer variant (two of three launches) gets its own register
-// allocation: as one function the decoder / step / embedding tail cost it ~30 spilled registers.
-template <int LAST_MODE>
-__global__ void __launch_bounds__(NT)
-k_node_update(NodeArgs A, UpdW W, float *chi, int step, int sde, const float *noise, int embed_next, PreW pre0) {
-    constexpr int last_mode = LAST_MODE;
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    Smem &sm = *reinterpret_cast<Smem *>(smem_raw);
-    int flip = 0, rflip = 0;
-    const int t = threadIdx.x, f = t & 127, ks = t >> 7, n0 = blockIdx.x * NB, N = A.N;
-    const int kq = ks * 32;                  // this thread's quarter of a 128-deep reduction
-    constexpr bool mid = last_mode == PP_NU_MID;
-    WSet wa, wb, wc, wd, we;
-    wload<32>(wa, W.outT, 128, f, kq, 0.f);
-    wload<32>(wb, W.ffn_inT, 512, f, kq, 0.f);            // FFN-in, half 0: units f and f + 128
-    wload<32>(wc, W.ffn_inT, 512, f + 128, kq, 0.f);
-    // per-feature vectors and row inputs, all up front
-    const float out_b = W.out_b[f], g0 = W.g0[f], b0 = W.b0[f], g1 = W.g1[f], b1 = W.b1[f], ffn_out_b = W.ffn_out_b[f];
-    const float fib = W.ffn_in_b[t];
-    const VN ms = load_rows(A.msum, 1, n0, N, 0);
-    const VN hv = load_rows(A.hV, 128, n0, N, f);
-    const VN rm = load_rows(A.rmask, 1, n0, N, 0);
-    if (ks == 0) sm.a[f] = load_rows(A.S, 128, n0, N, f);
+    nf4 eacc = {0.f, 0.f, 0.f, 0.f}, etime = eacc;
+    nh8 bh[4], bl[4];
+    nf4 cH, cL;
+    const nf4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    // ---- W_out on the masked mean S: mean_j mask_j (W_out y_j + b) = W_out mean_j(mask_j y_j) + b mean_j(mask_j) -----
+    LDB4(sm.a_hi, sm.a_lo)
+    cH = zero4; cL = zero4;
+    NTILE4(0, cH, cL)
+    nf4 x = fold(cH, cL) + *reinterpret_cast<const nf4 *>(par + NU_P_OUTB + fc) * ms + hv4;
+    const nf4 h1 = ln128(sm.stats[0], wv, r, g, x, *reinterpret_cast<const nf4 *>(par + NU_P_G0 + fc),
+                         *reinterpret_cast<const nf4 *>(par + NU_P_B0 + fc));
+    publish4(sm.b_hi, sm.b_lo, r * NU_S128 + fc, h1);
     __syncthreads();
-    // mean_j mask_j (W_out y_j + b) = W_out mean_j(mask_j y_j) + b mean_j(mask_j)
-    VN part = wdot<32>(wa, sm.a + kq, vn(0.f));
-    wload<32>(wa, W.ffn_inT, 512, 256 + f, kq, part.g[0].x);           // FFN-in, units f + 256, f + 384
-    wload<32>(wd, W.ffn_inT, 512, 256 + f + 128, kq, part.g[0].x);
-    VN m = meet(sm, flip, part, 128, f, ks);
-    m = vadd(m, vscale(ms, out_b));
-#if defined(PP_X_NU_STOP) && PP_X_NU_STOP == 1
-    return;
-#endif
-    VN h1 = layernorm(sm, rflip, vadd(hv, m), g0, b0);
-    if (ks == 0) sm.h[f] = h1;
+    // ---- FFN 128 -> 512: hidden tiles 4 w .. 4 w + 3 ----------------------------------------------------------------
+    LDB4(sm.b_hi, sm.b_lo)
+#define FFN_IN_TILE(c)                                                                                     \
+    cH = zero4; cL = zero4;                                                                                \
+    NTILE4(4 + 4 * (c), cH, cL)                                                                            \
+    publish4(sm.c_hi, sm.c_lo, r * NU_S512 + 16 * (4 * wv + (c)) + 4 * g,                                  \
+             relu_sat(fold(cH, cL) + *reinterpret_cast<const nf4 *>(par + NU_P_FIB + 16 * (4 * wv + (c)) + 4 * g)));
+    FFN_IN_TILE(0) FFN_IN_TILE(1) FFN_IN_TILE(2) FFN_IN_TILE(3)
     __syncthreads();
-#if defined(PP_X_NU_STOP) && PP_X_NU_STOP == 2
-    return;
-#endif
-    // FFN 128 -> 512: thread (f, ks) builds the ks-th K-quarter of hidden units f, f+128, f+256, f+384 in one pass
-    // over h1, then every thread owns one hidden unit
-    {
-        VN *buf = sm.part[flip];
-        flip ^= 1;
-        VN u0 = vn(0.f), u1 = vn(0.f), u2 = vn(0.f), u3 = vn(0.f);
-        wdot4(wb, wc, wa, wd, sm.h + kq, u0, u1, u2, u3);
-        buf[ks * 512 + f] = u0;
-        buf[ks * 512 + f + 128] = u1;
-        buf[ks * 512 + f + 256] = u2;
-        buf[ks * 512 + f + 384] = u3;
-        wload<32>(wb, W.ffn_outT, 128, f, ks * 128, u0.g[0].x);       // FFN-out: this thread's 128 inputs in four sets
-        wload<32>(wc, W.ffn_outT, 128, f, ks * 128 + 32, u1.g[0].x);
-        wload<32>(wa, W.ffn_outT, 128, f, ks * 128 + 64, u2.g[0].x);
-        wload<32>(wd, W.ffn_outT, 128, f, ks * 128 + 96, u3.g[0].x);
-        __syncthreads();
-        VN hd = vadd(vadd(buf[t], buf[512 + t]), vadd(buf[1024 + t], buf[1536 + t]));
-        sm.a[t] = vrelu(vadd(hd, vn(fib)));
-    }
+    // ---- FFN 512 -> 128, LayerNorm, mask ------------------------------------------------------------------------------
+    nh8 fh[2], fl[2];
+    ldB(sm.c_hi, sm.c_lo, r * NU_S512 + 8 * g, 0, fh[0], fl[0]);
+    cH = zero4; cL = zero4;
+    FOSTAGE(0) FOSTAGE(1) FOSTAGE(2) FOSTAGE(3) FOSTAGE(4) FOSTAGE(5) FOSTAGE(6) FOSTAGE(7)
+    FOSTAGE(8) FOSTAGE(9) FOSTAGE(10) FOSTAGE(11) FOSTAGE(12) FOSTAGE(13) FOSTAGE(14) FOSTAGE(15)
+    x = fold(cH, cL) + *reinterpret_cast<const nf4 *>(par + NU_P_FOB + fc) + h1;
+    const nf4 h2 = ln128(sm.stats[1], wv, r, g, x, *reinterpret_cast<const nf4 *>(par + NU_P_G1 + fc),
+                         *reinterpret_cast<const nf4 *>(par + NU_P_B1 + fc)) * rm;
+    if (live && (MODE != PP_NU_STEP || !embed_next)) *reinterpret_cast<nf4 *>(A.hV + (size_t)n * 128 + fc) = h2;
+    publish4(sm.a_hi, sm.a_lo, r * NU_S128 + fc, h2);
     __syncthreads();
-#if defined(PP_X_NU_STOP) && PP_X_NU_STOP == 3
-    return;
-#endif
-    part = wdot<32>(wb, sm.a + ks * 128, vn(0.f));
-    part = wdot<32>(wc, sm.a + ks * 128 + 32, part);
-    part = wdot<32>(wa, sm.a + ks * 128 + 64, part);
-    part = wdot<32>(wd, sm.a + ks * 128 + 96, part);
-    // next phase's weights: the two message functions (middle layers) / decoder + next embedding (last layer)
-    float in_b_1, pts_b_1 = 0.f, in_b_2 = 0.f, pts_b_2 = 0.f;
-    float db0 = 0.f, db1 = 0.f, db2 = 0.f, db3 = 0.f;
-    if constexpr (mid) {
-        const float tk = part.g[0].x;
-        wload<32>(wb, W.pre_edge.AT, 128, f, kq, tk);
-        wload<32>(wc, W.pre_edge.CT, 128, f, kq, tk);
-        // point weights: threads f < 24 take the edge message's column f, threads 32 <= f < 56 the next node message's
-        // column f - 32, so one register set serves both and nothing is fetched between the two dot products
-        if (f < 24) { wload<32>(we, W.pre_edge.ptsT, 24, f, kq, tk); pts_b_1 = W.pre_edge.pts_b[f]; pts_b_2 = W.pre_next.pts_b[f]; }
-        else if (f >= 32 && f < 56) wload<32>(we, W.pre_next.ptsT, 24, f - 32, kq, tk);
-        wload<32>(wa, W.pre_next.AT, 128, f, kq, tk);
-        wload<32>(wd, W.pre_next.CT, 128, f, kq, tk);
-        in_b_1 = W.pre_edge.in_b[f];
-        in_b_2 = W.pre_next.in_b[f];
-    } else {
-        // decoder 128 -> 64 -> 32 -> 16 -> 4: K-quarters of 32 / 16 / 8 / 4 inputs
-        const float tk = part.g[0].x;
-        if (f < 64) { wload<32>(wb, W.d0_inT, 64, f, kq, tk); db0 = W.d0_in_b[f]; }
-        if (f < 32) { wload<16, 0>(wc, W.d0_outT, 32, f, ks * 16, tk); db1 = W.d0_out_b[f]; }
-        if (f < 16) { wload<8, 16>(wc, W.d2_inT, 16, f, ks * 8, tk); db2 = W.d2_in_b[f]; }
-        if (f < 4) { wload<4, 24>(wc, W.d2_outT, 4, f, ks * 4, tk); db3 = W.d2_out_b[f]; }
-        wload<32>(wa, pre0.AT, 128, f, kq, tk);
-        wload<32>(wd, pre0.CT, 128, f, kq, tk);
-        if (f < 24) { wload<32>(we, pre0.ptsT, 24, f, kq, tk); pts_b_1 = pre0.pts_b[f]; }
-        in_b_1 = pre0.in_b[f];
-    }
-    VN o = meet(sm, flip, part, 128, f, ks);
-    o = vadd(o, vn(ffn_out_b));
-#if defined(PP_X_NU_STOP) && PP_X_NU_STOP == 4
-    return;
-#endif
-    VN h2 = layernorm(sm, rflip, vadd(h1, o), g1, b1);
-    h2 = vmul(h2, rm);
-    if (ks == 0) {
-        store_rows(A.hV, 128, n0, N, f, h2);
-        sm.h[f] = h2;
-    }
-    __syncthreads();
-#if defined(PP_X_NU_STOP) && PP_X_NU_STOP == 5
-    return;
-#endif
-#if defined(PP_X_NU_STOP) && PP_X_NU_STOP == 6
-    if (!mid) return;
-#endif
-    if constexpr (mid) {
-        // inputs of this layer's edge message and of the next layer's node message in one pass over h2:
-        // columns PAe 0..127 | PCe 128..255 | PAn 256..383 | PCn 384..511 | ptsE 512..535 | ptsN 536..559
-        VN *buf = sm.part[flip];
-        flip ^= 1;
-        VN u0 = vn(0.f), u1 = vn(0.f), u2 = vn(0.f), u3 = vn(0.f);
-        wdot4(wb, wc, wa, wd, sm.h + kq, u0, u1, u2, u3);
-        buf[ks * 576 + f] = u0;
-        buf[ks * 576 + 128 + f] = u1;
-        buf[ks * 576 + 256 + f] = u2;
-        buf[ks * 576 + 384 + f] = u3;
-        if (f < 24) buf[ks * 576 + 512 + f] = wdot<32>(we, sm.h + kq, vn(0.f));
-        else if (f >= 32 && f < 56) buf[ks * 576 + 536 + (f - 32)] = wdot<32>(we, sm.h + kq, vn(0.f));
-        __syncthreads();
-        {
-            const int c = ks * 128 + f;           // ks-group 0: PAe, 1: PCe, 2: PAn, 3: PCn
-            VN a = vadd(vadd(buf[c], buf[576 + c]), vadd(buf[1152 + c], buf[1728 + c]));
-            if (ks == 0) store_rows(A.PAe, 128, n0, N, f, vadd(a, vn(in_b_1)));
-            else if (ks == 1) store_rows(A.PCe, 128, n0, N, f, a);
-            else if (ks == 2) store_rows(A.PAn, 128, n0, N, f, vadd(a, vn(in_b_2)));
-            else store_rows(A.PCn, 128, n0, N, f, a);
-            if (ks < 2 && f < 24) {               // local points: ks-group 0 -> edge message, 1 -> next node message
-                const int pc = 512 + 24 * ks + f;
-                VN pl = vadd(vadd(buf[pc], buf[576 + pc]), vadd(buf[1152 + pc], buf[1728 + pc]));
-                pl = vadd(pl, vn(ks == 0 ? pts_b_1 : pts_b_2));
-                sm.p[24 * ks + f] = pl;
-                store_rows(ks == 0 ? A.ptsE : A.ptsN, 48, n0, N, f, pl);
+    LDB4(sm.a_hi, sm.a_lo)
+
+    if constexpr (!LAST) {
+        // ---- inputs of this layer's edge message and of the next layer's node message ----------------------------------
+        cH = zero4; cL = zero4;
+        NTILE4(36, cH, cL)
+        if (live) *reinterpret_cast<nf4 *>(A.PAe + (size_t)n * 128 + fc) = fold(cH, cL) + *reinterpret_cast<const nf4 *>(par + NU_P_PAE_B + fc);
+        cH = zero4; cL = zero4;
+        NTILE4(40, cH, cL)
+        if (live) *reinterpret_cast<nf4 *>(A.PCe + (size_t)n * 128 + fc) = fold(cH, cL);
+        cH = zero4; cL = zero4;
+        NTILE4(44, cH, cL)
+        if (live) *reinterpret_cast<nf4 *>(A.PAn + (size_t)n * 128 + fc) = fold(cH, cL) + *reinterpret_cast<const nf4 *>(par + NU_P_PAN_B + fc);
+        cH = zero4; cL = zero4;
+        NTILE4(48, cH, cL)
+        if (live) *reinterpret_cast<nf4 *>(A.PCn + (size_t)n * 128 + fc) = fold(cH, cL);
+        cH = zero4; cL = zero4;
+        NTILE4_IF(52, wv < 3, cH, cL)
+        if (wv < 3) {              // local points: features 0..23 edge message, 24..47 next node message
+            const nf4 p = fold(cH, cL) + *reinterpret_cast<const nf4 *>(par + NU_P_PTS_B + fc);
+            *reinterpret_cast<nf4 *>(&sm.pts[r][fc]) = p;
+            if (live) {
+                if (fc < 24) *reinterpret_cast<nf4 *>(A.ptsE + (size_t)n * 48 + fc) = p;
+                else *reinterpret_cast<nf4 *>(A.ptsN + (size_t)n * 48 + fc - 24) = p;
             }
         }
         __syncthreads();
-        if (t < 16 * NB) {                        // (message m, point q, residue i): p_glob = R p_loc + t
-            const int mm = t / (8 * NB), q = (t / NB) & 7, i = t % NB;
-            const int n = n0 + i;
-            if (n < N) {
+        if (tid < 256) {           // (message m, point q, residue i): p_glob = R p_loc + t
+            const int mm = tid >> 7, q = (tid >> 4) & 7, i = tid & 15, ni = n0 + i;
+            if (ni < N) {
                 float *pts = mm == 0 ? A.ptsE : A.ptsN;
-                const float *fr = A.frames + (size_t)n * 12;
-                const float x = vcomp(sm.p[24 * mm + 3 * q], i), y = vcomp(sm.p[24 * mm + 3 * q + 1], i),
-                            z = vcomp(sm.p[24 * mm + 3 * q + 2], i);
-                for (int r = 0; r < 3; r++)
-                    pts[(size_t)n * 48 + 24 + 3 * q + r] = (fr[3 * r] * x + fr[3 * r + 1] * y + fr[3 * r + 2] * z) + fr[9 + r];
+                const float *fr = A.frames + (size_t)ni * 12;
+                const float px = sm.pts[i][24 * mm + 3 * q], py = sm.pts[i][24 * mm + 3 * q + 1], pz = sm.pts[i][24 * mm + 3 * q + 2];
+#pragma unroll
+                for (int rr = 0; rr < 3; rr++)
+                    pts[(size_t)ni * 48 + 24 + 3 * q + rr] = (fr[3 * rr] * px + fr[3 * rr + 1] * py + fr[3 * rr + 2] * pz) + fr[9 + rr];
             }
         }
         return;
-    }
-    // decoder: 128 -> 64 -> 32 -> relu -> 16 -> 4 (weights in wb / wc)
-    VN v;
-    {
-        VN pp = f < 64 ? wdot<32>(wb, sm.h + kq, vn(0.f)) : vn(0.f);
-        // wb is free: the next embedding's 30 dense rows (14 angle features + 16 time features)
-        if (embed_next) {
-            int off = 21 * 128 + f;
-            asm volatile("" : "+v"(off) : "v"(pp.g[0].x));
-#pragma unroll
-            for (int i = 0; i < 30; i++) wb.v[i] = A.embT[off + i * 128];
-            wb.v[30] = A.emb_b[f];
+    } else {
+        // ---- decoder 128 -> 64 -> 32 -> relu -> 16 -> 4 (TorsionalDiffusion.py:105-109) --------------------------------
+        cH = zero4; cL = zero4;
+        NTILE4_IF(36, wv < 4, cH, cL)
+        if (wv < 4) {
+            publish4(sm.c_hi, sm.c_lo, r * NU_S512 + fc, relu_sat(fold(cH, cL) + *reinterpret_cast<const nf4 *>(par + NU_P_DB0 + fc)));
         }
-        VN r = meet(sm, flip, pp, 128, f, ks);
-        v = f < 64 ? vrelu(vadd(r, vn(db0))) : vn(0.f);
-    }
-    if (ks == 0 && f < 64) sm.a[f] = v;
-    __syncthreads();
-    {
-        VN pp = f < 32 ? wdot<16, 0>(wc, sm.a + ks * 16, vn(0.f)) : vn(0.f);
-        VN r = meet(sm, flip, pp, 128, f, ks);
-        v = f < 32 ? vrelu(vadd(r, vn(db1))) : vn(0.f);
-    }
-    if (ks == 0 && f < 32) sm.a[64 + f] = v;
-    __syncthreads();
-    {
-        VN pp = f < 16 ? wdot<8, 16>(wc, sm.a + 64 + ks * 8, vn(0.f)) : vn(0.f);
-        VN r = meet(sm, flip, pp, 128, f, ks);
-        v = f < 16 ? vrelu(vadd(r, vn(db2))) : vn(0.f);
-    }
-    if (ks == 0 && f < 16) sm.a[96 + f] = v;
-    __syncthreads();
-    {
-        VN pp = f < 4 ? wdot<4, 24>(wc, sm.a + 96 + ks * 4, vn(0.f)) : vn(0.f);
-        VN r = meet(sm, flip, pp, 128, f, ks);
-        v = f < 4 ? vadd(r, vn(db3)) : vn(0.f);
-    }
-    if (ks == 0 && f < 4) {
-        sm.a[112 + f] = v;
-        store_rows(A.score, 4, n0, N, f, v);
-    }
-    __syncthreads();
-    if constexpr (last_mode != PP_NU_STEP) return;
-    // reverse step on (residue i, chi k) = 4 NB threads
-    if (t < 4 * NB) {
-        int i = t >> 2, k = t & 3, n = n0 + i;
-        if (n < N) {
-            const StepParams &sp = A.steps[step];
-            float x = chi[(size_t)n * 4 + k];
-            float sw = vcomp(sm.a[112 + k], i) * sp.w;
-            bool m1 = A.m1pi[(size_t)n * 4 + k] != 0, m2 = A.m2pi[(size_t)n * 4 + k] != 0;
-            float y = x;
-            if (!sde) {
-                if (m1 || m2) y = x + sp.c_ode * sw;
-            } else {
-                size_t NN = (size_t)N * 4;
-                const float *nz = noise + (size_t)step * 2 * NN;
-                if (m1) y = x + (sp.c_drift * sw + sp.c_diff * nz[(size_t)n * 4 + k]);
-                if (m2) y = y + (sp.c_drift * sw + sp.c_diff * nz[NN + (size_t)n * 4 + k]);
+        __syncthreads();
+        // the rest of the decoder is one wave's work: 64 -> 32 (two tiles), 32 -> 16, 16 -> 4; activations go through
+        // columns 64..127 of the same image (a wave's LDS operations execute in order; the asm is the compiler fence).
+        // The other waves only keep their weight stream going (the stages' fetches) and wait at the next barrier.
+        const bool w0 = wv == 0;
+        {
+            nh8 dh[2], dl[2];
+            if (w0) {
+                ldB(sm.c_hi, sm.c_lo, r * NU_S512 + 8 * g, 0, dh[0], dl[0]);
+                ldB(sm.c_hi, sm.c_lo, r * NU_S512 + 8 * g, 1, dh[1], dl[1]);
             }
-            y = wrap_pi(y) * A.sc_mask[(size_t)n * 4 + k];
-            chi[(size_t)n * 4 + k] = y;
+            nf4 eH = zero4, eL = zero4;
+            cH = zero4; cL = zero4;
+            NSTAGE_IF(40, w0, cH, mm3(AK, dh[0], dl[0], cH, cL))
+            NSTAGE_IF(41, w0, cH, mm3(AK, dh[1], dl[1], cH, cL))
+            NSTAGE_IF(42, w0, eH, mm3(AK, dh[0], dl[0], eH, eL))
+            NSTAGE_IF(43, w0, eH, mm3(AK, dh[1], dl[1], eH, eL))
+            if (w0) {
+                publish4(sm.c_hi, sm.c_lo, r * NU_S512 + 64 + 4 * g, relu_sat(fold(cH, cL) + *reinterpret_cast<const nf4 *>(par + NU_P_DB1 + 4 * g)));
+                publish4(sm.c_hi, sm.c_lo, r * NU_S512 + 80 + 4 * g, relu_sat(fold(eH, eL) + *reinterpret_cast<const nf4 *>(par + NU_P_DB1 + 16 + 4 * g)));
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                ldB(sm.c_hi, sm.c_lo, r * NU_S512 + 8 * g, 2, dh[0], dl[0]);
+            }
+            cH = zero4; cL = zero4;
+            NSTAGE_IF(44, w0, cH, mm3(AK, dh[0], dl[0], cH, cL))
+            if (w0) {
+                publish4(sm.c_hi, sm.c_lo, r * NU_S512 + 96 + 4 * g, relu_sat(fold(cH, cL) + *reinterpret_cast<const nf4 *>(par + NU_P_DB2 + 4 * g)));
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                ldB(sm.c_hi, sm.c_lo, r * NU_S512 + 8 * g, 3, dh[0], dl[0]);      // columns 112..127: stale but finite, zero weights
+            }
+            cH = zero4; cL = zero4;
+            NSTAGE_IF(45, w0, cH, mm3(AK, dh[0], dl[0], cH, cL))
         }
-    }
-    __syncthreads();
-    if (!embed_next) return;
-    // next step's node embedding (embed_pre with the dense rows already in wb)
-    {
-        if (t < 6) sm.p[t] = load_rows(A.bb_sincos, 6, n0, N, t);
-        else if (t < 14) {
-            int k = (t - 6) >> 1, sc = (t - 6) & 1;
-            VN x = load_rows(chi, 4, n0, N, k), mk = load_rows(A.sc_mask, 4, n0, N, k), sv;
-            VN_FOR sv.g[gi] = sc ? f4v{cosf(x.g[gi].x), cosf(x.g[gi].y), cosf(x.g[gi].z), cosf(x.g[gi].w)}
-                                 : f4v{sinf(x.g[gi].x), sinf(x.g[gi].y), sinf(x.g[gi].z), sinf(x.g[gi].w)};
-            sm.p[t] = vmul(sv, mk);
+        if (w0) {
+            if (g == 0) {          // registers 0..3 of lane group 0 = the four scores of residue r
+                const nf4 sc = fold(cH, cL) + *reinterpret_cast<const nf4 *>(par + NU_P_DB3);
+                if (live) *reinterpret_cast<nf4 *>(A.score + (size_t)n * 4) = sc;
+                if constexpr (MODE == PP_NU_STEP) {
+                    // reverse step (schedule.py:198-235 with the two periodicity masks, TorsionalDiffusion.py:268-280)
+                    const float sp_c_ode = spv[0], sp_w = spv[1], sp_c_drift = spv[2], sp_c_diff = spv[3];
+                    nf4 y;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const bool p1 = (m1 >> (8 * k)) & 0xffu, p2 = (m2 >> (8 * k)) & 0xffu;
+                        const float sw = sc[k] * sp_w;
+                        float yk = chi4[k];
+                        if (!sde) {
+                            if (p1 || p2) yk = chi4[k] + sp_c_ode * sw;
+                        } else {
+                            if (p1) yk = chi4[k] + (sp_c_drift * sw + sp_c_diff * nz1[k]);
+                            if (p2) yk = yk + (sp_c_drift * sw + sp_c_diff * nz2[k]);
+                        }
+                        y[k] = wrap_pi(yk) * scm4[k];
+                    }
+                    if (live) *reinterpret_cast<nf4 *>(chi + (size_t)n * 4) = y;
+                    if (embed_next) {
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            sm.sc[r][2 * k] = sinf(y[k]) * scm4[k];
+                            sm.sc[r][2 * k + 1] = cosf(y[k]) * scm4[k];
+                        }
+                    }
+                }
+            }
         }
-        VN acc = vn(wb.v[30]);
-        VN_FOR {
-            const int b = n0 + 4 * gi;
-            const int t0 = b + 0 < N ? (int)A.rtype[b + 0] : 0, t1 = b + 1 < N ? (int)A.rtype[b + 1] : 0;
-            const int t2 = b + 2 < N ? (int)A.rtype[b + 2] : 0, t3 = b + 3 < N ? (int)A.rtype[b + 3] : 0;
-            acc.g[gi].x += A.embT[t0 * 128 + f]; acc.g[gi].y += A.embT[t1 * 128 + f];
-            acc.g[gi].z += A.embT[t2 * 128 + f]; acc.g[gi].w += A.embT[t3 * 128 + f];
+        if constexpr (MODE != PP_NU_STEP) return;
+        if (!embed_next) return;
+        __syncthreads();
+        // ---- next step's node embedding (encoder.py:218-242) and the layer-0 node-message inputs ---------------------
+        // (Computing the chi-independent part of this sum early, in the shadow of the first weight fetches, made sampling
+        // irreproducible from run to run -- results differed in a few residues, more often with a shallower prefetch ring;
+        // tools/debug/nu_repro2.py, 100/100 runs at L = 400 against 0/200 with the sum placed here.  The cause was not
+        // found in the ISA; test_sampling_is_bit_reproducible guards the placement.)
+        {
+            const nf4 oh4 = *reinterpret_cast<const nf4 *>(A.embT + (size_t)rt * 128 + fc);
+            eacc = *reinterpret_cast<const nf4 *>(par + NU_P_EMB_B + fc) + oh4;
+#pragma unroll
+            for (int k = 0; k < 6; k++) {
+                const nf4 wk = *reinterpret_cast<const nf4 *>(par + NU_P_EMBT + k * 128 + fc);
+                eacc = nf4{fmaf(wk[0], bb[k], eacc[0]), fmaf(wk[1], bb[k], eacc[1]), fmaf(wk[2], bb[k], eacc[2]), fmaf(wk[3], bb[k], eacc[3])};
+            }
+            const float *te = A.steps[step + 1].temb;
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const nf4 wk = *reinterpret_cast<const nf4 *>(par + NU_P_EMBT + (14 + k) * 128 + fc);
+                const float tk = te[k];
+                etime = nf4{fmaf(wk[0], tk, etime[0]), fmaf(wk[1], tk, etime[1]), fmaf(wk[2], tk, etime[2]), fmaf(wk[3], tk, etime[3])};
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const nf4 wk = *reinterpret_cast<const nf4 *>(par + NU_P_EMBT + (6 + k) * 128 + fc);
+            const float sk = sm.sc[r][k];
+            eacc = nf4{fmaf(wk[0], sk, eacc[0]), fmaf(wk[1], sk, eacc[1]), fmaf(wk[2], sk, eacc[2]), fmaf(wk[3], sk, eacc[3])};
+        }
+        const nf4 h0 = ln128(sm.stats[2], wv, r, g, eacc + etime, *reinterpret_cast<const nf4 *>(par + NU_P_EMB_G + fc),
+                             *reinterpret_cast<const nf4 *>(par + NU_P_EMB_BETA + fc));
+        if (live) *reinterpret_cast<nf4 *>(A.hV + (size_t)n * 128 + fc) = h0;
+        publish4(sm.b_hi, sm.b_lo, r * NU_S128 + fc, h0);
+        __syncthreads();
+        LDB4(sm.b_hi, sm.b_lo)
+        cH = zero4; cL = zero4;
+        NTILE4(46, cH, cL)
+        if (live) *reinterpret_cast<nf4 *>(A.PAn + (size_t)n * 128 + fc) = fold(cH, cL) + *reinterpret_cast<const nf4 *>(par + NU_P_PAN0_B + fc);
+        cH = zero4; cL = zero4;
+        NTILE4(50, cH, cL)
+        if (live) *reinterpret_cast<nf4 *>(A.PCn + (size_t)n * 128 + fc) = fold(cH, cL);
+        if (wv < 2) {
+            cH = zero4; cL = zero4;
+            NTILE4(54, cH, cL)
+            if (fc < 24) {
+                const nf4 p = fold(cH, cL) + *reinterpret_cast<const nf4 *>(par + NU_P_PTS0_B + fc);
+                *reinterpret_cast<nf4 *>(&sm.pts[r][fc]) = p;
+                if (live) *reinterpret_cast<nf4 *>(A.ptsN + (size_t)n * 48 + fc) = p;
+            }
         }
         __syncthreads();
+        if (tid < 128) {
+            const int q = tid >> 4, i = tid & 15, ni = n0 + i;
+            if (ni < N) {
+                const float *fr = A.frames + (size_t)ni * 12;
+                const float px = sm.pts[i][3 * q], py = sm.pts[i][3 * q + 1], pz = sm.pts[i][3 * q + 2];
 #pragma unroll
-        for (int k = 0; k < 14; k++) acc = vfma(wb.v[k], sm.p[k], acc);
-        const float *te = A.steps[step + 1].temb;
-        float tacc = 0.f;
-#pragma unroll
-        for (int k = 0; k < 16; k++) tacc = fmaf(wb.v[14 + k], te[k], tacc);
-        VN e = vadd(acc, vn(tacc));
-        VN h = layernorm(sm, rflip, e, A.emb_g[f], A.emb_beta[f]);
-        if (ks == 0) {
-            store_rows(A.hV, 128, n0, N, f, h);
-            sm.h[f] = h;
+                for (int rr = 0; rr < 3; rr++)
+                    A.ptsN[(size_t)ni * 48 + 24 + 3 * q + rr] = (fr[3 * rr] * px + fr[3 * rr + 1] * py + fr[3 * rr + 2] * pz) + fr[9 + rr];
+            }
         }
-        __syncthreads();
     }
-    message_inputs_pre(sm, flip, wa, wd, we, nullptr, in_b_1, pts_b_1, A.frames, n0, N, A.ptsN, A.PAn, A.PCn);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -680,11 +783,11 @@ static pp_status node_attrs() {
         PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_node_embed),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Smem)));
         PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_node_update<PP_NU_MID>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Smem)));
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SmemU)));
         PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_node_update<PP_NU_STEP>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Smem)));
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SmemU)));
         PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_node_update<PP_NU_SCORE>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Smem)));
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SmemU)));
         done = true;
     }
     return PP_OK;
@@ -704,33 +807,45 @@ pp_status pp_launch_node_update(pp_ctx *c, int layer, int last_mode, float *chi,
                                 const float *noise, bool embed_next_step, hipStream_t s) {
     pp_status st0 = node_attrs();
     if (st0 != PP_OK) return st0;
+    if ((last_mode == PP_NU_MID) != (layer < 2)) {
+        pp_set_error("pp_launch_node_update: layers 0 and 1 are middle layers, layer 2 is the last one");
+        return PP_ERR_INVALID;
+    }
     const pp_plan *p = c->plan;
-    const LayerOff &o = p->off.layer[layer];
     const LayerT &t = p->lt[layer];
-    NodeArgs A = make_args(c);
-    UpdW W;
-    W.outT = t.nm_out_T; W.out_b = p->w + o.nm_out_b;
-    W.g0 = p->w + o.norm_g[0]; W.b0 = p->w + o.norm_b[0];
-    W.g1 = p->w + o.norm_g[1]; W.b1 = p->w + o.norm_b[1];
-    W.ffn_inT = t.nd_in_T; W.ffn_in_b = p->w + o.nd_in_b;
-    W.ffn_outT = t.nd_out_T; W.ffn_out_b = p->w + o.nd_out_b;
-    W.pre_edge = make_pre(p, layer, true);
-    W.pre_next = make_pre(p, layer < 2 ? layer + 1 : 0, false);
-    W.d0_inT = p->d0_in_T; W.d0_in_b = p->w + p->off.d0_in_b;
-    W.d0_outT = p->d0_out_T; W.d0_out_b = p->w + p->off.d0_out_b;
-    W.d2_inT = p->d2_in_T; W.d2_in_b = p->w + p->off.d2_in_b;
-    W.d2_outT = p->d2_out_T; W.d2_out_b = p->w + p->off.d2_out_b;
-    PreW pre0 = make_pre(p, 0, false);
-    const int embed_next = (last_mode == PP_NU_STEP && embed_next_step) ? 1 : 0;    // node embedding for step + 1 afterwards
-    const int st = step;
-    const dim3 grid((c->N + NB - 1) / NB), block(NT);
+    NUpdArgs A;
+    A.N = c->N;
+    A.rmask = c->b.residue_mask;
+    A.rtype = c->b.residue_type;
+    A.bb_sincos = c->b.BB_D_sincos;
+    A.sc_mask = c->b.SC_D_mask;
+    A.m1pi = c->b.chi_1pi_periodic_mask;
+    A.m2pi = c->b.chi_2pi_periodic_mask;
+    A.frames = c->frames;
+    A.steps = c->steps;
+    A.embT = p->node_emb_T;
+    A.wstream = t.nu_stream;
+    A.params = t.nu_params;
+    A.hV = c->hV; A.S = c->S; A.msum = c->msum;
+    A.ptsN = c->ptsN; A.PAn = c->PAn; A.PCn = c->PCn;
+    A.ptsE = c->ptsE; A.PAe = c->PAe; A.PCe = c->PCe;
+    A.score = c->score;
+    int embed_next = (last_mode == PP_NU_STEP && embed_next_step) ? 1 : 0;    // node embedding for step + 1 afterwards
+#ifdef PP_X_NU_EMBED_LAUNCH      /* experiment: the next step's embedding as its own launch (k_node_embed) */
+    const bool embed_after = embed_next != 0;
+    embed_next = 0;
+#endif
+    const dim3 grid((c->N + 15) / 16), block(512);
     const int sde = mode == PP_MODE_SDE ? 1 : 0;
     if (last_mode == PP_NU_MID)
-        hipLaunchKernelGGL(k_node_update<PP_NU_MID>, grid, block, sizeof(Smem), s, A, W, chi, st, sde, noise, embed_next, pre0);
+        hipLaunchKernelGGL(k_node_update<PP_NU_MID>, grid, block, sizeof(SmemU), s, A, chi, step, sde, noise, embed_next);
     else if (last_mode == PP_NU_STEP)
-        hipLaunchKernelGGL(k_node_update<PP_NU_STEP>, grid, block, sizeof(Smem), s, A, W, chi, st, sde, noise, embed_next, pre0);
+        hipLaunchKernelGGL(k_node_update<PP_NU_STEP>, grid, block, sizeof(SmemU), s, A, chi, step, sde, noise, embed_next);
     else
-        hipLaunchKernelGGL(k_node_update<PP_NU_SCORE>, grid, block, sizeof(Smem), s, A, W, chi, st, sde, noise, embed_next, pre0);
+        hipLaunchKernelGGL(k_node_update<PP_NU_SCORE>, grid, block, sizeof(SmemU), s, A, chi, step, sde, noise, embed_next);
     PP_HIP_CHECK(hipGetLastError());
+#ifdef PP_X_NU_EMBED_LAUNCH
+    if (embed_after) return pp_launch_node_embed(c, chi, step + 1, s);
+#endif
     return PP_OK;
 }

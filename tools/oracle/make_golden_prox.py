@@ -1,0 +1,98 @@
+"""Container-only: proximal-stage goldens at the benchmark sizes + an fp64 arbiter (tests/golden/g6_*.npz).
+
+    PYTHONDONTWRITEBYTECODE=1 python tools/oracle/make_golden_prox.py [--only L64,L120,T1124,S1500] [--no64 S1500]
+
+Runs the UNMODIFIED reference ``proximal_optimizer`` (optimize.py:21-73) through tools/oracle/refshim.py
+
+  * in fp32 (what ``sampling(use_proximal=True)`` does, TorsionalDiffusion.py:286-298): 50 Adam steps from the
+    reference's own 100-step sampling result (the ``chi_ode_100`` of g4_T1124 / g5_S1500; ``init_chi_seed11`` for the
+    small synthetic cases), storing the angles after steps 1, 5, 10, 20, 50, the 50 pre-step losses, the accepted angles
+    and the metrics of ``analyze_samples`` on them;
+  * in fp64 (batch tensors and angles cast to double; same code) -- the arbiter: a test may ask
+    |HIP - ref64| <= c * |ref32 - ref64| instead of a bound on |HIP - ref32| that fp32 round-off itself cannot hold.
+
+Only data is written (inputs are already in the g3p/g4/g5 fixtures).
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.abspath(os.path.join(HERE, "..", ".."))
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+
+import refshim  # noqa: E402
+from packppi_amd.batch import Batch, TENSOR_KEYS  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+KEEP = (1, 5, 10, 20, 50)
+
+
+def load_fixture(name):
+    z = np.load(os.path.join(GOLD, name + ".npz"))
+    b = Batch({k: torch.from_numpy(z["batch." + k]) for k in TENSOR_KEYS})
+    b["num_proteins"] = int(z["batch.num_proteins"])
+    b["max_size"] = int(z["batch.max_size"])
+    return z, b
+
+
+def ref_batch(b, double=False):
+    d = {}
+    for k, v in b.items():
+        if isinstance(v, torch.Tensor):
+            v = v.clone()
+            if double and v.dtype == torch.float32:
+                v = v.double()
+        d[k] = v
+    return refshim.Data(**d)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="L64,L120,T1124,S1500")
+    ap.add_argument("--no64", default="S1500", help="cases without the fp64 run (host memory)")
+    ap.add_argument("--threads", type=int, default=6)
+    args = ap.parse_args()
+    torch.set_num_threads(args.threads)
+    from src.models.components.optimize import proximal_optimizer
+    model = refshim.build_reference_module(0)          # only analyze_samples is used: weights do not matter
+
+    cases = {"L64": ("g3_proximal_L64", "init_chi_seed11"), "L120": ("g3_proximal_L120", "init_chi_seed11"),
+             "T1124": ("g4_T1124", "chi_ode_100"), "S1500": ("g5_S1500", "chi_ode_100")}
+    for tag in args.only.split(","):
+        fx, key = cases[tag]
+        z, b = load_fixture(fx)
+        chi0 = torch.from_numpy(z[key]).float()
+        out = {"source_fixture": np.array(fx), "chi0_key": np.array(key)}
+        for prec in ("32", "64"):
+            if prec == "64" and tag in args.no64.split(","):
+                continue
+            dbl = prec == "64"
+            rb = ref_batch(b, dbl)
+            x0 = chi0.double() if dbl else chi0.clone()
+            t0 = time.time()
+            chis, losses = proximal_optimizer(rb, x0, 12., 0.5, 1., 50)
+            print(f"  {tag} fp{prec}: 50 steps {time.time() - t0:.1f}s  loss {losses[0]:.6f} -> {losses[-1]:.6f}", flush=True)
+            for n in KEEP:
+                out[f"chi{prec}_step{n}"] = chis[n - 1].detach().numpy()
+            out[f"losses{prec}"] = np.array(losses, np.float64)
+            accepted = chis[-1].detach() if losses[-1] < losses[0] else x0
+            out[f"accepted{prec}"] = accepted.numpy()
+            with torch.no_grad():
+                for k, v in model.analyze_samples(rb, SC_D_sample=accepted).items():
+                    out[f"metric{prec}.{k}"] = np.float64(v)
+                if not dbl:
+                    for k, v in model.analyze_samples(rb, SC_D_sample=x0).items():
+                        out[f"metric32_before.{k}"] = np.float64(v)
+        path = os.path.join(GOLD, f"g6_prox_{tag}.npz")
+        np.savez_compressed(path, **out)
+        print(f"  wrote {os.path.basename(path)} {os.path.getsize(path) / 1e6:.2f} MB", flush=True)
+
+
+if __name__ == "__main__":
+    main()
