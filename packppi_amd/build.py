@@ -37,8 +37,12 @@ def build_library(force=False, verbose=True, extra_flags=(), tag=""):
         return LIB
     hipcc = _hipcc()
     objs = []
+    only = os.environ.get("PACKPPI_VARIANT_SOURCES", "").split()      # tagged build: recompile only these, reuse the base objects
     for src in SOURCES:
         obj = os.path.join(CSRC, src.replace(".hip", f".{tag}.o" if tag else ".o"))
+        if tag and only and src not in only:
+            objs.append(os.path.join(CSRC, src.replace(".hip", ".o")))
+            continue
         cmd = [hipcc, *FLAGS, *extra_flags, "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)

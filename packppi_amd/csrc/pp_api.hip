@@ -253,6 +253,8 @@ static size_t put_node_stream(std::vector<float> &arena, const float *w, const W
                 for (int ks = 0; ks < 2; ks++) put(wv == 0 ? w + off.d0_out_w : nullptr, 64, 16 * t, 16, 32 * ks, 32);
             put(wv == 0 ? w + off.d2_in_w : nullptr, 32, 0, 16, 0, 32);
             put(wv == 0 ? w + off.d2_out_w : nullptr, 16, 0, 4, 0, 16);
+            // node_embedding.weight [128][51], input columns 21..50 (6 backbone sin/cos, 8 chi sin/cos, 16 time) as one k-step
+            put(w + off.node_emb_w, 51, 16 * wv, 16, 21, 30);
             for (int ks = 0; ks < 4; ks++) put(w + L0.nm_in_w, 456, 16 * wv, 16, 32 * ks, 32);
             for (int ks = 0; ks < 4; ks++) put(w + L0.nm_in_w, 456, 16 * wv, 16, 256 + 32 * ks, 32);
             for (int ks = 0; ks < 4; ks++) put(wv < 2 ? w + L0.pts_node_w : nullptr, 128, 16 * wv, wv == 0 ? 16 : 8, 32 * ks, 32);
@@ -279,9 +281,6 @@ static size_t put_node_params(std::vector<float> &arena, const float *w, const W
         cp(NU_P_DB0, off.d0_in_b, 64); cp(NU_P_DB1, off.d0_out_b, 32); cp(NU_P_DB2, off.d2_in_b, 16); cp(NU_P_DB3, off.d2_out_b, 4);
         cp(NU_P_PAN0_B, L0.nm_in_b, 128); cp(NU_P_PTS0_B, L0.pts_node_b, 24);
         cp(NU_P_EMB_B, off.node_emb_b, 128); cp(NU_P_EMB_G, off.norm_nodes_g, 128); cp(NU_P_EMB_BETA, off.norm_nodes_b, 128);
-        // node_embedding.weight [128][51], input columns 21..50 (6 backbone sin/cos, 8 chi sin/cos, 16 time), transposed
-        for (int k = 0; k < 30; k++)
-            for (int f = 0; f < 128; f++) d[NU_P_EMBT + k * 128 + f] = w[off.node_emb_w + (size_t)f * 51 + 21 + k];
     }
     return at;
 }

@@ -53,7 +53,7 @@ struct LayerT {
 #define PP_NU_WAVES 8
 #define PP_NU_SLOT_FLOATS 512
 #define PP_NU_SLOTS_MID 56     // W_out 4 | FFN-in 16 | FFN-out 16 | PAe 4 | PCe 4 | PAn 4 | PCn 4 | pts 4 (waves 0-2)
-#define PP_NU_SLOTS_LAST 58    // W_out 4 | FFN-in 16 | FFN-out 16 | D1 4 (waves 0-3) | D2 4, D3 1, D4 1 (wave 0) | PAn 4 | PCn 4 | pts 4 (waves 0-1)
+#define PP_NU_SLOTS_LAST 59    // W_out 4 | FFN-in 16 | FFN-out 16 | D1 4 (waves 0-3) | D2 4, D3 1, D4 1 (wave 0) | embed 1 | PAn 4 | PCn 4 | pts 4 (waves 0-1)
 #define PP_NU_LO_SCALE 2048.0f
 enum {
     NU_P_OUTB = 0, NU_P_G0 = 128, NU_P_B0 = 256, NU_P_FIB = 384, NU_P_FOB = 896, NU_P_G1 = 1024, NU_P_B1 = 1152,
@@ -61,7 +61,7 @@ enum {
     NU_P_PAE_B = 1280, NU_P_PAN_B = 1408, NU_P_PTS_B = 1536, NU_P_MID_TOTAL = 1600,
     // LAST
     NU_P_DB0 = 1280, NU_P_DB1 = 1344, NU_P_DB2 = 1376, NU_P_DB3 = 1392, NU_P_PAN0_B = 1408, NU_P_PTS0_B = 1536,
-    NU_P_EMB_B = 1568, NU_P_EMB_G = 1696, NU_P_EMB_BETA = 1824, NU_P_EMBT = 1952, NU_P_LAST_TOTAL = 1952 + 30 * 128
+    NU_P_EMB_B = 1568, NU_P_EMB_G = 1696, NU_P_EMB_BETA = 1824, NU_P_LAST_TOTAL = 1952
 };
 
 struct StepParams;

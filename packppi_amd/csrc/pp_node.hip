@@ -306,6 +306,7 @@ typedef unsigned nu2 __attribute__((ext_vector_type(2)));
 #define NU_NRING (NU_ND + 1)
 #define NU_S128 144        // halves per residue row of a 128-feature operand image
 #define NU_S512 528        // ... of the 512-feature one
+#define NU_S32 48          // ... of the 32-feature one (node embedding inputs)
 #define NU_INV_LO (1.0f / PP_NU_LO_SCALE)
 
 struct AOpN {
@@ -318,7 +319,8 @@ struct SmemU {
     _Float16 c_hi[16 * NU_S512], c_lo[16 * NU_S512];     // FFN hidden; decoder activations in columns 0..127
     float stats[3][8][16][2];                            // LayerNorm partials (per wave: mean, centred sum of squares)
     float pts[16][48];                                   // local points of the tile
-    float sc[16][8];                                     // layer 2: masked sin / cos of the stepped chi
+    _Float16 e_hi[16 * NU_S32], e_lo[16 * NU_S32];       // layer 2: dense inputs of the next step's node embedding (30 of 32)
+    float fr[16][12];                                    // backbone frames of the tile's residues
     float par[NU_P_LAST_TOTAL];                          // parameter block (layers 0, 1 use the first NU_P_MID_TOTAL)
 };
 
@@ -341,7 +343,7 @@ struct NUpdArgs {
 template <bool LAST>
 __device__ constexpr int nu_slot_waves(int s) {       // how many waves (0 .. n-1) own slot s; see pp_internal.h
     if (!LAST) return s < 52 ? 8 : 3;
-    return s < 36 ? 8 : s < 40 ? 4 : s < 46 ? 1 : s < 54 ? 8 : 2;
+    return s < 36 ? 8 : s < 40 ? 4 : s < 46 ? 1 : s < 55 ? 8 : 2;
 }
 
 __device__ __forceinline__ void gload_N(const nh8 *__restrict__ wq, int slot, AOpN &a) {
@@ -353,6 +355,10 @@ __device__ __forceinline__ void gload_N(const nh8 *__restrict__ wq, int slot, AO
 }
 #define MFMA_N(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
 __device__ __forceinline__ void mm3(const AOpN &a, const nh8 &bh, const nh8 &bl, nf4 &cH, nf4 &cL) {
+#ifdef PP_X_NU_NOMFMA        /* timing experiment (wrong results): the weight stream and the barriers without the matrix work */
+    asm volatile("" ::"v"(a.hi), "v"(a.lo), "v"(bh), "v"(bl));
+    return;
+#endif
     cH = MFMA_N(a.hi, bh, cH);
     cL = MFMA_N(a.hi, bl, cL);
     cL = MFMA_N(a.lo, bh, cL);
@@ -426,14 +432,17 @@ __device__ __forceinline__ nf4 ln128(float (*st)[16][2], int wv, int r, int g, c
     return (x - mean) * rstd * gain + beta;
 }
 
-// stage k: fetch slot k + NU_ND (if this wave owns it), then BODY on the operands of slot k (AK).  The scheduling barrier
+// stage k: fetch slot k + NU_ND (if this wave owns it), then BODY on the operands of slot k (AK).  The fetch condition is
+// the slot's owner set only: a run-time condition such as embed_next here makes the compiler's vmcnt bookkeeping assume
+// the path without the later fetches, and every wait after it drains the ring (the last step of a sampling run fetches 12
+// slots per wave it never uses; s_endpgm waits for them).  The scheduling barrier
 // keeps fetches and MFMAs in their stage; the empty asm on the accumulator keeps the (pure) MFMAs from sinking.
 #define NSTAGE_IF(k, OWN, ACCV, BODY)                                                                                  \
     {                                                                                                                  \
         __builtin_amdgcn_sched_barrier(0);                                                                             \
-        if constexpr ((k) + NU_ND < NLOAD) {                                                                           \
+        if constexpr ((k) + NU_ND < NLOAD && !NU_X_NOLOAD) {                                                           \
             constexpr int nw_ = nu_slot_waves<LAST>((k) + NU_ND);                                                      \
-            if ((nw_ == 8 || wv < nw_) && ((k) + NU_ND < 46 || !LAST || embed_next || NU_X_NOPRED))                    \
+            if (nw_ == 8 || wv < nw_)                                                                                  \
                 gload_N(wq, (k) + NU_ND, AR[((k) + NU_ND) % NU_NRING]);                                                \
         }                                                                                                              \
         if (OWN) {                                                                                                     \
@@ -459,10 +468,10 @@ __device__ __forceinline__ nf4 ln128(float (*st)[16][2], int wv, int r, int g, c
         mm3(AK, fh[(s) & 1], fl[(s) & 1], cH, cL);                                                   \
     })
 
-#ifdef PP_X_NU_NOPRED
-#define NU_X_NOPRED true
+#ifdef PP_X_NU_NOLOAD        /* timing experiment (wrong results): no weight fetches after the prologue's */
+#define NU_X_NOLOAD true
 #else
-#define NU_X_NOPRED false
+#define NU_X_NOLOAD false
 #endif
 template <int MODE>
 __global__ void __launch_bounds__(512)
@@ -485,30 +494,49 @@ k_node_update(NUpdArgs A, float *chi, int step, int sde, const float *noise, int
     const nf4 s4 = *reinterpret_cast<const nf4 *>(A.S + (size_t)sn * 128 + scol);
     const nf4 hv4 = *reinterpret_cast<const nf4 *>(A.hV + (size_t)nc * 128 + fc);
     const float ms = A.msum[nc], rm = A.rmask[nc];
-    nf4 chi4 = {0.f, 0.f, 0.f, 0.f}, scm4 = chi4, nz1 = chi4, nz2 = chi4;
-    unsigned m1 = 0, m2 = 0;
+    const nf4 zero4i = {0.f, 0.f, 0.f, 0.f};
+    float chi1 = 0.f, scm1 = 0.f, nz1 = 0.f, nz2 = 0.f;       // wave 0: lane (r, g) steps chi g of residue r
+    bool p1 = false, p2 = false;
     int rt = 0;
-    float bb[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    nf4 spv = chi4;                            // c_ode, w, c_drift, c_diff of this step
+    nf4 spv = zero4i;                          // c_ode, w, c_drift, c_diff of this step
     if constexpr (MODE == PP_NU_STEP) {
-        if (wv == 0 && g == 0) {
+        if (wv == 0) {
             spv = *reinterpret_cast<const nf4 *>(&A.steps[step].c_ode);
-            chi4 = *reinterpret_cast<const nf4 *>(chi + (size_t)nc * 4);
-            scm4 = *reinterpret_cast<const nf4 *>(A.sc_mask + (size_t)nc * 4);
-            m1 = *reinterpret_cast<const unsigned *>(A.m1pi + (size_t)nc * 4);
-            m2 = *reinterpret_cast<const unsigned *>(A.m2pi + (size_t)nc * 4);
+            chi1 = chi[(size_t)nc * 4 + g];
+            scm1 = A.sc_mask[(size_t)nc * 4 + g];
+            p1 = A.m1pi[(size_t)nc * 4 + g] != 0;
+            p2 = A.m2pi[(size_t)nc * 4 + g] != 0;
             if (sde) {
                 const size_t NN = (size_t)N * 4;
-                const float *nz = noise + (size_t)step * 2 * NN + (size_t)nc * 4;
-                nz1 = *reinterpret_cast<const nf4 *>(nz);
-                nz2 = *reinterpret_cast<const nf4 *>(nz + NN);
+                const float *nz = noise + (size_t)step * 2 * NN + (size_t)nc * 4 + g;
+                nz1 = nz[0];
+                nz2 = nz[NN];
             }
         }
+        if (embed_next) rt = (int)A.rtype[nc];
+    }
+    // small inputs of the kernel's tail, staged in LDS now (a dependent fetch there would sit on the critical path): the
+    // tile's backbone frames (threads 0..47) and, in layer 2, the chi-independent dense inputs of the next step's node
+    // embedding as MFMA operand rows (encoder.py:218-242: 6 backbone sin / cos by threads 128..143, the 16-d time embedding
+    // by threads 192..207; the 8 chi sin / cos follow after the reverse step)
+    nf4 tailv = {0.f, 0.f, 0.f, 0.f};
+    nf4 ev[4] = {tailv, tailv, tailv, tailv};
+    const int erow = tid & 15, ern = n0 + erow < N ? n0 + erow : N - 1;
+    const bool e_bb = MODE == PP_NU_STEP && tid >= 128 && tid < 144, e_te = MODE == PP_NU_STEP && tid >= 192 && tid < 208;
+    if (tid < 48) {
+        const int row = tid / 3, rn = n0 + row < N ? n0 + row : N - 1;
+        tailv = *reinterpret_cast<const nf4 *>(A.frames + (size_t)rn * 12 + 4 * (tid - 3 * row));
+    } else if (e_bb) {
         if (embed_next) {
-            rt = (int)A.rtype[nc];
-            const nf2 *bp = reinterpret_cast<const nf2 *>(A.bb_sincos + (size_t)nc * 6);
+            const nf2 *bp = reinterpret_cast<const nf2 *>(A.bb_sincos + (size_t)ern * 6);
             const nf2 b0 = bp[0], b1 = bp[1], b2 = bp[2];
-            bb[0] = b0[0]; bb[1] = b0[1]; bb[2] = b1[0]; bb[3] = b1[1]; bb[4] = b2[0]; bb[5] = b2[1];
+            ev[0] = nf4{b0[0], b0[1], b1[0], b1[1]};
+            ev[1] = nf4{b2[0], b2[1], 0.f, 0.f};
+        }
+    } else if (e_te) {
+        if (embed_next) {
+            const nf4 *tp = reinterpret_cast<const nf4 *>(A.steps[step + 1].temb);
+            ev[0] = tp[0]; ev[1] = tp[1]; ev[2] = tp[2]; ev[3] = tp[3];
         }
     }
     constexpr int NPV = (NPAR / 4 + 511) / 512;
@@ -529,13 +557,31 @@ k_node_update(NUpdArgs A, float *chi, int step, int sde, const float *noise, int
         const int q = tid + 512 * i;
         if (q < NPAR / 4) reinterpret_cast<nf4 *>(sm.par)[q] = pv[i];
     }
+    // next step's embedding: the one-hot column is fetched now, used at the very end
+    nf4 oh4 = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (MODE == PP_NU_STEP) {
+        if (embed_next) oh4 = *reinterpret_cast<const nf4 *>(A.embT + (size_t)rt * 128 + fc);
+    }
+    if (tid < 48) reinterpret_cast<nf4 *>(&sm.fr[0][0])[tid] = tailv;
+    else if (e_bb) {                       // features 0..5 (6, 7 are rewritten with chi_0's sin / cos later)
+        publish4(sm.e_hi, sm.e_lo, erow * NU_S32, ev[0]);
+        publish4(sm.e_hi, sm.e_lo, erow * NU_S32 + 4, ev[1]);
+    } else if (e_te) {                     // features 14..29, zeros in 30, 31; 12..13 are rewritten later
+        publish4(sm.e_hi, sm.e_lo, erow * NU_S32 + 12, nf4{0.f, 0.f, ev[0][0], ev[0][1]});
+        publish4(sm.e_hi, sm.e_lo, erow * NU_S32 + 16, nf4{ev[0][2], ev[0][3], ev[1][0], ev[1][1]});
+        publish4(sm.e_hi, sm.e_lo, erow * NU_S32 + 20, nf4{ev[1][2], ev[1][3], ev[2][0], ev[2][1]});
+        publish4(sm.e_hi, sm.e_lo, erow * NU_S32 + 24, nf4{ev[2][2], ev[2][3], ev[3][0], ev[3][1]});
+        publish4(sm.e_hi, sm.e_lo, erow * NU_S32 + 28, nf4{ev[3][2], ev[3][3], 0.f, 0.f});
+    }
     publish4(sm.a_hi, sm.a_lo, srow * NU_S128 + scol, s4);
     __syncthreads();
 
-    nf4 eacc = {0.f, 0.f, 0.f, 0.f}, etime = eacc;
+#if defined(PP_X_NU_STOP) && PP_X_NU_STOP == 1     /* timing experiment: stop here */
+    return;
+#endif
     nh8 bh[4], bl[4];
     nf4 cH, cL;
-    const nf4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const nf4 zero4 = zero4i;
     // ---- W_out on the masked mean S: mean_j mask_j (W_out y_j + b) = W_out mean_j(mask_j y_j) + b mean_j(mask_j) -----
     LDB4(sm.a_hi, sm.a_lo)
     cH = zero4; cL = zero4;
@@ -545,6 +591,9 @@ k_node_update(NUpdArgs A, float *chi, int step, int sde, const float *noise, int
                          *reinterpret_cast<const nf4 *>(par + NU_P_B0 + fc));
     publish4(sm.b_hi, sm.b_lo, r * NU_S128 + fc, h1);
     __syncthreads();
+#if defined(PP_X_NU_STOP) && PP_X_NU_STOP == 2     /* timing experiment: stop here */
+    return;
+#endif
     // ---- FFN 128 -> 512: hidden tiles 4 w .. 4 w + 3 ----------------------------------------------------------------
     LDB4(sm.b_hi, sm.b_lo)
 #define FFN_IN_TILE(c)                                                                                     \
@@ -554,6 +603,9 @@ k_node_update(NUpdArgs A, float *chi, int step, int sde, const float *noise, int
              relu_sat(fold(cH, cL) + *reinterpret_cast<const nf4 *>(par + NU_P_FIB + 16 * (4 * wv + (c)) + 4 * g)));
     FFN_IN_TILE(0) FFN_IN_TILE(1) FFN_IN_TILE(2) FFN_IN_TILE(3)
     __syncthreads();
+#if defined(PP_X_NU_STOP) && PP_X_NU_STOP == 3     /* timing experiment: stop here */
+    return;
+#endif
     // ---- FFN 512 -> 128, LayerNorm, mask ------------------------------------------------------------------------------
     nh8 fh[2], fl[2];
     ldB(sm.c_hi, sm.c_lo, r * NU_S512 + 8 * g, 0, fh[0], fl[0]);
@@ -566,6 +618,9 @@ k_node_update(NUpdArgs A, float *chi, int step, int sde, const float *noise, int
     if (live && (MODE != PP_NU_STEP || !embed_next)) *reinterpret_cast<nf4 *>(A.hV + (size_t)n * 128 + fc) = h2;
     publish4(sm.a_hi, sm.a_lo, r * NU_S128 + fc, h2);
     __syncthreads();
+#if defined(PP_X_NU_STOP) && PP_X_NU_STOP == 4     /* timing experiment: stop here */
+    return;
+#endif
     LDB4(sm.a_hi, sm.a_lo)
 
     if constexpr (!LAST) {
@@ -597,7 +652,7 @@ k_node_update(NUpdArgs A, float *chi, int step, int sde, const float *noise, int
             const int mm = tid >> 7, q = (tid >> 4) & 7, i = tid & 15, ni = n0 + i;
             if (ni < N) {
                 float *pts = mm == 0 ? A.ptsE : A.ptsN;
-                const float *fr = A.frames + (size_t)ni * 12;
+                const float *fr = sm.fr[i];
                 const float px = sm.pts[i][24 * mm + 3 * q], py = sm.pts[i][24 * mm + 3 * q + 1], pz = sm.pts[i][24 * mm + 3 * q + 2];
 #pragma unroll
                 for (int rr = 0; rr < 3; rr++)
@@ -613,6 +668,9 @@ k_node_update(NUpdArgs A, float *chi, int step, int sde, const float *noise, int
             publish4(sm.c_hi, sm.c_lo, r * NU_S512 + fc, relu_sat(fold(cH, cL) + *reinterpret_cast<const nf4 *>(par + NU_P_DB0 + fc)));
         }
         __syncthreads();
+#if defined(PP_X_NU_STOP) && PP_X_NU_STOP == 5     /* timing experiment: stop here */
+        return;
+#endif
         // the rest of the decoder is one wave's work: 64 -> 32 (two tiles), 32 -> 16, 16 -> 4; activations go through
         // columns 64..127 of the same image (a wave's LDS operations execute in order; the asm is the compiler fence).
         // The other waves only keep their weight stream going (the stages' fetches) and wait at the next barrier.
@@ -646,82 +704,65 @@ k_node_update(NUpdArgs A, float *chi, int step, int sde, const float *noise, int
             NSTAGE_IF(45, w0, cH, mm3(AK, dh[0], dl[0], cH, cL))
         }
         if (w0) {
-            if (g == 0) {          // registers 0..3 of lane group 0 = the four scores of residue r
-                const nf4 sc = fold(cH, cL) + *reinterpret_cast<const nf4 *>(par + NU_P_DB3);
-                if (live) *reinterpret_cast<nf4 *>(A.score + (size_t)n * 4) = sc;
-                if constexpr (MODE == PP_NU_STEP) {
-                    // reverse step (schedule.py:198-235 with the two periodicity masks, TorsionalDiffusion.py:268-280)
-                    const float sp_c_ode = spv[0], sp_w = spv[1], sp_c_drift = spv[2], sp_c_diff = spv[3];
-                    nf4 y;
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        const bool p1 = (m1 >> (8 * k)) & 0xffu, p2 = (m2 >> (8 * k)) & 0xffu;
-                        const float sw = sc[k] * sp_w;
-                        float yk = chi4[k];
-                        if (!sde) {
-                            if (p1 || p2) yk = chi4[k] + sp_c_ode * sw;
-                        } else {
-                            if (p1) yk = chi4[k] + (sp_c_drift * sw + sp_c_diff * nz1[k]);
-                            if (p2) yk = yk + (sp_c_drift * sw + sp_c_diff * nz2[k]);
-                        }
-                        y[k] = wrap_pi(yk) * scm4[k];
-                    }
-                    if (live) *reinterpret_cast<nf4 *>(chi + (size_t)n * 4) = y;
-                    if (embed_next) {
-#pragma unroll
-                        for (int k = 0; k < 4; k++) {
-                            sm.sc[r][2 * k] = sinf(y[k]) * scm4[k];
-                            sm.sc[r][2 * k + 1] = cosf(y[k]) * scm4[k];
-                        }
-                    }
+            // registers 0..3 of lane group 0 = the four scores of residue r
+            const nf4 sc = fold(cH, cL) + *reinterpret_cast<const nf4 *>(par + NU_P_DB3);
+            if (g == 0 && live) *reinterpret_cast<nf4 *>(A.score + (size_t)n * 4) = sc;
+            if constexpr (MODE == PP_NU_STEP) {
+                // reverse step (schedule.py:198-235 with the two periodicity masks, TorsionalDiffusion.py:268-280): one
+                // (residue, chi) per lane -- lane (r, g) takes score g from lane (r, 0)
+                const float s0 = __shfl(sc[0], r), s1 = __shfl(sc[1], r), s2 = __shfl(sc[2], r), s3 = __shfl(sc[3], r);
+                const float sg = g == 0 ? s0 : g == 1 ? s1 : g == 2 ? s2 : s3;
+                const float sp_c_ode = spv[0], sp_w = spv[1], sp_c_drift = spv[2], sp_c_diff = spv[3];
+                const float sw = sg * sp_w;
+                float yk = chi1;
+                if (!sde) {
+                    if (p1 || p2) yk = chi1 + sp_c_ode * sw;
+                } else {
+                    if (p1) yk = chi1 + (sp_c_drift * sw + sp_c_diff * nz1);
+                    if (p2) yk = yk + (sp_c_drift * sw + sp_c_diff * nz2);
+                }
+                const float y = wrap_pi(yk) * scm1;
+                if (live) chi[(size_t)n * 4 + g] = y;
+                if (embed_next) {          // features 6 + 2 g, 7 + 2 g of the embedding operand
+                    unsigned hp, lp;
+                    split2(sinf(y) * scm1, cosf(y) * scm1, hp, lp);
+                    *reinterpret_cast<unsigned *>(sm.e_hi + r * NU_S32 + 6 + 2 * g) = hp;
+                    *reinterpret_cast<unsigned *>(sm.e_lo + r * NU_S32 + 6 + 2 * g) = lp;
                 }
             }
         }
         if constexpr (MODE != PP_NU_STEP) return;
         if (!embed_next) return;
         __syncthreads();
+#if defined(PP_X_NU_STOP) && PP_X_NU_STOP == 6     /* timing experiment: stop here */
+        return;
+#endif
         // ---- next step's node embedding (encoder.py:218-242) and the layer-0 node-message inputs ---------------------
-        // (Computing the chi-independent part of this sum early, in the shadow of the first weight fetches, made sampling
-        // irreproducible from run to run -- results differed in a few residues, more often with a shallower prefetch ring;
-        // tools/debug/nu_repro2.py, 100/100 runs at L = 400 against 0/200 with the sum placed here.  The cause was not
-        // found in the ISA; test_sampling_is_bit_reproducible guards the placement.)
-        {
-            const nf4 oh4 = *reinterpret_cast<const nf4 *>(A.embT + (size_t)rt * 128 + fc);
-            eacc = *reinterpret_cast<const nf4 *>(par + NU_P_EMB_B + fc) + oh4;
-#pragma unroll
-            for (int k = 0; k < 6; k++) {
-                const nf4 wk = *reinterpret_cast<const nf4 *>(par + NU_P_EMBT + k * 128 + fc);
-                eacc = nf4{fmaf(wk[0], bb[k], eacc[0]), fmaf(wk[1], bb[k], eacc[1]), fmaf(wk[2], bb[k], eacc[2]), fmaf(wk[3], bb[k], eacc[3])};
-            }
-            const float *te = A.steps[step + 1].temb;
-#pragma unroll
-            for (int k = 0; k < 16; k++) {
-                const nf4 wk = *reinterpret_cast<const nf4 *>(par + NU_P_EMBT + (14 + k) * 128 + fc);
-                const float tk = te[k];
-                etime = nf4{fmaf(wk[0], tk, etime[0]), fmaf(wk[1], tk, etime[1]), fmaf(wk[2], tk, etime[2]), fmaf(wk[3], tk, etime[3])};
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const nf4 wk = *reinterpret_cast<const nf4 *>(par + NU_P_EMBT + (6 + k) * 128 + fc);
-            const float sk = sm.sc[r][k];
-            eacc = nf4{fmaf(wk[0], sk, eacc[0]), fmaf(wk[1], sk, eacc[1]), fmaf(wk[2], sk, eacc[2]), fmaf(wk[3], sk, eacc[3])};
-        }
-        const nf4 h0 = ln128(sm.stats[2], wv, r, g, eacc + etime, *reinterpret_cast<const nf4 *>(par + NU_P_EMB_G + fc),
+        // bias + one-hot column + W[:, 21:51] . (30 dense inputs) as one MFMA k-step (slot 46)
+        nh8 eh, el;
+        eh = *reinterpret_cast<const nh8 *>(sm.e_hi + r * NU_S32 + 8 * g);
+        el = *reinterpret_cast<const nh8 *>(sm.e_lo + r * NU_S32 + 8 * g);
+        cH = zero4; cL = zero4;
+        NSTAGE(46, cH, mm3(AK, eh, el, cH, cL))
+        const nf4 e0 = fold(cH, cL) + (*reinterpret_cast<const nf4 *>(par + NU_P_EMB_B + fc) + oh4);
+        const nf4 h0 = ln128(sm.stats[2], wv, r, g, e0, *reinterpret_cast<const nf4 *>(par + NU_P_EMB_G + fc),
                              *reinterpret_cast<const nf4 *>(par + NU_P_EMB_BETA + fc));
         if (live) *reinterpret_cast<nf4 *>(A.hV + (size_t)n * 128 + fc) = h0;
         publish4(sm.b_hi, sm.b_lo, r * NU_S128 + fc, h0);
         __syncthreads();
+#if defined(PP_X_NU_STOP) && PP_X_NU_STOP == 7     /* timing experiment: stop here */
+        return;
+#endif
         LDB4(sm.b_hi, sm.b_lo)
         cH = zero4; cL = zero4;
-        NTILE4(46, cH, cL)
+        NTILE4(47, cH, cL)
         if (live) *reinterpret_cast<nf4 *>(A.PAn + (size_t)n * 128 + fc) = fold(cH, cL) + *reinterpret_cast<const nf4 *>(par + NU_P_PAN0_B + fc);
         cH = zero4; cL = zero4;
-        NTILE4(50, cH, cL)
+        NTILE4(51, cH, cL)
         if (live) *reinterpret_cast<nf4 *>(A.PCn + (size_t)n * 128 + fc) = fold(cH, cL);
         if (wv < 2) {
             cH = zero4; cL = zero4;
-            NTILE4(54, cH, cL)
+            NTILE4(55, cH, cL)
             if (fc < 24) {
                 const nf4 p = fold(cH, cL) + *reinterpret_cast<const nf4 *>(par + NU_P_PTS0_B + fc);
                 *reinterpret_cast<nf4 *>(&sm.pts[r][fc]) = p;
@@ -732,7 +773,7 @@ k_node_update(NUpdArgs A, float *chi, int step, int sde, const float *noise, int
         if (tid < 128) {
             const int q = tid >> 4, i = tid & 15, ni = n0 + i;
             if (ni < N) {
-                const float *fr = A.frames + (size_t)ni * 12;
+                const float *fr = sm.fr[i];
                 const float px = sm.pts[i][3 * q], py = sm.pts[i][3 * q + 1], pz = sm.pts[i][3 * q + 2];
 #pragma unroll
                 for (int rr = 0; rr < 3; rr++)
