@@ -1,17 +1,24 @@
 #!/usr/bin/env python
-"""Benchmark of the PackPPI-MSC sampling path on MI355X (contract: see the task brief / DESIGN.md §Measurement).
+"""Benchmark of the PackPPI-MSC sampling path on MI355X (contract: see the task brief / DESIGN.md section 5).
 
     python bench.py --gpus N --steps K --warmup W
 
 One "step" = one full ``sampling()`` pass (100 reverse-diffusion network evaluations, no proximal) over the
 rank's batch.  Workload at every N: ``data/T1124_lig.pdb`` (738 true residues, fixture
 tests/golden/g4_T1124.npz) per GPU -- BASELINE.json configs[1]; ranks hold independent complexes (weak scaling,
-no data-path collective); the only collective is the all-gather of per-complex metric rows.
+no data-path collective); the only collective is the all-gather of per-complex metric rows (RCCL when the backend
+is "nccl").  The line also carries a secondary figure for BASELINE configs[4]'s per-GPU share (32 synthetic ~300-residue
+complexes per rank, sampled as one packed ragged batch).
 Prints ONE JSON line on rank 0.
+
+N > 1: the driver launches one rank per GPU with torch.distributed.run; run by hand without WORLD_SIZE, this script
+starts that launcher itself as a child process BEFORE anything touches the GPU and exits with its code.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -23,84 +30,103 @@ sys.path.insert(0, ROOT)
 
 N_DIFFUSION_STEPS = 100
 # algorithmic FLOPs (2/MAC, dense projections only) of ONE launch of the dominant kernel (edge update), per edge:
-# edge message MLP 456->128->128->128 + FFN 128->512->128   (SURVEY.md §8d itemisation)
+# edge message MLP 456->128->128->128 + FFN 128->512->128   (SURVEY.md section 8d itemisation)
 EDGE_UPDATE_FLOP_PER_EDGE = 2 * (456 * 128 + 128 * 128 + 128 * 128) + 2 * (128 * 512 + 512 * 128)
 NODE_MSG_FLOP_PER_EDGE = 2 * (456 * 128 + 128 * 128 + 128 * 128)
+# node update, per residue and launch (layers 0, 1): W_out + FFN + the four 128x128 message-input projections + 2 x 24 points
+NODE_UPDATE_FLOP_PER_RES = 2 * (128 * 128 + 2 * 128 * 512 + 4 * 128 * 128 + 2 * 24 * 128)
+NODE_UPDATE_STREAM_BYTES = 56 * 8 * 2048       # one workgroup's weight stream (pp_internal.h PP_NU_SLOTS_MID slots x 8 waves x 2 KB)
 FP32_MFMA_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 F16_MFMA_PEAK_TFLOPS = 2500.0       # MI355X_MICROARCH.md, "Peak BF16/FP16 MFMA ~2.5 PF dense"
+HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md, "HBM3E peak BW 8.0 TB/s spec"
+CU_VMEM_PEAK_GBS = 64 * 2.4         # one CU's vector-memory path: 64 B/clk at 2.4 GHz
+PROFILE_TAG = "r02_v14"             # the committed rocprofv3 summaries of THIS command (profiles/<tag>_*.{csv,json})
+
+
+def _load_fixture(name, init_key):
+    from packppi_amd.batch import Batch
+    z = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
+    b = Batch()
+    for k in z.files:
+        if k.startswith("batch."):
+            key = k[6:]
+            b[key] = int(z[k]) if key in ("num_proteins", "max_size") else torch.from_numpy(z[k])
+    return b, torch.from_numpy(z[init_key]), torch.from_numpy(z["chi_ode_100"])
 
 
 def load_t1124():
-    from packppi_amd.batch import Batch
-    z = np.load(os.path.join(ROOT, "tests", "golden", "g4_T1124.npz"))
-    b = Batch()
-    for k in z.files:
-        if k.startswith("batch."):
-            key = k[6:]
-            b[key] = int(z[k]) if key in ("num_proteins", "max_size") else torch.from_numpy(z[k])
-    return b, torch.from_numpy(z["init_chi_seed1124"]), torch.from_numpy(z["chi_ode_100"])
+    return _load_fixture("g4_T1124", "init_chi_seed1124")
 
 
 def load_s1500():
-    """The 1500-residue synthetic complex with the reference's own 100-step output on the same noise, if the fixture
-    is present (tests/golden/g5_S1500.npz, tools/oracle/make_golden.py --only g5)."""
-    from packppi_amd.batch import Batch
-    path = os.path.join(ROOT, "tests", "golden", "g5_S1500.npz")
-    if not os.path.exists(path):
-        return None
-    z = np.load(path)
-    b = Batch()
-    for k in z.files:
-        if k.startswith("batch."):
-            key = k[6:]
-            b[key] = int(z[k]) if key in ("num_proteins", "max_size") else torch.from_numpy(z[k])
-    return b, torch.from_numpy(z["init_chi_seed1500"]), torch.from_numpy(z["chi_ode_100"])
+    """The 1500-residue synthetic complex with the reference's own 100-step output on the same noise
+    (tests/golden/g5_S1500.npz, tools/oracle/make_golden.py --only g5)."""
+    return _load_fixture("g5_S1500", "init_chi_seed1500")
 
 
-def synth_workload(kind, rank):
+def c5_complexes(rank, dev):
+    """This rank's 32 of BASELINE config 4's 256 synthetic complexes (L ~ U{270..330}, default_rng(256), seeds 10000 + i)."""
     from packppi_amd import synth
-    from packppi_amd.batch import collate
-    from packppi_amd.featurize import protein_to_batch, protein_to_data
-    if kind == "s1500":
-        return protein_to_batch(synth.make_complex(1500, 1500))
+    from packppi_amd.featurize import protein_to_batch
     lens = synth.c5_lengths(256)
-    mine = list(range(rank * 32, rank * 32 + 32))
-    return collate([protein_to_data(synth.make_complex(lens[i], 10000 + i)) for i in mine])
+    ids = [(rank * 32 + k) % 256 for k in range(32)]
+    return [protein_to_batch(synth.make_complex(lens[i], 10000 + i)).to(dev) for i in ids]
 
 
-def cpu_baseline(batch, init, weights, n_sample_steps):
+def cpu_baseline(batch, init, weights, n_sample_steps, n_grad_steps):
     """Oracle (CPU port of the reference algorithm, recomputing the graph every step like the reference) on a
-    bounded sample of the same workload; extrapolated linearly to 100 diffusion steps."""
+    bounded sample of the same workload; extrapolated linearly to 100 diffusion steps.  `value` is the torch.no_grad
+    figure (what the >= 50x target is judged against); `as_shipped` repeats it with autograd recording, which
+    is how eval_diffusion.py:62 calls sampling()."""
     from oracle import ref_cpu as O
     # the GPU box gives one GPU a 16-core CPU share; torch's default (all 128 hardware threads) oversubscribes
     # these small ops and is ~6x slower
     cores = min(16, os.cpu_count() or 1)
     torch.set_num_threads(cores)
-    sched = torch.linspace(1, 0, N_DIFFUSION_STEPS + 1)[: n_sample_steps + 1]
+    sched = torch.linspace(1, 0, N_DIFFUSION_STEPS + 1)
+    res = batch.true_residues()
     with torch.no_grad():
         O.sampling(weights, batch, init, sched[:2], hoist=False)          # warm-up
         t0 = time.perf_counter()
-        O.sampling(weights, batch, init, sched, hoist=False)
+        O.sampling(weights, batch, init, sched[: n_sample_steps + 1], hoist=False)
         dt = time.perf_counter() - t0
-    res = batch.true_residues()
-    per100 = dt / n_sample_steps * N_DIFFUSION_STEPS
-    return {"value": res / per100, "unit": "residues/s", "cores": cores, "kind": "port",
-            "sample": f"{n_sample_steps} of {N_DIFFUSION_STEPS} diffusion steps of the same complex under "
-                      f"torch.no_grad, graph recomputed per step as the reference does; {dt:.1f} s measured, "
-                      f"scaled x{N_DIFFUSION_STEPS / n_sample_steps:g}"}
+    out = {"value": res / (dt / n_sample_steps * N_DIFFUSION_STEPS), "unit": "residues/s", "cores": cores, "kind": "port",
+           "sample": f"{n_sample_steps} of {N_DIFFUSION_STEPS} diffusion steps of the same complex under "
+                     f"torch.no_grad, graph recomputed per step as the reference does; {dt:.1f} s measured, "
+                     f"scaled x{N_DIFFUSION_STEPS / n_sample_steps:g}"}
+    if n_grad_steps > 0:
+        wg = {k: v.clone().requires_grad_(True) for k, v in weights.items()}       # nn.Parameters, no torch.no_grad
+        x = init
+        t0 = time.perf_counter()
+        for j in range(n_grad_steps):
+            x = O.sampling(wg, batch, x, sched[j: j + 2], hoist=False).detach()   # the reference's step() is @no_grad
+        dtg = time.perf_counter() - t0
+        out["as_shipped"] = {"value": res / (dtg / n_grad_steps * N_DIFFUSION_STEPS), "unit": "residues/s",
+                             "sample": f"{n_grad_steps} steps with autograd recording (eval_diffusion.py:62 calls sampling() "
+                                       f"without torch.no_grad); {dtg:.1f} s measured, scaled x{N_DIFFUSION_STEPS / n_grad_steps:g}"}
+    return out
 
 
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed PMC summary of this same command (tools/profile/run_profiles.sh;
-    counters cannot be read from inside the process).  None when no summary is committed."""
-    import glob
-    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_traffic.json")))
-    if not files:
-        return None
+    counters cannot be read from inside the process): profiles/<PROFILE_TAG>_pmc_traffic.json.  None when it is absent."""
+    path = os.path.join(ROOT, "profiles", PROFILE_TAG + "_pmc_traffic.json")
     try:
-        return json.load(open(files[-1]))["kernels"][kernel]["hbm_bytes"]
-    except (KeyError, ValueError):
+        return json.load(open(path))["kernels"][kernel]["hbm_bytes"]
+    except (OSError, KeyError, ValueError):
         return None
+
+
+def spawn_ranks(n):
+    """python bench.py --gpus N by hand: start N ranks (one per GPU) through torch.distributed.run as a CHILD process.
+    Nothing in this process has touched the GPU yet (import torch does not), so no initialised process is replaced."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -109,15 +135,21 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="t1124", choices=["t1124", "s1500", "c5"])
-    ap.add_argument("--proximal", action="store_true", help="add the 50-step proximal optimisation (configs[2])")
+    ap.add_argument("--proximal", action="store_true", help="add the 50-step proximal optimisation (configs[2] / configs[3])")
     ap.add_argument("--cpu-steps", type=int, default=20, help="diffusion steps of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-grad-steps", type=int, default=2, help="steps of the autograd-on CPU sample (0 = skip)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the configs[4] share (c5) figure")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: one rank per GPU (torch.distributed.run --nproc-per-node {args.gpus})")
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -133,46 +165,42 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
+    from packppi_amd.lib import Context
     from packppi_amd.module import TDiffusionModule
     from packppi_amd.weights import make_random_state_dict
     weights = make_random_state_dict(20251003)
-    ref_chi = None
-    if args.workload == "t1124":
-        batch, init, ref_chi = load_t1124()
-        name = "data/T1124_lig.pdb (L=739, 738 true residues), 1 complex per GPU"
-    else:
-        batch = synth_workload(args.workload, rank)
-        init = None
-        if args.workload == "s1500" and load_s1500() is not None:      # same complex, with the reference's output
-            batch, init, ref_chi = load_s1500()
-        name = {"s1500": "synthetic 1500-residue 2-chain complex (default_rng(1500)), 1 per GPU",
-                "c5": "32 synthetic complexes L~U{270..330} per GPU (default_rng(256))"}[args.workload]
-    residues = batch.true_residues()
     model = TDiffusionModule(weights, device=dev)
     model.schedule = torch.linspace(1, 0, N_DIFFUSION_STEPS + 1)
-    gb = batch.to(dev)
-    if init is None:
-        torch.manual_seed(1000 + rank)
-        init_d, _ = model.add_sc_noise(gb, torch.ones(batch.residue_type.numel(), device=dev))
-        init = init_d.cpu()
+    ref_chi, complexes = None, None
+    if args.workload == "c5":
+        complexes = c5_complexes(rank, dev)
+        residues = sum(c.true_residues() for c in complexes)
+        name = "32 synthetic complexes L~U{270..330} per GPU (default_rng(256)), one packed ragged batch"
+        g = torch.Generator().manual_seed(1000 + rank)
+        inits = {i: (torch.rand(1, int(c["max_size"]), 4, generator=g) * 2 - 1) * np.pi * c.SC_D_mask.cpu()
+                 for i, c in enumerate(complexes)}
+
+        def one_pass():
+            if args.proximal:
+                raise SystemExit("--proximal with --workload c5: use the per-complex workloads")
+            return sample_sharded_local(model, complexes, inits)
     else:
-        init_d = init.to(dev)
-    ctx = model._context(gb)
+        batch, init, ref_chi = load_t1124() if args.workload == "t1124" else load_s1500()
+        name = {"t1124": "data/T1124_lig.pdb (L=739, 738 true residues), 1 complex per GPU",
+                "s1500": "synthetic 1500-residue 2-chain complex (default_rng(1500)), 1 per GPU"}[args.workload]
+        residues = batch.true_residues()
+        gb, init_d = batch.to(dev), init.to(dev)
+        ctx = model._context(gb)
 
-    # One timed pass = what TDiffusionModule.sampling() costs on a batch it has not seen: the per-complex preparation
-    # (kNN graph, frames, edge embedding, layer-0 static products: pp_complex_prepare, a fresh context) + 100 evaluations.
-    from packppi_amd.lib import Context
-
-    def one_pass():
-        chi = Context(model._plan, gb).sample(init_d, model.schedule)
-        if args.proximal:
-            from packppi_amd.functional import proximal_optimizer
-            chis, losses = proximal_optimizer(gb, chi, 12.0, 0.5, 1.0, 50)
-            chi = chis[-1] if losses[-1] < losses[0] else chi
-        return chi
-
-    for _ in range(args.warmup):
-        chi = one_pass()
+        # One timed pass = what TDiffusionModule.sampling() costs on a batch it has not seen: the per-complex preparation
+        # (kNN graph, frames, edge embedding, layer-0 static products: pp_complex_prepare, a fresh context) + 100 evaluations.
+        def one_pass():
+            chi = Context(model._plan, gb).sample(init_d, model.schedule)
+            if args.proximal:
+                from packppi_amd.functional import proximal_optimizer
+                chis, losses = proximal_optimizer(gb, chi, 12.0, 0.5, 1.0, 50)
+                chi = chis[-1] if losses[-1] < losses[0] else chi
+            return chi
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -180,62 +208,136 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        chi = one_pass()
-    fence()
-    elapsed = time.perf_counter() - t0
-    total_res = residues
-    if dist is not None:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-        rr = torch.tensor([residues], device=dev, dtype=torch.float64)
-        dist.all_reduce(rr, op=dist.ReduceOp.SUM)
-        total_res = int(rr.item())
+    def timed(fn, steps, warmup):
+        out = None
+        for _ in range(warmup):
+            out = fn()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = fn()
+        fence()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            tt = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        return el, out
 
-    # per-complex metric row (the one real collective of the path: RCCL all-gather of metric rows)
-    m = model.analyze_samples(gb, chi)
-    row = torch.stack([torch.as_tensor(float(v), device=dev) for v in m.values()]).float()
+    def allsum(v):
+        if dist is None:
+            return v
+        t = torch.tensor([v], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return int(t.item())
+
+    elapsed, chi = timed(one_pass, args.steps, args.warmup)
+    total_res = allsum(residues)
+
+    # per-complex metric rows: the one real collective of the path (RCCL all-gather of fixed-width rows)
+    if complexes is None:
+        m = model.analyze_samples(gb, chi)
+        row = torch.stack([torch.as_tensor(float(v), device=dev) for v in m.values()]).float()
+        atom_rmsd = float(m["atom_rmsd"])
+    else:
+        from packppi_amd.batch import pack, unpack
+        from packppi_amd.parallel import metrics_to_row
+        first = unpack(pack(complexes), chi)[0]
+        m = model.analyze_samples(complexes[0], first)
+        row, atom_rmsd = metrics_to_row(m).to(dev), float(m["atom_rmsd"])
     rows = [row]
     if dist is not None:
         rows = [torch.empty_like(row) for _ in range(world)]
         dist.all_gather(rows, row)
+    ranks_seen = len(rows)
     max_dchi = None
     if ref_chi is not None and not args.proximal:
         d = (chi.cpu().double() - ref_chi.double()).abs()
         d = torch.minimum(d, (2 * np.pi - d).abs())[batch.SC_D_mask.bool()]
         max_dchi = float(d.max())
 
-    # dominant-kernel roofline, measured live: one more pass of the same workload with every launch of the kernel
-    # bracketed by HIP events on the launch stream (pp_profile_kernel).  Back-to-back launches of the edge kernel alone
-    # (pp_time_kernel) run ~10 % slower than in situ (sustained-MFMA clocks), so they are reported only as a cross-check.
-    insitu = {}
-    for which, kname in ((1, "k_edge_update"), (0, "k_node_message"), (2, "k_node_update")):
-        ctx.profile_kernel(which)
-        ctx.sample(init_d, model.schedule)
-        insitu[kname] = ctx.profile_read()
-    t_edge = insitu["k_edge_update"][0] * 1e-3
-    t_node = insitu["k_node_message"][0] * 1e-3
-    t_edge_b2b = ctx.time_kernel(1, 20) * 1e-3
-    n_edges = residues * ctx.K
-    # k_edge_update(l) also computes the node message of layer l + 1 (fused): its algorithmic work is both MLP chains
-    # of the reference (layers.py:119-148), 2 FLOP per MAC of the dense layers, per edge.  Executed MFMA work is lower:
-    # layer 0's W_B h_E0 products are timestep-invariant and computed once per complex.
-    fused_flop_per_edge = EDGE_UPDATE_FLOP_PER_EDGE + NODE_MSG_FLOP_PER_EDGE
-    achieved = fused_flop_per_edge * n_edges / t_edge / 1e12
-    # which edge kernels the library was built with: 1 = split-f16 (default), 0 = exact fp32 (PACKPPI_EDGE=f32)
-    from packppi_amd import lib as _lib
-    split_f16 = _lib.load().pp_edge_variant() == 1
-    if split_f16:
-        # 342 (layer 1) / 318 (layer 0) v_mfma_f32_32x32x16_f16 per residue and launch, 32768 FLOP each: every fp32
-        # product is three f16 products (hi hi + hi lo + lo hi)
-        executed_mfma = 0.5 * (342 + 318) * 32768.0 * residues
-        peak, dtype = F16_MFMA_PEAK_TFLOPS, "f32 (dense layers as split-f16: two f16 per operand, three f16 MFMAs per product, fp32 accumulate)"
-    else:
-        executed_mfma = (2960 + 656 - 128) * 4096.0 * residues    # average of the layer-0 and layer-1 launches
-        peak, dtype = FP32_MFMA_PEAK_TFLOPS, "f32"
+    # secondary figure: BASELINE configs[4]'s per-GPU share through the packed multi-complex path
+    secondary = None
+    if complexes is None and not args.no_secondary and not args.proximal:
+        c5 = c5_complexes(rank, dev)
+        g = torch.Generator().manual_seed(1000 + rank)
+        c5_init = {i: (torch.rand(1, int(c["max_size"]), 4, generator=g) * 2 - 1) * np.pi * c.SC_D_mask.cpu()
+                   for i, c in enumerate(c5)}
+        el5, _ = timed(lambda: sample_sharded_local(model, c5, c5_init), 3, 1)
+        res5 = allsum(sum(c.true_residues() for c in c5))
+        secondary = {"workload": "BASELINE configs[4] share: 32 synthetic complexes L~U{270..330} per GPU as one packed ragged "
+                                 "batch (no padding rows), 100 steps, no proximal",
+                     "value": res5 * 3 / el5, "unit": "residues/s", "ms_per_step": el5 / 3 * 1e3, "residues": res5,
+                     "complexes": 32 * world}
+
+    # kernel roofline, measured live: one more pass of the same workload in which every launch of the kernel carries a
+    # start / stop HIP event pair on the launch stream (pp_profile_kernel -> hipExtLaunchKernelGGL: the dispatch's own
+    # begin and end), the interval rocprofv3's kernel trace of this command reports (profiles/<PROFILE_TAG>_kernel_stats.csv).
+    roof = None
+    if complexes is None:
+        insitu = {}
+        for which, kname in ((1, "k_edge_update"), (0, "k_node_message"), (2, "k_node_update")):
+            ctx.profile_kernel(which)
+            ctx.sample(init_d, model.schedule)
+            insitu[kname] = ctx.profile_read()
+        t_edge = insitu["k_edge_update"][0] * 1e-3
+        t_node = insitu["k_node_message"][0] * 1e-3
+        t_nu = insitu["k_node_update"][0] * 1e-3
+        n_edges = residues * ctx.K
+        # k_edge_update(l) also computes the node message of layer l + 1 (fused): its algorithmic work is both MLP chains
+        # of the reference (layers.py:119-148), 2 FLOP per MAC of the dense layers, per edge.  Executed MFMA work is lower:
+        # layer 0's W_B h_E0 products are timestep-invariant and computed once per complex.
+        fused_flop_per_edge = EDGE_UPDATE_FLOP_PER_EDGE + NODE_MSG_FLOP_PER_EDGE
+        achieved = fused_flop_per_edge * n_edges / t_edge / 1e12
+        from packppi_amd import lib as _lib
+        split_f16 = _lib.load().pp_edge_variant() == 1      # 1 = split-f16 (default), 0 = exact fp32 (PACKPPI_EDGE=f32)
+        if split_f16:
+            # every WAVE of a workgroup issues 342 (layer 1) / 318 (layer 0) v_mfma_f32_32x32x16_f16 per launch (SQ_INSTS_MFMA /
+            # residues = 4 x that, profiles/*_sq_counters.txt), 32768 FLOP each; every fp32 product is three f16 products
+            executed_mfma = 4 * 0.5 * (342 + 318) * 32768.0 * residues
+            peak, dtype = F16_MFMA_PEAK_TFLOPS, "f32 (dense layers as split-f16: two f16 per operand, three f16 MFMAs per product, fp32 accumulate)"
+        else:
+            executed_mfma = (2960 + 656 - 128) * 4096.0 * residues    # average of the layer-0 and layer-1 launches
+            peak, dtype = FP32_MFMA_PEAK_TFLOPS, "f32"
+        whole = 46792576.0 * total_res * N_DIFFUSION_STEPS * args.steps / elapsed / 1e12 / max(args.gpus, 1)
+        roof = {"bound": "mfma", "kernel": "k_edge_update", "achieved": achieved,
+                "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                "peak_is": "dense F16 MFMA (the pipe the kernel runs on)" if split_f16 else "FP32 matrix",
+                "limiter": "not the pipe: SQ counters put the MFMA pipe at ~30 % busy; the kernel is bound by instruction issue "
+                           "and latency around the MFMAs (the per-workgroup weight stream, LDS exchanges, LayerNorms); `bound` "
+                           "names the roofline that would bind at the limit",
+                "achieved_is": "the reference's fp32 dense-layer arithmetic (2 FLOP per MAC) per second; the kernel "
+                               "issues 3 f16 MFMAs per product, see executed_mfma_tflops",
+                "achieved_over_fp32_matrix_peak": achieved / FP32_MFMA_PEAK_TFLOPS,
+                "edge_kernels": "split-f16" if split_f16 else "fp32",
+                "traffic": pmc_traffic("k_edge_update") if args.workload == "t1124" else None,
+                "traffic_unit": f"HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes of this "
+                                f"command; profiles/{PROFILE_TAG}_pmc_traffic.json)",
+                "kernel_ms": t_edge * 1e3,
+                "kernel_ms_is": "mean begin-to-end interval of the dispatches inside the sampling loop (start/stop HIP events attached to each launch)",
+                "kernel_does": "edge update of layer l + node message of layer l+1, one launch",
+                "algorithmic_flop_per_launch": fused_flop_per_edge * n_edges,
+                "executed_mfma_tflops": executed_mfma / t_edge / 1e12,
+                # whole pass against SURVEY 8(d): 46 792 576 algorithmic FLOP per residue per network evaluation
+                "whole_pass_algorithmic_tflops": whole,
+                "whole_pass_frac_of_peak": whole / FP32_MFMA_PEAK_TFLOPS,
+                "kernel_launches_timed": insitu["k_edge_update"][1],
+                "node_message_kernel_ms": t_node * 1e3,
+                "node_message_layer0_tflops": NODE_MSG_FLOP_PER_EDGE * n_edges / t_node / 1e12,
+                # second kernel: the node update (mean over its three launches per evaluation)
+                "node_update": {
+                    "kernel": "k_node_update", "kernel_ms": t_nu * 1e3, "launches_timed": insitu["k_node_update"][1],
+                    "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                    "algorithmic_bytes_per_launch": residues * (2 * 512 + 5 * 512 + 2 * 192 + 16) + NODE_UPDATE_STREAM_BYTES,
+                    "achieved": (residues * (2 * 512 + 5 * 512 + 2 * 192 + 16) + NODE_UPDATE_STREAM_BYTES) / t_nu / 1e9,
+                    "frac": (residues * (2 * 512 + 5 * 512 + 2 * 192 + 16) + NODE_UPDATE_STREAM_BYTES) / t_nu / 1e9 / HBM_PEAK_GBS,
+                    "algorithmic_tflops": NODE_UPDATE_FLOP_PER_RES * residues / t_nu / 1e12,
+                    "limiter": "neither HBM nor the matrix pipe: (residues / 16) workgroups each pull the layer's whole "
+                               "packed weight set through ONE CU's vector-memory path, the launch lasts as long as one CU "
+                               "needs for that stream plus launch and input latency",
+                    "weight_stream_bytes_per_workgroup": NODE_UPDATE_STREAM_BYTES,
+                    "weight_stream_GBs_per_CU_lower_bound": NODE_UPDATE_STREAM_BYTES / t_nu / 1e9,
+                    "CU_vector_memory_peak_GBs": CU_VMEM_PEAK_GBS}}
 
     if rank == 0:
         out = {
@@ -245,43 +347,35 @@ def main():
             "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": dtype, "data": "synthetic (seeded random weights; T1124 backbone fixture, seeded initial noise)"
+            "dtype": "f32 (dense layers as split-f16: two f16 per operand, three f16 MFMAs per product, fp32 accumulate)",
+            "data": "synthetic (seeded random weights; T1124 backbone fixture, seeded initial noise)"
             if args.workload == "t1124" else "synthetic",
             "config": {"workload": name, "diffusion_steps": N_DIFFUSION_STEPS, "proximal": bool(args.proximal),
                        "residues_per_gpu": residues, "mode": "ode"},
-            "roofline": {"bound": "mfma", "kernel": "k_edge_update", "achieved": achieved,
-                         "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "peak_is": "dense F16 MFMA (the pipe the kernel runs on)" if split_f16 else "FP32 matrix",
-                         "achieved_is": "the reference's fp32 dense-layer arithmetic (2 FLOP per MAC) per second; the kernel "
-                                        "issues 3 f16 MFMAs per product, see executed_mfma_tflops",
-                         "achieved_over_fp32_matrix_peak": achieved / FP32_MFMA_PEAK_TFLOPS,
-                         "edge_kernels": "split-f16" if split_f16 else "fp32",
-                         "traffic": pmc_traffic("k_edge_update") if args.workload == "t1124" else None,
-                         "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate --pmc "
-                                         "passes of this command; profiles/*_pmc_traffic.json)",
-                         "kernel_ms": t_edge * 1e3,
-                         "kernel_does": "edge update of layer l + node message of layer l+1, one launch",
-                         "algorithmic_flop_per_launch": fused_flop_per_edge * n_edges,
-                         "executed_mfma_tflops": executed_mfma / t_edge / 1e12,
-                         # whole pass against SURVEY 8(d): 46 792 576 algorithmic FLOP per residue per network evaluation
-                         "whole_pass_algorithmic_tflops": 46792576.0 * total_res * N_DIFFUSION_STEPS * args.steps / elapsed / 1e12
-                                                          / max(args.gpus, 1),
-                         "whole_pass_frac_of_peak": 46792576.0 * total_res * N_DIFFUSION_STEPS * args.steps / elapsed / 1e12
-                                                    / max(args.gpus, 1) / FP32_MFMA_PEAK_TFLOPS,
-                         "kernel_launches_timed": insitu["k_edge_update"][1],
-                         "kernel_ms_back_to_back": t_edge_b2b * 1e3,
-                         "node_update_kernel_ms": insitu["k_node_update"][0],
-                         "node_message_kernel_ms": t_node * 1e3,
-                         "node_message_layer0_tflops": NODE_MSG_FLOP_PER_EDGE * n_edges / t_node / 1e12},
-            "parity": {"max_abs_dchi_vs_reference_rad": max_dchi, "atom_rmsd": float(m["atom_rmsd"])},
-            "metrics_rows_gathered": len(rows),
+            "parity": {"max_abs_dchi_vs_reference_rad": max_dchi, "atom_rmsd": atom_rmsd},
+            "ranks_seen": ranks_seen, "metrics_rows_gathered": ranks_seen,
         }
-        if args.cpu_steps > 0 and args.gpus == 1:
-            out["cpu_baseline"] = cpu_baseline(batch, init, weights, args.cpu_steps)
+        if roof is not None:
+            out["dtype"] = dtype
+            out["roofline"] = roof
+        if secondary is not None:
+            out["secondary"] = secondary
+        if args.cpu_steps > 0 and args.gpus == 1 and complexes is None:
+            out["cpu_baseline"] = cpu_baseline(batch, init, weights, args.cpu_steps, args.cpu_grad_steps)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def sample_sharded_local(model, complexes, inits):
+    """The sampling part of parallel.sample_sharded for complexes this rank already owns (no metric gather): one packed
+    ragged batch, context prepared inside the timed pass like the single-complex workloads."""
+    from packppi_amd.batch import pack
+    from packppi_amd.lib import Context
+    pb = pack(complexes)
+    x0 = torch.cat([inits[i][:, : int(c["residue_mask"].sum())] for i, c in enumerate(complexes)], 1).to(model.device)
+    return Context(model._plan, pb).sample(x0, model.schedule)
 
 
 if __name__ == "__main__":

@@ -82,7 +82,9 @@ pp_status pp_plan_create(const float *weights, size_t n_weights, const pp_tables
 void pp_plan_destroy(pp_plan *plan);
 
 /* Replaces rc.make_atom14_dists_bounds(tol, vtf) as consumed by find_sc_violations
- * (clash.py:299-308): `lower`/`upper` are HOST [21,14,14] tables for these parameters. */
+ * (clash.py:299-308): `lower`/`upper` are HOST [21,14,14] tables for these parameters.  The tables are
+ * caller-owned and may be freed on return, so this call waits for `stream` and copies them synchronously
+ * (the one blocking call besides the measurement aids; it runs once per parameter set, not per batch). */
 pp_status pp_plan_set_clash_params(pp_plan *plan, float overlap_tolerance, const float *lower,
                                    const float *upper, void *stream);
 
@@ -97,8 +99,27 @@ pp_status pp_plan_set_clash_params(pp_plan *plan, float overlap_tolerance, const
 pp_status pp_complex_prepare(pp_plan *plan, const pp_batch *batch, void *stream, pp_ctx **ctx);
 void pp_ctx_destroy(pp_ctx *ctx);
 
+/* The same for complexes of different lengths WITHOUT the padding rows of collate_fn
+ * (complex_datamodule.py:196-226): the batch tensors are [1, sum of lengths, ...] with the complexes'
+ * rows back to back, `seg_offsets` (DEVICE, int32 [n_seg + 1], caller-owned like the batch) gives the first
+ * row of every complex and the total, min_len / max_len their shortest and longest length.  Neighbour
+ * search, clash partners and E_idx numbering stay inside each complex; every other stage is per row or per
+ * edge.  Results equal those of each complex prepared on its own (K = min(32, length): complexes shorter
+ * than 32 residues cannot be mixed with longer ones -> PP_ERR_UNSUPPORTED).  pp_proximal needs one complex
+ * per ctx. */
+pp_status pp_complex_prepare_packed(pp_plan *plan, const pp_batch *batch, const int32_t *seg_offsets, int n_seg,
+                                    int min_len, int max_len, void *stream, pp_ctx **ctx);
+
 /* Inspection (tests): copy out E_idx [B,L,K] and the embedded edges h_E0 [B,L,K,128]; K = min(32,L). */
 pp_status pp_ctx_get_graph(pp_ctx *ctx, int64_t *E_idx, float *hE0, void *stream);
+
+/* Replace the ctx's neighbour lists by the caller's E_idx [B,L,K] (per-complex numbering, as
+ * ProteinEncoder._dist returns them, encoder.py:105-118) and redo the edge embedding.  For callers who need
+ * the reference's own choice where torch.topk leaves it open: when two CA distances at rank K and K+1 are
+ * exactly equal, which of the two residues is a neighbour is unspecified in the reference (it differs between
+ * its CPU and GPU paths); this library's search takes the lower index.  Validates the indices (one
+ * read-back: the call waits for `stream`). */
+pp_status pp_ctx_set_graph(pp_ctx *ctx, const int64_t *E_idx, void *stream);
 
 /* Replaces TDiffusionModule.network(batch, SC_D_noised, t) (TorsionalDiffusion.py:90-109) for a
  * timestep shared by all residues.  score [B,L,4]; hV [B,L,128] may be NULL. */
@@ -106,7 +127,8 @@ pp_status pp_score(pp_ctx *ctx, const float *chi, float t, float *score, float *
 
 /* Replaces the loop of TDiffusionModule.sampling (TorsionalDiffusion.py:259-280):
  * chi [B,L,4] holds the initial noised angles on entry and the sample on exit.
- * `schedule` is a HOST array of n_schedule times (n_schedule-1 network evaluations).
+ * `schedule` is a HOST array of n_schedule times (n_schedule-1 network evaluations); it is read before the
+ * call returns, and the per-step scalars derived from it travel as kernel arguments (no staging copy, no wait).
  * mode PP_MODE_SDE needs `sde_noise` [n_schedule-1, 2, B*L, 4] (the two N(0,1) draws of
  * schedule.py:225 per step, 1pi schedule first); NULL is allowed for PP_MODE_ODE. */
 pp_status pp_sample(pp_ctx *ctx, float *chi, const float *schedule, int n_schedule, int mode,
@@ -133,10 +155,10 @@ pp_status pp_time_kernel(pp_ctx *ctx, int which, int iters, float *avg_ms, void 
 
 /* Measurement aid, no reference counterpart: in-situ duration of a hot kernel.  After
  * pp_profile_kernel(ctx, which) (0 node message, 1 edge update, 2 node update) every launch of that
- * kernel made by pp_score / pp_sample is bracketed by a pair of HIP events on the launch stream;
- * pp_profile_read waits for the last one, returns the summed intervals (ms) less the measured
- * interval of an empty event pair per launch, and the number of launches, and switches profiling
- * off again. */
+ * kernel made by pp_score / pp_sample carries a start / stop HIP event pair on the launch stream
+ * (hipExtLaunchKernelGGL: the dispatch's own begin and end, the interval rocprofv3's kernel trace reports);
+ * pp_profile_read waits for the last one, returns the summed intervals (ms) and the number of
+ * launches, and switches profiling off again. */
 pp_status pp_profile_kernel(pp_ctx *ctx, int which);
 pp_status pp_profile_read(pp_ctx *ctx, float *total_ms, int *launches);
 

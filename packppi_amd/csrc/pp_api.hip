@@ -418,7 +418,6 @@ extern "C" void pp_plan_destroy(pp_plan *p) {
     for (void *q : ptrs) if (q) (void)hipFree(q);
     for (const ArenaSlot &sl : p->arena_pool) {
         (void)hipFree(sl.p);
-        if (sl.steps_host) (void)hipHostFree(sl.steps_host);
     }
     delete p;
 }
@@ -445,21 +444,47 @@ extern "C" void pp_ctx_destroy(pp_ctx *c) {
         pp_plan *p = c->plan;
         std::lock_guard<std::mutex> g(p->pool_mutex);
         if (p->arena_pool.size() < 4) {
-            p->arena_pool.push_back({c->arena, c->arena_bytes, c->steps_host, c->last_stream});
-            c->steps_host = nullptr;
+            p->arena_pool.push_back({c->arena, c->arena_bytes, c->last_stream});
         } else {
             (void)hipFree(c->arena);
         }
     }
-    if (c->steps_host) (void)hipHostFree(c->steps_host);
     for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
     delete c;
 }
 
-extern "C" pp_status pp_complex_prepare(pp_plan *plan, const pp_batch *b, void *stream, pp_ctx **out) {
+// (first row, length) of the complex every row belongs to: a padded batch [B][L] ...
+__global__ void k_fill_seg(int2 *__restrict__ seg, int N, int L) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n < N) seg[n] = make_int2((n / L) * L, L);
+}
+// ... or complexes packed back to back, rows off[s] .. off[s + 1] - 1 (pp_complex_prepare_packed)
+__global__ void k_fill_seg_packed(int2 *__restrict__ seg, int N, const int32_t *__restrict__ off, int n_seg) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    int lo = 0, hi = n_seg - 1;                   // last s with off[s] <= n
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (off[mid] <= n) lo = mid; else hi = mid - 1;
+    }
+    seg[n] = make_int2(off[lo], off[lo + 1] - off[lo]);
+}
+
+static pp_status prepare_impl(pp_plan *plan, const pp_batch *b, const int32_t *seg_offsets, int n_seg, int min_len,
+                              int max_len, void *stream, pp_ctx **out) {
+    const bool packed = seg_offsets != nullptr;
     if (!plan || !b || !out) FAIL(PP_ERR_INVALID, "pp_complex_prepare: null argument");
     if (b->B <= 0 || b->L <= 0) FAIL(PP_ERR_INVALID, "pp_complex_prepare: B and L must be positive");
-    if (b->L > 16384) FAIL(PP_ERR_UNSUPPORTED, "pp_complex_prepare: L > 16384 residues per complex is not supported");
+    if ((packed ? max_len : b->L) > 16384) FAIL(PP_ERR_UNSUPPORTED, "pp_complex_prepare: L > 16384 residues per complex is not supported");
+    if (packed) {
+        if (b->B != 1) FAIL(PP_ERR_INVALID, "pp_complex_prepare_packed: the batch tensors are [1, sum of lengths, ...]");
+        if (n_seg < 1 || min_len < 1 || max_len < min_len || (long long)n_seg * min_len > b->L || (long long)n_seg * max_len < b->L)
+            FAIL(PP_ERR_INVALID, "pp_complex_prepare_packed: segment count / lengths do not fit the batch");
+        // K = min(32, L) is a per-batch constant of the reference (encoder.py:115): complexes shorter than 32 residues
+        // cannot share a context with longer ones
+        if (min_len < PP_TOP_K && min_len != max_len)
+            FAIL(PP_ERR_UNSUPPORTED, "pp_complex_prepare_packed: complexes shorter than 32 residues must be prepared on their own");
+    }
     if (!b->X || !b->residue_type || !b->BB_D)
         FAIL(PP_ERR_INVALID, "pp_complex_prepare: batch needs at least X, residue_type and BB_D");
     const bool net = plan->has_network;
@@ -471,8 +496,12 @@ extern "C" pp_status pp_complex_prepare(pp_plan *plan, const pp_batch *b, void *
     if (!c) FAIL(PP_ERR_INVALID, "out of host memory");      // value-initialised: every pointer null, prof_which = -1
     c->plan = plan;
     c->b = *b;
-    c->B = b->B; c->L = b->L; c->N = b->B * b->L;
-    c->K = b->L < PP_TOP_K ? b->L : PP_TOP_K;
+    c->packed = packed;
+    c->B = packed ? n_seg : b->B;
+    c->L = packed ? max_len : b->L;
+    c->N = b->B * b->L;
+    const int shortest = packed ? min_len : b->L;
+    c->K = shortest < PP_TOP_K ? shortest : PP_TOP_K;
     const size_t N = c->N, K = c->K;
     pp_status st = PP_OK;
     // one arena for all workspaces (a context per batch is created and destroyed on the sampling path: ~35 hipMalloc /
@@ -492,8 +521,8 @@ extern "C" pp_status pp_complex_prepare(pp_plan *plan, const pp_batch *b, void *
     ALLOC(xyz, N * 42); ALLOC(rec, N * 64); ALLOC(axes, N * 24); ALLOC(brad, N); ALLOC(per_res, N); ALLOC(dchi, N * 4);
     ALLOC(px, N * 4); ALLOC(pm, N * 4); ALLOC(pv, N * 4); ALLOC(pz, N * 4); ALLOC(pxeff, N * 4); ALLOC(pmask, N);
     ALLOC(scal, 64);
-    c->max_steps = 1024;
-    if (net) { ALLOC(steps, (size_t)c->max_steps); }
+    ALLOC(seg, N);
+    c->max_steps = 1 << 20;
 #undef ALLOC
     c->last_stream = static_cast<hipStream_t>(stream);
     {
@@ -507,7 +536,6 @@ extern "C" pp_status pp_complex_prepare(pp_plan *plan, const pp_batch *b, void *
             if (sl.stream != c->last_stream) (void)hipStreamSynchronize(sl.stream);
             c->arena = sl.p;
             c->arena_bytes = sl.bytes;
-            c->steps_host = sl.steps_host;
         }
     }
     if (!c->arena && hipMalloc(&c->arena, total) != hipSuccess) {
@@ -519,9 +547,11 @@ extern "C" pp_status pp_complex_prepare(pp_plan *plan, const pp_batch *b, void *
         char *base = static_cast<char *>(c->arena);
         for (const Slot &sl : slots) { *sl.p = base; base += sl.bytes; }
     }
-    if (net && st == PP_OK && !c->steps_host && hipHostMalloc(reinterpret_cast<void **>(&c->steps_host), c->max_steps * sizeof(StepParams)) != hipSuccess) {
-        pp_set_error("hipHostMalloc failed");
-        st = PP_ERR_HIP;
+    if (st == PP_OK) {
+        hipStream_t s_ = static_cast<hipStream_t>(stream);
+        if (packed) hipLaunchKernelGGL(k_fill_seg_packed, dim3((c->N + 255) / 256), dim3(256), 0, s_, c->seg, c->N, seg_offsets, n_seg);
+        else hipLaunchKernelGGL(k_fill_seg, dim3((c->N + 255) / 256), dim3(256), 0, s_, c->seg, c->N, c->L);
+        if (hipGetLastError() != hipSuccess) { pp_set_error("segment table launch failed"); st = PP_ERR_HIP; }
     }
     if (net && st == PP_OK) st = pp_launch_prepare(c, static_cast<hipStream_t>(stream));
     if (net && st == PP_OK) st = pp_launch_edge_static(c, static_cast<hipStream_t>(stream));
@@ -530,12 +560,21 @@ extern "C" pp_status pp_complex_prepare(pp_plan *plan, const pp_batch *b, void *
     return PP_OK;
 }
 
-__global__ void k_widen_idx(const int32_t *__restrict__ src, int64_t *__restrict__ dst, size_t n, int L, int K) {
+extern "C" pp_status pp_complex_prepare(pp_plan *plan, const pp_batch *b, void *stream, pp_ctx **out) {
+    return prepare_impl(plan, b, nullptr, 0, 0, 0, stream, out);
+}
+
+extern "C" pp_status pp_complex_prepare_packed(pp_plan *plan, const pp_batch *b, const int32_t *seg_offsets, int n_seg,
+                                               int min_len, int max_len, void *stream, pp_ctx **out) {
+    if (!seg_offsets) FAIL(PP_ERR_INVALID, "pp_complex_prepare_packed: null segment offsets");
+    return prepare_impl(plan, b, seg_offsets, n_seg, min_len, max_len, stream, out);
+}
+
+__global__ void k_widen_idx(const int32_t *__restrict__ src, int64_t *__restrict__ dst, size_t n, const int2 *__restrict__ seg, int K) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
         size_t node = i / K;
-        int b = (int)(node / L);
-        dst[i] = (int64_t)src[i] - (int64_t)b * L;      // back to the per-complex residue numbering of the reference
+        dst[i] = (int64_t)src[i] - (int64_t)seg[node].x;      // back to the per-complex residue numbering of the reference
     }
 }
 
@@ -544,9 +583,25 @@ extern "C" pp_status pp_ctx_get_graph(pp_ctx *c, int64_t *E_idx, float *hE0, voi
     if (!c->plan->has_network) FAIL(PP_ERR_INVALID, "pp_ctx_get_graph: plan was created without network weights");
     hipStream_t s = static_cast<hipStream_t>(stream);
     size_t n = (size_t)c->N * c->K;
-    if (E_idx) hipLaunchKernelGGL(k_widen_idx, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, c->eidx, E_idx, n, c->L, c->K);
+    if (E_idx) hipLaunchKernelGGL(k_widen_idx, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, c->eidx, E_idx, n, c->seg, c->K);
     if (hE0) PP_HIP_CHECK(hipMemcpyAsync(hE0, c->hE0, n * 128 * sizeof(float), hipMemcpyDeviceToDevice, s));
     PP_HIP_CHECK(hipGetLastError());
+    return PP_OK;
+}
+
+extern "C" pp_status pp_ctx_set_graph(pp_ctx *c, const int64_t *E_idx, void *stream) {
+    if (c) c->last_stream = static_cast<hipStream_t>(stream);
+    if (!c || !E_idx) FAIL(PP_ERR_INVALID, "pp_ctx_set_graph: null argument");
+    if (!c->plan->has_network) FAIL(PP_ERR_INVALID, "pp_ctx_set_graph: plan was created without network weights");
+    PP_HIP_CHECK(hipSetDevice(c->plan->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    pp_status st = pp_launch_prepare(c, s, E_idx);
+    if (st == PP_OK) st = pp_launch_edge_static(c, s);
+    if (st != PP_OK) return st;
+    int bad = 0;          // inspection-grade call: it validates the indices, which needs one read-back
+    PP_HIP_CHECK(hipMemcpyAsync(&bad, c->scal, sizeof(int), hipMemcpyDeviceToHost, s));
+    PP_HIP_CHECK(hipStreamSynchronize(s));
+    if (bad) FAIL(PP_ERR_INVALID, "pp_ctx_set_graph: " + std::to_string(bad) + " neighbour indices outside their complex");
     return PP_OK;
 }
 
@@ -576,42 +631,44 @@ static void fill_step(StepParams *sp, float t, float dt) {
     sp->c_diff = g * sqrtf(dt);
 }
 
-// RAII-less bracket for pp_profile_kernel: records an event on `s` when kernel class `which` is being profiled.
-static inline void prof_mark(pp_ctx *c, int which, hipStream_t s) {
-    if (c->prof_which != which) return;
-    if (c->prof_n == c->prof_ev.size()) {
+// pp_profile_kernel: arm the launch of kernel class `which` that follows (the launcher's PP_LAUNCH takes the event pair)
+static inline void prof_arm(pp_ctx *c, int which) { c->prof_armed = c->prof_which == which; }
+static inline void prof_disarm(pp_ctx *c) { c->prof_armed = false; }
+bool pp_prof_take(pp_ctx *c, hipEvent_t *e0, hipEvent_t *e1) {
+    c->prof_armed = false;
+    while (c->prof_ev.size() < c->prof_n + 2) {
         hipEvent_t e;
-        if (hipEventCreate(&e) != hipSuccess) return;
+        if (hipEventCreate(&e) != hipSuccess) return false;
         c->prof_ev.push_back(e);
     }
-    (void)hipEventRecord(c->prof_ev[c->prof_n++], s);
-    c->prof_stream = s;
-    c->prof_stream_valid = true;
+    *e0 = c->prof_ev[c->prof_n++];
+    *e1 = c->prof_ev[c->prof_n++];
+    return true;
 }
 
 static pp_status run_network(pp_ctx *c, hipStream_t s, int step, int last_mode, float *chi, int mode, const float *noise,
-                             bool embed_next) {
+                             const StepParams *cur, const StepParams *next) {
     pp_status st;
     for (int l = 0; l < 3; l++) {
         if (l == 0 || !pp_edge_fused()) {   // fused build: layers 1 and 2 come from the tail of the previous edge update
-            prof_mark(c, 0, s);
+            prof_arm(c, 0);
             st = pp_launch_node_message(c, l, s);
-            prof_mark(c, 0, s);
+            prof_disarm(c);
             if (st != PP_OK) return st;
         }
         if (l < 2) {
-            prof_mark(c, 2, s);
-            st = pp_launch_node_update(c, l, PP_NU_MID, chi, step, mode, noise, false, s);
-            prof_mark(c, 2, s);
+            prof_arm(c, 2);
+            st = pp_launch_node_update(c, l, PP_NU_MID, chi, step, mode, noise, nullptr, nullptr, s);
+            prof_disarm(c);
             if (st != PP_OK) return st;
-            prof_mark(c, 1, s);
+            prof_arm(c, 1);
             st = pp_launch_edge_update(c, l, s);
-            prof_mark(c, 1, s);
+            prof_disarm(c);
             if (st != PP_OK) return st;
         } else {
-            prof_mark(c, 2, s);
-            st = pp_launch_node_update(c, l, last_mode, chi, step, mode, noise, last_mode == PP_NU_STEP && embed_next, s);
-            prof_mark(c, 2, s);
+            prof_arm(c, 2);
+            st = pp_launch_node_update(c, l, last_mode, chi, step, mode, noise, cur, last_mode == PP_NU_STEP ? next : nullptr, s);
+            prof_disarm(c);
             if (st != PP_OK) return st;
         }
     }
@@ -624,13 +681,11 @@ extern "C" pp_status pp_score(pp_ctx *c, const float *chi, float t, float *score
     if (!c->plan->has_network) FAIL(PP_ERR_INVALID, "pp_score: plan was created without network weights");
     hipStream_t s = static_cast<hipStream_t>(stream);
     PP_HIP_CHECK(hipSetDevice(c->plan->device));
-    // the staging slot may still be in flight from a previous call on this stream
-    PP_HIP_CHECK(hipStreamSynchronize(s));
-    fill_step(&c->steps_host[0], t, 0.f);
-    PP_HIP_CHECK(hipMemcpyAsync(c->steps, c->steps_host, sizeof(StepParams), hipMemcpyHostToDevice, s));
+    StepParams sp;
+    fill_step(&sp, t, 0.f);
     pp_status st;
-    if ((st = pp_launch_node_embed(c, chi, 0, s)) != PP_OK) return st;
-    if ((st = run_network(c, s, 0, PP_NU_SCORE, nullptr, PP_MODE_ODE, nullptr, false)) != PP_OK) return st;
+    if ((st = pp_launch_node_embed(c, chi, sp, s)) != PP_OK) return st;
+    if ((st = run_network(c, s, 0, PP_NU_SCORE, nullptr, PP_MODE_ODE, nullptr, &sp, nullptr)) != PP_OK) return st;
     PP_HIP_CHECK(hipMemcpyAsync(score, c->score, (size_t)c->N * 4 * sizeof(float), hipMemcpyDeviceToDevice, s));
     if (hV) PP_HIP_CHECK(hipMemcpyAsync(hV, c->hV, (size_t)c->N * 128 * sizeof(float), hipMemcpyDeviceToDevice, s));
     return PP_OK;
@@ -642,23 +697,23 @@ extern "C" pp_status pp_sample(pp_ctx *c, float *chi, const float *schedule, int
     if (!c || !chi || !schedule) FAIL(PP_ERR_INVALID, "pp_sample: null argument");
     if (!c->plan->has_network) FAIL(PP_ERR_INVALID, "pp_sample: plan was created without network weights");
     if (n_schedule < 2) FAIL(PP_ERR_INVALID, "pp_sample: schedule needs at least 2 times");
-    if (n_schedule - 1 > c->max_steps) FAIL(PP_ERR_UNSUPPORTED, "pp_sample: more than 1024 steps");
+    if (n_schedule - 1 > c->max_steps) FAIL(PP_ERR_UNSUPPORTED, "pp_sample: more than 2^20 steps");
     if (mode != PP_MODE_ODE && mode != PP_MODE_SDE) FAIL(PP_ERR_INVALID, "pp_sample: unknown mode");
     if (mode == PP_MODE_SDE && !sde_noise) FAIL(PP_ERR_INVALID, "pp_sample: sde mode needs the per-step noise tensor");
     hipStream_t s = static_cast<hipStream_t>(stream);
     PP_HIP_CHECK(hipSetDevice(c->plan->device));
     const int nsteps = n_schedule - 1;
-    PP_HIP_CHECK(hipStreamSynchronize(s));
-    for (int j = 0; j < nsteps; j++) fill_step(&c->steps_host[j], schedule[j], schedule[j] - schedule[j + 1]);
-    PP_HIP_CHECK(hipMemcpyAsync(c->steps, c->steps_host, (size_t)nsteps * sizeof(StepParams), hipMemcpyHostToDevice, s));
+    // per-step scalars are kernel arguments: nothing is staged, nothing waits for the stream
+    std::vector<StepParams> steps((size_t)nsteps);
+    for (int j = 0; j < nsteps; j++) fill_step(&steps[j], schedule[j], schedule[j] - schedule[j + 1]);
     pp_status st;
     // (A hipGraph replay of the loop was measured and dropped: with no stray event records in the stream the kernel
     // trace shows back-to-back dispatches, and capture + replay was 2 % slower than plain launches.)
-    if ((st = pp_launch_node_embed(c, chi, 0, s)) != PP_OK) return st;
+    if ((st = pp_launch_node_embed(c, chi, steps[0], s)) != PP_OK) return st;
     static const bool dbg = getenv("PP_DEBUG") != nullptr;
     const auto h0 = std::chrono::steady_clock::now();
     for (int j = 0; j < nsteps; j++) {
-        if ((st = run_network(c, s, j, PP_NU_STEP, chi, mode, sde_noise, j + 1 < nsteps)) != PP_OK) return st;
+        if ((st = run_network(c, s, j, PP_NU_STEP, chi, mode, sde_noise, &steps[j], j + 1 < nsteps ? &steps[j + 1] : nullptr)) != PP_OK) return st;
     }
     if (dbg) {
         const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - h0).count();
@@ -690,7 +745,7 @@ extern "C" pp_status pp_proximal(pp_ctx *c, const float *chi, float lamda, int n
                                  float *chi_last, float *losses, void *stream) {
     if (c) c->last_stream = static_cast<hipStream_t>(stream);
     if (!c || !chi || !losses) FAIL(PP_ERR_INVALID, "pp_proximal: null argument");
-    if (c->B != 1) FAIL(PP_ERR_INVALID, "pp_proximal: batch.num_proteins must be 1 (optimize.py:27)");
+    if (c->B != 1) FAIL(PP_ERR_INVALID, "pp_proximal: batch.num_proteins must be 1 (optimize.py:27); optimise the complexes of a packed or padded batch one by one");
     if (num_steps < 1) FAIL(PP_ERR_INVALID, "pp_proximal: num_steps must be >= 1");
     if (!c->plan->clash_params_set) FAIL(PP_ERR_INVALID, "pp_proximal: call pp_plan_set_clash_params first");
     if (!c->b.atom_mask || !c->b.residue_index) FAIL(PP_ERR_INVALID, "pp_proximal: batch lacks atom_mask / residue_index");
@@ -752,7 +807,8 @@ extern "C" pp_status pp_debug_buffer(pp_ctx *c, int which, float *dst, size_t n)
 }
 
 // Measurement aid (bench.py): in-situ duration of one hot kernel.  After pp_profile_kernel(ctx, which) every launch of
-// that kernel inside pp_score / pp_sample is bracketed by a pair of HIP events on the launch stream;
+// that kernel inside pp_score / pp_sample carries a start / stop HIP event pair (hipExtLaunchKernelGGL: the
+// dispatch's own begin and end timestamps);
 // pp_profile_read synchronises, sums the pair intervals, reports (total ms, launches) and switches profiling off.
 extern "C" pp_status pp_profile_kernel(pp_ctx *c, int which) {
     if (!c || which < 0 || which > 2) FAIL(PP_ERR_INVALID, "pp_profile_kernel: which must be 0 (node message), 1 (edge update) or 2 (node update)");
@@ -771,24 +827,6 @@ extern "C" pp_status pp_profile_read(pp_ctx *c, float *total_ms, int *launches) 
         float ms = 0.f;
         PP_HIP_CHECK(hipEventElapsedTime(&ms, c->prof_ev[2 * i], c->prof_ev[2 * i + 1]));
         tot += ms;
-    }
-    // the interval of an EMPTY event pair on the same stream is the bracket's own cost: measure and remove it
-    if (pairs && c->prof_stream_valid) {
-        hipEvent_t e[18];
-        int made = 0;
-        for (; made < 18; made++) if (hipEventCreate(&e[made]) != hipSuccess) break;
-        if (made == 18) {
-            for (int i = 0; i < 18; i++) (void)hipEventRecord(e[i], c->prof_stream);
-            (void)hipEventSynchronize(e[17]);
-            double empty = 0.0;
-            for (int i = 1; i < 9; i++) {            // first pair discarded (cold)
-                float ms = 0.f;
-                (void)hipEventElapsedTime(&ms, e[2 * i], e[2 * i + 1]);
-                empty += ms;
-            }
-            tot -= empty / 8.0 * (double)pairs;
-        }
-        for (int i = 0; i < made; i++) (void)hipEventDestroy(e[i]);
     }
     *total_ms = (float)tot;
     *launches = (int)pairs;

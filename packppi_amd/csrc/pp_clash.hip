@@ -186,7 +186,7 @@ k_atom14(int N, const float *__restrict__ X, const int64_t *__restrict__ rtype,
 #define CL_MAXC 2048     // candidate list capacity per wave (entries beyond are handled by re-scanning)
 
 __global__ void __launch_bounds__(64 * CL_WAVES)
-k_clash(int N, int L, const float *__restrict__ xyz, const float4 *__restrict__ rec, const float *__restrict__ exists,
+k_clash(int N, const int2 *__restrict__ seg, const float *__restrict__ xyz, const float4 *__restrict__ rec, const float *__restrict__ exists,
         const float *__restrict__ lower, const float *__restrict__ upper, const int32_t *__restrict__ a2g,
         const float *__restrict__ axes, float tol, float inv_ntot,
         float *__restrict__ per_res, float *__restrict__ dchi) {
@@ -195,7 +195,7 @@ k_clash(int N, int L, const float *__restrict__ xyz, const float4 *__restrict__ 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = blockIdx.x;              // one workgroup per residue; its waves take interleaved 64-partner windows
     if (i >= N) return;
-    const int b = i / L;
+    const int row0 = seg[i].x, L = seg[i].y;      // partner residues: the rows of this residue's own complex
     const int a = lane & 15, slot = lane >> 4;
     const bool own = a < 14;
     // rec[n] (written by k_atom14): 14 x (x, y, z, exists * radius) | (CA, bounding radius) | (n side-chain atoms,
@@ -230,7 +230,7 @@ k_clash(int N, int L, const float *__restrict__ xyz, const float4 *__restrict__ 
             int jl = jscan + lane;
             bool keep = false;
             if (jl < L) {
-                int jg = b * L + jl;
+                int jg = row0 + jl;
                 if (jg != i) {
                     const float4 cj = rec[(size_t)jg * 16 + 14];
                     const float4 mj = rec[(size_t)jg * 16 + 15];
@@ -240,7 +240,7 @@ k_clash(int N, int L, const float *__restrict__ xyz, const float4 *__restrict__ 
                 }
             }
             unsigned long long bal = __ballot(keep);
-            if (keep) list[cnt + __popcll(bal & ((1ull << lane) - 1ull))] = b * L + jl;
+            if (keep) list[cnt + __popcll(bal & ((1ull << lane) - 1ull))] = row0 + jl;
             cnt += __popcll(bal);
         }
         base = jscan;
@@ -446,7 +446,7 @@ pp_status pp_launch_atom14(pp_ctx *c, const float *chi, float *xyz, hipStream_t 
 
 pp_status pp_launch_clash(pp_ctx *c, const float *xyz, float *per_res, float *dchi, hipStream_t s) {
     const pp_plan *p = c->plan;
-    hipLaunchKernelGGL(k_clash, dim3(c->N), dim3(64 * CL_WAVES), 0, s, c->N, c->L, xyz,
+    hipLaunchKernelGGL(k_clash, dim3(c->N), dim3(64 * CL_WAVES), 0, s, c->N, c->seg, xyz,
                        reinterpret_cast<const float4 *>(c->rec), c->b.atom_mask,
                        p->bounds_lower, p->bounds_upper, p->atom14_to_group, c->axes, p->clash_tol,
                        1.0f / (float)c->N, per_res, dchi);

@@ -696,8 +696,8 @@ pp_status pp_launch_edge_static(pp_ctx *c, hipStream_t s) {
 pp_status pp_launch_node_message(pp_ctx *c, int layer, hipStream_t s) {
     EDGE_ATTR_CHECK()
     EdgeArgs A = edge_args(c, layer, false);
-    if (layer == 0) hipLaunchKernelGGL((k_node_message<PP_NM_SLOTS, true>), dim3(c->N), dim3(ET), NM_SMEM, s, A);
-    else hipLaunchKernelGGL((k_node_message<PP_NM_SLOTS, false>), dim3(c->N), dim3(ET), NM_SMEM, s, A);
+    if (layer == 0) PP_LAUNCH(c, (k_node_message<PP_NM_SLOTS, true>), dim3(c->N), dim3(ET), NM_SMEM, s, A);
+    else PP_LAUNCH(c, (k_node_message<PP_NM_SLOTS, false>), dim3(c->N), dim3(ET), NM_SMEM, s, A);
     PP_HIP_CHECK(hipGetLastError());
     return PP_OK;
 }
@@ -707,8 +707,8 @@ pp_status pp_launch_edge_update(pp_ctx *c, int layer, hipStream_t s) {
     EDGE_ATTR_CHECK()
     if (layer < 0 || layer > 1) { pp_set_error("pp_launch_edge_update: layer must be 0 or 1"); return PP_ERR_INVALID; }
     EdgeArgs A = edge_args(c, layer, true);
-    if (layer == 0) hipLaunchKernelGGL((k_edge_update<PP_EU_SLOTS, true, true>), dim3(c->N), dim3(ET), EU_SMEM, s, A);
-    else hipLaunchKernelGGL((k_edge_update<PP_EU_SLOTS, false, true>), dim3(c->N), dim3(ET), EU_SMEM, s, A);
+    if (layer == 0) PP_LAUNCH(c, (k_edge_update<PP_EU_SLOTS, true, true>), dim3(c->N), dim3(ET), EU_SMEM, s, A);
+    else PP_LAUNCH(c, (k_edge_update<PP_EU_SLOTS, false, true>), dim3(c->N), dim3(ET), EU_SMEM, s, A);
     PP_HIP_CHECK(hipGetLastError());
     return PP_OK;
 }

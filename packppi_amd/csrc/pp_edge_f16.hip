@@ -855,35 +855,6 @@ __device__ __forceinline__ float dist_eps_nc(const float *a, const float *b, flo
     s = s + dz * dz;
     return sqrtf(s + eps);
 }
-__device__ __forceinline__ void cross3_nc(const float *a, const float *b, float *o) {
-#pragma clang fp contract(off)
-    o[0] = a[1] * b[2] - a[2] * b[1];
-    o[1] = a[2] * b[0] - a[0] * b[2];
-    o[2] = a[0] * b[1] - a[1] * b[0];
-}
-__device__ __forceinline__ void unit_nan0_nc(float *v) {
-#pragma clang fp contract(off)
-    float n = sqrtf((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]);
-    for (int k = 0; k < 3; k++) {
-        float q = v[k] / n;
-        v[k] = (q != q) ? 0.f : q;
-    }
-}
-// sign * arccos(n1 . n2) with NaN -> 0 (encoder.py:164-174)
-__device__ float pair_dihedral_nc(const float *p0, const float *p1, const float *p2, const float *p3) {
-#pragma clang fp contract(off)
-    float u0[3], u1[3], u2[3], n1[3], n2[3], c12[3];
-    for (int k = 0; k < 3; k++) { u0[k] = p2[k] - p1[k]; u1[k] = p0[k] - p1[k]; u2[k] = p3[k] - p2[k]; }
-    cross3_nc(u0, u1, n1); unit_nan0_nc(n1);
-    cross3_nc(u0, u2, n2); unit_nan0_nc(n2);
-    cross3_nc(u1, u2, c12);
-    float sg = (c12[0] * u0[0] + c12[1] * u0[1]) + c12[2] * u0[2];
-    float sgn = (sg > 0.f) ? 1.f : ((sg < 0.f) ? -1.f : 0.f);
-    float dt = (n1[0] * n2[0] + n1[1] * n2[1]) + n1[2] * n2[2];
-    float ang = sgn * acosf(dt);
-    return (ang != ang) ? 0.f : ang;
-}
-
 // chunk C of the RBF block: k-steps (atom pairs) 2C and 2C+1 (the 26th is padding and skipped)
 template <int C>
 __device__ __forceinline__ void emb_step(const AOp &a, const float *gb, int lane, f32x16 &acc) {
@@ -967,11 +938,10 @@ k_edge_embed_f16(EmbedArgs A) {
         long off = (long)(A.res_index[n] - A.res_index[jn]) + 32;
         off = off < 0 ? 0 : (off > 64 ? 64 : off);
         const float etype = (A.chain[n] == A.chain[jn]) ? 2.f : 1.f;
-        float phi = 0.f, psi = 0.f;
-        if (jn != n) {     // the j == i edge is 0 by construction (self-edge dihedrals)
-            phi = pair_dihedral_nc(&s_pos[32][6], &s_pos[j][0], &s_pos[j][3], &s_pos[j][6]);
-            psi = pair_dihedral_nc(&s_pos[32][0], &s_pos[32][3], &s_pos[32][6], &s_pos[j][0]);
-        }
+        // phi_ij = dih(C_i, N_j, CA_j, C_j), psi_ij = dih(N_i, CA_i, C_i, N_j), rounded as the reference rounds them
+        // (pp_internal.h); the j == i edge included: its values are the reference's own arccos rounding noise
+        const float phi = pp_pair_dihedral_t(&s_pos[32][6], &s_pos[j][0], &s_pos[j][3], &s_pos[j][6]);
+        const float psi = pp_pair_dihedral_t(&s_pos[32][0], &s_pos[32][3], &s_pos[32][6], &s_pos[j][0]);
         load_tile(A.bias + 32 * wave, h, acc[0]);
         add_tile(A.WT + (size_t)off * 128 + 32 * wave, h, acc[0]);
         f32x16 w;
@@ -1145,7 +1115,7 @@ pp_status pp_launch_node_message(pp_ctx *c, int layer, hipStream_t s) {
     EDGE_ATTR_CHECK()
     EdgeArgs A = edge_args(c, layer, false);
     const int R = pick_R(c->N);
-    hipLaunchKernelGGL(nm_kernel_r(R, layer == 0), dim3((c->N + R - 1) / R), dim3(ET), nm_smem(R), s, A);
+    PP_LAUNCH(c, nm_kernel_r(R, layer == 0), dim3((c->N + R - 1) / R), dim3(ET), nm_smem(R), s, A);
     PP_HIP_CHECK(hipGetLastError());
     return PP_OK;
 }
@@ -1160,7 +1130,7 @@ pp_status pp_launch_edge_update(pp_ctx *c, int layer, hipStream_t s) {
     if (layer < 0 || layer > 1) { pp_set_error("pp_launch_edge_update: layer must be 0 or 1"); return PP_ERR_INVALID; }
     EdgeArgs A = edge_args(c, layer, true);
     const int R = pick_R(c->N);
-    hipLaunchKernelGGL(eu_kernel_r(R, layer == 0), dim3((c->N + R - 1) / R), dim3(ET), eu_smem(R), s, A);
+    PP_LAUNCH(c, eu_kernel_r(R, layer == 0), dim3((c->N + R - 1) / R), dim3(ET), eu_smem(R), s, A);
     PP_HIP_CHECK(hipGetLastError());
     return PP_OK;
 }

@@ -1,6 +1,7 @@
 // Internal declarations shared by the HIP translation units of libpackppi_hip.so (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <vector>
 #include <mutex>
 #include <stdint.h>
@@ -64,11 +65,9 @@ enum {
     NU_P_EMB_B = 1568, NU_P_EMB_G = 1696, NU_P_EMB_BETA = 1824, NU_P_LAST_TOTAL = 1952
 };
 
-struct StepParams;
 struct ArenaSlot {
     void *p;
     size_t bytes;
-    StepParams *steps_host;  // the pinned staging buffer travels with the arena (hipHostMalloc / hipHostFree are slow)
     hipStream_t stream;      // work on this stream may still be using the memory
 };
 struct pp_plan {
@@ -96,7 +95,7 @@ struct pp_plan {
     bool clash_params_set;
 };
 
-// Per-step scalars of the reverse process, computed on the host (schedule.py:198-235).
+// Per-step scalars of the reverse process, computed on the host (schedule.py:198-235) and handed to the kernels as arguments.
 struct StepParams {
     float temb[16];     // sinusoidal embedding of t
     float c_ode;        // 0.5 * g^2 * dt
@@ -109,7 +108,9 @@ struct StepParams {
 struct pp_ctx {
     pp_plan *plan;
     pp_batch b;               // caller-owned device pointers
-    int B, L, K, N;           // N = B*L nodes
+    int B, L, K, N;           // N = B*L nodes (packed context: B = number of complexes, L = longest, N = sum of lengths)
+    bool packed = false;      // rows of the complexes back to back, no padding rows (pp_complex_prepare_packed)
+    int2 *seg;                // [N] (first row, length) of the complex each row belongs to
     // static per complex
     int32_t *eidx;            // [N][K] global node index of each neighbour
     float *mask_att;          // [N][32] mask_i*mask_j (0 for slots >= K)
@@ -126,8 +127,6 @@ struct pp_ctx {
     float *ptsE, *PAe, *PCe;  // edge-message inputs
     float *score;             // [N][4]
     float *chi_tmp;           // [N][4]
-    StepParams *steps;        // device [max_steps]
-    StepParams *steps_host;   // pinned host staging
     void *arena = nullptr;          // ONE device allocation behind every workspace pointer above (one hipMalloc / hipFree per ctx)
     size_t arena_bytes = 0;
     hipStream_t last_stream = nullptr;   // the stream of the most recent call on this context (arena hand-over)
@@ -142,12 +141,12 @@ struct pp_ctx {
     float *px, *pm, *pv, *pz, *pxeff;   // proximal: param, Adam moments, anchor, effective chi  [N][4]
     uint8_t *pmask;           // [N]
     float *scal;              // small scalar scratch
-    // in-situ kernel timing (pp_profile_kernel): event pairs recorded around every launch of one hot kernel
+    // in-situ kernel timing (pp_profile_kernel): every launch of one hot kernel carries a start / stop event pair
+    // (hipExtLaunchKernelGGL: the dispatch's own begin / end timestamps, what rocprofv3's kernel trace reports)
     int prof_which = -1;       // -1 off, 0 node message, 1 edge update, 2 node update
+    bool prof_armed = false;   // the next PP_LAUNCH on this ctx is one of the profiled kernel
     std::vector<hipEvent_t> prof_ev;
     size_t prof_n = 0;         // events used (2 per launch)
-    hipStream_t prof_stream = nullptr;
-    bool prof_stream_valid = false;
 };
 
 void pp_set_error(const std::string &msg);
@@ -160,11 +159,67 @@ void pp_set_error(const std::string &msg);
         }                                                                                    \
     } while (0)
 
+// next (start, stop) event pair of an armed profiling run; false when profiling is off for this launch
+bool pp_prof_take(pp_ctx *c, hipEvent_t *e0, hipEvent_t *e1);
+#define PP_LAUNCH(c, kernel, grid, block, shmem, s, ...)                                              \
+    do {                                                                                               \
+        hipEvent_t e0_ = nullptr, e1_ = nullptr;                                                       \
+        if ((c)->prof_armed && pp_prof_take((c), &e0_, &e1_))                                          \
+            hipExtLaunchKernelGGL(kernel, grid, block, shmem, s, e0_, e1_, 0, __VA_ARGS__);            \
+        else                                                                                           \
+            hipLaunchKernelGGL(kernel, grid, block, shmem, s, __VA_ARGS__);                            \
+    } while (0)
+
+// ---- inter-residue dihedral, rounded like the reference's ATen CPU ops (encoder.py:164-174) ------------------------------
+// sgn * arccos(n1 . n2) has no clamp: where four atoms are coplanar (every j == i edge; on ideal-geometry backbones also a few
+// trans pairs with |psi| within 3e-4 of pi) the argument is 1 or -1 up to rounding, and one ulp decides between NaN -> 0,
+// exactly pi and pi - 5e-4: the feature is rounding noise of size pi.  The only way to agree with the reference there is to
+// round as it does.  Measured against torch 2.10 CPU (tools/debug/aten_rounding_probe.py, 76 864 dihedrals of four C5
+// complexes, argument and sign bit-equal):  torch.cross  c = fma(a1, b2, -(a2 * b1))  (second product rounded first);
+// torch.norm  sqrt(fma(z, z, fma(y, y, x * x)));  (a * b).sum(-1)  ((p0 + p1) + p2) on separately rounded products; IEEE
+// division.  arccos itself differs from ATen's by at most an ulp, which is smooth.
+#ifdef __HIPCC__
+__device__ __forceinline__ void pp_cross_t(const float *a, const float *b, float *o) {
+#pragma clang fp contract(off)
+    const float q0 = a[2] * b[1], q1 = a[0] * b[2], q2 = a[1] * b[0];
+    o[0] = __builtin_fmaf(a[1], b[2], -q0);
+    o[1] = __builtin_fmaf(a[2], b[0], -q1);
+    o[2] = __builtin_fmaf(a[0], b[1], -q2);
+}
+__device__ __forceinline__ float pp_dot_t(const float *a, const float *b) {
+#pragma clang fp contract(off)
+    const float p0 = a[0] * b[0], p1 = a[1] * b[1], p2 = a[2] * b[2];
+    return (p0 + p1) + p2;
+}
+__device__ __forceinline__ void pp_unit_t(float *v) {
+#pragma clang fp contract(off)
+    const float x2 = v[0] * v[0];
+    const float n = sqrtf(__builtin_fmaf(v[2], v[2], __builtin_fmaf(v[1], v[1], x2)));
+    for (int k = 0; k < 3; k++) {
+        const float q = v[k] / n;
+        v[k] = (q != q) ? 0.f : q;           // nan_to_num of 0 / 0; +-inf cannot occur for finite input
+    }
+}
+__device__ __forceinline__ float pp_pair_dihedral_t(const float *p0, const float *p1, const float *p2, const float *p3) {
+#pragma clang fp contract(off)
+    float u0[3], u1[3], u2[3], n1[3], n2[3], c12[3];
+    for (int k = 0; k < 3; k++) { u0[k] = p2[k] - p1[k]; u1[k] = p0[k] - p1[k]; u2[k] = p3[k] - p2[k]; }
+    pp_cross_t(u0, u1, n1); pp_unit_t(n1);
+    pp_cross_t(u0, u2, n2); pp_unit_t(n2);
+    pp_cross_t(u1, u2, c12);
+    const float sg = pp_dot_t(c12, u0);
+    const float sgn = (sg > 0.f) ? 1.f : ((sg < 0.f) ? -1.f : 0.f);
+    const float ang = sgn * acosf(pp_dot_t(n1, n2));
+    return (ang != ang) ? 0.f : ang;
+}
+#endif
+
 // ---- launchers implemented in the kernel translation units ----------------------------------
-pp_status pp_launch_prepare(pp_ctx *c, hipStream_t s);
-pp_status pp_launch_node_embed(pp_ctx *c, const float *chi, int step, hipStream_t s);
+pp_status pp_launch_prepare(pp_ctx *c, hipStream_t s, const int64_t *E_idx = nullptr);   // E_idx: given neighbour lists instead of the kNN search
+pp_status pp_launch_node_embed(pp_ctx *c, const float *chi, const StepParams &sp, hipStream_t s);
+// cur: this step's scalars (layer 2 inside sampling); next: the next step, if its node embedding is to follow (else null)
 pp_status pp_launch_node_update(pp_ctx *c, int layer, int last_mode, float *chi, int step, int mode,
-                                const float *noise, bool embed_next, hipStream_t s);
+                                const float *noise, const StepParams *cur, const StepParams *next, hipStream_t s);
 pp_status pp_launch_edge_static(pp_ctx *c, hipStream_t s);
 #ifdef PP_EDGE_F16
 pp_status pp_launch_edge_embed_f16(pp_ctx *c, hipStream_t s);   // pp_edge_f16.hip: MFMA form of k_edge_embed

@@ -14,6 +14,8 @@
 // sit in LDS as float4 groups (one component per residue).  The kernel is bound by one block's dependent chain, not by
 // bytes (same time for 16 and 256 blocks), so k_node_update fetches every phase's weights a phase or two ahead.
 // The cheap epilogues (LayerNorm, bias, ReLU) are replicated in the four ks-groups to keep control flow uniform.
+#include <string.h>
+
 #include "pp_internal.h"
 
 #define NT 512
@@ -31,7 +33,6 @@ struct NodeArgs {
     const float *sc_mask;        // [N][4]
     const uint8_t *m1pi, *m2pi;  // [N][4]
     const float *frames;         // [N][12]
-    const StepParams *steps;
     const float *embT, *emb_b, *emb_g, *emb_beta;
     float *hV, *S, *msum;
     float *ptsN, *PAn, *PCn, *ptsE, *PAe, *PCe;
@@ -216,7 +217,7 @@ __device__ void message_inputs(Smem &sm, int &flip, const PreW &w, const float *
 }
 
 // Node embedding for the block's residues -> value (before LN) of feature f (all ks-groups compute the same thing)
-__device__ __forceinline__ VN embed_pre(Smem &sm, const NodeArgs &A, const float *chi, int step, int n0) {
+__device__ __forceinline__ VN embed_pre(Smem &sm, const NodeArgs &A, const float *chi, const StepParams &sp, int n0) {
     const int t = threadIdx.x, f = t & 127;
     if (t < 6) sm.p[t] = load_rows(A.bb_sincos, 6, n0, A.N, t);
     else if (t < 14) {
@@ -237,7 +238,7 @@ __device__ __forceinline__ VN embed_pre(Smem &sm, const NodeArgs &A, const float
     }
 #pragma unroll
     for (int k = 0; k < 14; k++) acc = vfma(A.embT[(21 + k) * 128 + f], sm.p[k], acc);
-    const float *te = A.steps[step].temb;
+    const float *te = sp.temb;
     float tacc = 0.f;
 #pragma unroll
     for (int k = 0; k < 16; k++) tacc = fmaf(A.embT[(35 + k) * 128 + f], te[k], tacc);
@@ -245,12 +246,12 @@ __device__ __forceinline__ VN embed_pre(Smem &sm, const NodeArgs &A, const float
 }
 
 __global__ void __launch_bounds__(NT)
-k_node_embed(NodeArgs A, PreW pre0, const float *chi, int step) {
+k_node_embed(NodeArgs A, PreW pre0, const float *chi, StepParams sp) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     Smem &sm = *reinterpret_cast<Smem *>(smem_raw);
     int flip = 0, rflip = 0;
     const int f = threadIdx.x & 127, ks = threadIdx.x >> 7, n0 = blockIdx.x * NB;
-    VN v = embed_pre(sm, A, chi, step, n0);
+    VN v = embed_pre(sm, A, chi, sp, n0);
     VN h = layernorm(sm, rflip, v, A.emb_g[f], A.emb_beta[f]);
     if (ks == 0) {
         store_rows(A.hV, 128, n0, A.N, f, h);
@@ -324,6 +325,15 @@ struct SmemU {
     float par[NU_P_LAST_TOTAL];                          // parameter block (layers 0, 1 use the first NU_P_MID_TOTAL)
 };
 
+// per-step scalars and the next step's time embedding travel as kernel arguments (no device buffer to fill, so pp_score /
+// pp_sample never wait for the stream)
+struct StepScalars {
+    float c_ode, w, c_drift, c_diff;
+};
+struct TimeEmb {
+    float v[16];
+};
+
 struct NUpdArgs {
     int N;
     const float *rmask;          // [N]
@@ -332,7 +342,6 @@ struct NUpdArgs {
     const float *sc_mask;        // [N][4]
     const uint8_t *m1pi, *m2pi;  // [N][4]
     const float *frames;         // [N][12]
-    const StepParams *steps;
     const float *embT;           // [51][128]
     const float *wstream, *params;
     float *hV;
@@ -475,7 +484,7 @@ __device__ __forceinline__ nf4 ln128(float (*st)[16][2], int wv, int r, int g, c
 #endif
 template <int MODE>
 __global__ void __launch_bounds__(512)
-k_node_update(NUpdArgs A, float *chi, int step, int sde, const float *noise, int embed_next) {
+k_node_update(NUpdArgs A, float *chi, int step, int sde, const float *noise, int embed_next, StepScalars sp, TimeEmb te_next) {
     constexpr bool LAST = MODE != PP_NU_MID;
     constexpr int NSLOT = LAST ? PP_NU_SLOTS_LAST : PP_NU_SLOTS_MID;
     constexpr int NLOAD = MODE == PP_NU_SCORE ? 46 : NSLOT;       // slots this instance ever fetches
@@ -501,7 +510,7 @@ k_node_update(NUpdArgs A, float *chi, int step, int sde, const float *noise, int
     nf4 spv = zero4i;                          // c_ode, w, c_drift, c_diff of this step
     if constexpr (MODE == PP_NU_STEP) {
         if (wv == 0) {
-            spv = *reinterpret_cast<const nf4 *>(&A.steps[step].c_ode);
+            spv = nf4{sp.c_ode, sp.w, sp.c_drift, sp.c_diff};
             chi1 = chi[(size_t)nc * 4 + g];
             scm1 = A.sc_mask[(size_t)nc * 4 + g];
             p1 = A.m1pi[(size_t)nc * 4 + g] != 0;
@@ -535,8 +544,8 @@ k_node_update(NUpdArgs A, float *chi, int step, int sde, const float *noise, int
         }
     } else if (e_te) {
         if (embed_next) {
-            const nf4 *tp = reinterpret_cast<const nf4 *>(A.steps[step + 1].temb);
-            ev[0] = tp[0]; ev[1] = tp[1]; ev[2] = tp[2]; ev[3] = tp[3];
+#pragma unroll
+            for (int k = 0; k < 16; k++) ev[k >> 2][k & 3] = te_next.v[k];
         }
     }
     constexpr int NPV = (NPAR / 4 + 511) / 512;
@@ -795,7 +804,6 @@ static NodeArgs make_args(pp_ctx *c) {
     A.m1pi = c->b.chi_1pi_periodic_mask;
     A.m2pi = c->b.chi_2pi_periodic_mask;
     A.frames = c->frames;
-    A.steps = c->steps;
     A.embT = p->node_emb_T;
     A.emb_b = p->w + p->off.node_emb_b;
     A.emb_g = p->w + p->off.norm_nodes_g;
@@ -834,18 +842,19 @@ static pp_status node_attrs() {
     return PP_OK;
 }
 
-pp_status pp_launch_node_embed(pp_ctx *c, const float *chi, int step, hipStream_t s) {
+pp_status pp_launch_node_embed(pp_ctx *c, const float *chi, const StepParams &sp, hipStream_t s) {
     pp_status st = node_attrs();
     if (st != PP_OK) return st;
     NodeArgs A = make_args(c);
     PreW pre0 = make_pre(c->plan, 0, false);
-    hipLaunchKernelGGL(k_node_embed, dim3((c->N + NB - 1) / NB), dim3(NT), sizeof(Smem), s, A, pre0, chi, step);
+    hipLaunchKernelGGL(k_node_embed, dim3((c->N + NB - 1) / NB), dim3(NT), sizeof(Smem), s, A, pre0, chi, sp);
     PP_HIP_CHECK(hipGetLastError());
     return PP_OK;
 }
 
 pp_status pp_launch_node_update(pp_ctx *c, int layer, int last_mode, float *chi, int step, int mode,
-                                const float *noise, bool embed_next_step, hipStream_t s) {
+                                const float *noise, const StepParams *cur, const StepParams *next, hipStream_t s) {
+    const bool embed_next_step = next != nullptr;
     pp_status st0 = node_attrs();
     if (st0 != PP_OK) return st0;
     if ((last_mode == PP_NU_MID) != (layer < 2)) {
@@ -863,7 +872,6 @@ pp_status pp_launch_node_update(pp_ctx *c, int layer, int last_mode, float *chi,
     A.m1pi = c->b.chi_1pi_periodic_mask;
     A.m2pi = c->b.chi_2pi_periodic_mask;
     A.frames = c->frames;
-    A.steps = c->steps;
     A.embT = p->node_emb_T;
     A.wstream = t.nu_stream;
     A.params = t.nu_params;
@@ -878,15 +886,19 @@ pp_status pp_launch_node_update(pp_ctx *c, int layer, int last_mode, float *chi,
 #endif
     const dim3 grid((c->N + 15) / 16), block(512);
     const int sde = mode == PP_MODE_SDE ? 1 : 0;
+    StepScalars sp = {0.f, 0.f, 0.f, 0.f};
+    TimeEmb te = {};
+    if (cur) sp = {cur->c_ode, cur->w, cur->c_drift, cur->c_diff};
+    if (next) memcpy(te.v, next->temb, sizeof(te.v));
     if (last_mode == PP_NU_MID)
-        hipLaunchKernelGGL(k_node_update<PP_NU_MID>, grid, block, sizeof(SmemU), s, A, chi, step, sde, noise, embed_next);
+        PP_LAUNCH(c, k_node_update<PP_NU_MID>, grid, block, sizeof(SmemU), s, A, chi, step, sde, noise, embed_next, sp, te);
     else if (last_mode == PP_NU_STEP)
-        hipLaunchKernelGGL(k_node_update<PP_NU_STEP>, grid, block, sizeof(SmemU), s, A, chi, step, sde, noise, embed_next);
+        PP_LAUNCH(c, k_node_update<PP_NU_STEP>, grid, block, sizeof(SmemU), s, A, chi, step, sde, noise, embed_next, sp, te);
     else
-        hipLaunchKernelGGL(k_node_update<PP_NU_SCORE>, grid, block, sizeof(SmemU), s, A, chi, step, sde, noise, embed_next);
+        PP_LAUNCH(c, k_node_update<PP_NU_SCORE>, grid, block, sizeof(SmemU), s, A, chi, step, sde, noise, embed_next, sp, te);
     PP_HIP_CHECK(hipGetLastError());
 #ifdef PP_X_NU_EMBED_LAUNCH
-    if (embed_after) return pp_launch_node_embed(c, chi, step + 1, s);
+    if (embed_after) return pp_launch_node_embed(c, chi, *next, s);
 #endif
     return PP_OK;
 }

@@ -56,7 +56,7 @@ __global__ void k_frames(const float *__restrict__ X, int N, float *__restrict__
 // kNN: one block per residue row; K rounds of (value, index)-lexicographic arg-min.
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(KNN_THREADS)
-k_knn(const float *__restrict__ X, const float *__restrict__ rmask, int L, int K,
+k_knn(const float *__restrict__ X, const float *__restrict__ rmask, const int2 *__restrict__ seg, int K,
       int32_t *__restrict__ eidx, float *__restrict__ mask_att) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float *d = reinterpret_cast<float *>(smem_raw);            // [L]
@@ -65,15 +65,15 @@ k_knn(const float *__restrict__ X, const float *__restrict__ rmask, int L, int K
     __shared__ float s_max;
     __shared__ int s_pick;
     const int n = blockIdx.x;
-    const int b = n / L, i = n - b * L;
+    const int row0 = seg[n].x, L = seg[n].y;          // this row's complex: rows row0 .. row0 + L - 1
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const float mi = rmask[n];
     const float *ca_i = X + (size_t)n * 42 + 3;
     float ci[3] = {ca_i[0], ca_i[1], ca_i[2]};
     float lmax = 0.f;
     for (int j = tid; j < L; j += KNN_THREADS) {
-        const float *ca_j = X + (size_t)(b * L + j) * 42 + 3;
-        float m2 = mi * rmask[b * L + j];
+        const float *ca_j = X + (size_t)(row0 + j) * 42 + 3;
+        float m2 = mi * rmask[row0 + j];
         float v = m2 * dist_eps(ca_j, ci, 1e-6f);
         d[j] = v;
         lmax = fmaxf(lmax, v);
@@ -89,7 +89,7 @@ k_knn(const float *__restrict__ X, const float *__restrict__ rmask, int L, int K
     __syncthreads();
     const float dmax = s_max;
     for (int j = tid; j < L; j += KNN_THREADS) {
-        float m2 = mi * rmask[b * L + j];
+        float m2 = mi * rmask[row0 + j];
         d[j] = d[j] + (2.f * (1.f - m2)) * dmax;
     }
     __syncthreads();
@@ -114,8 +114,8 @@ k_knn(const float *__restrict__ X, const float *__restrict__ rmask, int L, int K
                 if (red_v[w] < v || (red_v[w] == v && red_i[w] < ix)) { v = red_v[w]; ix = red_i[w]; }
             s_pick = ix;
             d[ix] = INFINITY;
-            eidx[(size_t)n * K + k] = b * L + ix;
-            mask_att[(size_t)n * 32 + k] = mi * rmask[b * L + ix];
+            eidx[(size_t)n * K + k] = row0 + ix;
+            mask_att[(size_t)n * 32 + k] = mi * rmask[row0 + ix];
         }
         __syncthreads();
     }
@@ -125,32 +125,6 @@ k_knn(const float *__restrict__ X, const float *__restrict__ rmask, int L, int K
 // ---------------------------------------------------------------------------------------------
 // edge features + embedding: one block (128 threads) per residue, its K edges.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void cross3(const float *a, const float *b, float *o) {
-    o[0] = a[1] * b[2] - a[2] * b[1];
-    o[1] = a[2] * b[0] - a[0] * b[2];
-    o[2] = a[0] * b[1] - a[1] * b[0];
-}
-__device__ __forceinline__ void unit_nan0(float *v) {
-    float n = sqrtf((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]);
-    for (int k = 0; k < 3; k++) {
-        float q = v[k] / n;
-        v[k] = (q != q) ? 0.f : q;           // nan_to_num of 0/0; +-inf cannot occur for finite input
-    }
-}
-// sign * arccos(n1 . n2) with NaN -> 0 (encoder.py:164-174)
-__device__ float pair_dihedral(const float *p0, const float *p1, const float *p2, const float *p3) {
-    float u0[3], u1[3], u2[3], n1[3], n2[3], c12[3];
-    for (int k = 0; k < 3; k++) { u0[k] = p2[k] - p1[k]; u1[k] = p0[k] - p1[k]; u2[k] = p3[k] - p2[k]; }
-    cross3(u0, u1, n1); unit_nan0(n1);
-    cross3(u0, u2, n2); unit_nan0(n2);
-    cross3(u1, u2, c12);
-    float sg = (c12[0] * u0[0] + c12[1] * u0[1]) + c12[2] * u0[2];
-    float sgn = (sg > 0.f) ? 1.f : ((sg < 0.f) ? -1.f : 0.f);
-    float dt = (n1[0] * n2[0] + n1[1] * n2[1]) + n1[2] * n2[2];
-    float ang = sgn * acosf(dt);
-    return (ang != ang) ? 0.f : ang;
-}
-
 #define EF_THREADS 128
 #define EF_RBF 400
 #define EF_STRIDE 404      // padded row of the per-edge RBF vector in LDS
@@ -193,12 +167,10 @@ k_edge_embed(const float *__restrict__ bbpos, const int32_t *__restrict__ eidx,
         off = off < 0 ? 0 : (off > 64 ? 64 : off);
         s_extra[e][0] = (float)off;
         s_extra[e][1] = (chain[n] == chain[j]) ? 2.f : 1.f;
-        float phi = 0.f, psi = 0.f;
-        if (j != n) {     // the j == i edge is 0 by construction (self-edge dihedrals)
-            // phi_ij = dih(C_i, N_j, CA_j, C_j) ; psi_ij = dih(N_i, CA_i, C_i, N_j)
-            phi = pair_dihedral(&s_pos[32][6], &s_pos[e][0], &s_pos[e][3], &s_pos[e][6]);
-            psi = pair_dihedral(&s_pos[32][0], &s_pos[32][3], &s_pos[32][6], &s_pos[e][0]);
-        }
+        // phi_ij = dih(C_i, N_j, CA_j, C_j), psi_ij = dih(N_i, CA_i, C_i, N_j), rounded as the reference rounds them
+        // (pp_internal.h); the j == i edge included
+        const float phi = pp_pair_dihedral_t(&s_pos[32][6], &s_pos[e][0], &s_pos[e][3], &s_pos[e][6]);
+        const float psi = pp_pair_dihedral_t(&s_pos[32][0], &s_pos[32][3], &s_pos[32][6], &s_pos[e][0]);
         s_extra[e][2] = phi;
         s_extra[e][3] = psi;
     }
@@ -252,16 +224,38 @@ k_edge_embed(const float *__restrict__ bbpos, const int32_t *__restrict__ eidx,
     }
 }
 
-pp_status pp_launch_prepare(pp_ctx *c, hipStream_t s) {
+// caller-provided neighbour lists (pp_ctx_set_graph): per-complex numbering [N][K] int64 -> global rows + pair mask
+__global__ void k_import_graph(const int64_t *__restrict__ E_idx, const int2 *__restrict__ seg,
+                               const float *__restrict__ rmask, int N, int K, int32_t *__restrict__ eidx,
+                               float *__restrict__ mask_att, int *__restrict__ bad) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= N * 32) return;
+    const int n = t >> 5, k = t & 31;
+    if (k >= K) { mask_att[(size_t)n * 32 + k] = 0.f; return; }
+    const int64_t j = E_idx[(size_t)n * K + k];
+    const int2 sg = seg[n];
+    if (j < 0 || j >= sg.y) { atomicAdd(bad, 1); eidx[(size_t)n * K + k] = n; mask_att[(size_t)n * 32 + k] = 0.f; return; }
+    eidx[(size_t)n * K + k] = sg.x + (int)j;
+    mask_att[(size_t)n * 32 + k] = rmask[n] * rmask[sg.x + (int)j];
+}
+
+pp_status pp_launch_prepare(pp_ctx *c, hipStream_t s, const int64_t *E_idx) {
     const int N = c->N;
+    if (E_idx) {
+        // neighbour lists given: frames and backbone atoms are in place already, only the edge embedding follows
+        PP_HIP_CHECK(hipMemsetAsync(c->scal, 0, sizeof(int), s));
+        hipLaunchKernelGGL(k_import_graph, dim3((N * 32 + 255) / 256), dim3(256), 0, s, E_idx, c->seg, c->b.residue_mask, N, c->K,
+                           c->eidx, c->mask_att, reinterpret_cast<int *>(c->scal));
+    } else {
     hipLaunchKernelGGL(k_frames, dim3((N + 127) / 128), dim3(128), 0, s, c->b.X, N, c->frames, c->bbpos);
-    size_t smem = (size_t)c->L * sizeof(float);
+    size_t smem = (size_t)c->L * sizeof(float);       // L = the longest complex of the context
     if (smem > 64 * 1024) {
         PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_knn),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     }
-    hipLaunchKernelGGL(k_knn, dim3(N), dim3(KNN_THREADS), smem, s, c->b.X, c->b.residue_mask, c->L, c->K,
+    hipLaunchKernelGGL(k_knn, dim3(N), dim3(KNN_THREADS), smem, s, c->b.X, c->b.residue_mask, c->seg, c->K,
                        c->eidx, c->mask_att);
+    }
 #ifdef PP_EDGE_F16
     return pp_launch_edge_embed_f16(c, s);      // MFMA form (pp_edge_f16.hip); k_edge_embed below is the fp32 build's
 #else

@@ -16,7 +16,7 @@ _LIB_PATH = os.environ.get("PACKPPI_LIB") or os.path.join(os.path.dirname(os.pat
 _lib = None
 
 SYMBOLS = ("pp_version", "pp_last_error", "pp_plan_create", "pp_plan_destroy", "pp_plan_set_clash_params",
-           "pp_complex_prepare", "pp_ctx_destroy", "pp_ctx_get_graph", "pp_score", "pp_sample", "pp_atom14",
+           "pp_complex_prepare", "pp_complex_prepare_packed", "pp_ctx_destroy", "pp_ctx_get_graph", "pp_ctx_set_graph", "pp_score", "pp_sample", "pp_atom14",
            "pp_clash", "pp_proximal", "pp_time_kernel", "pp_profile_kernel", "pp_profile_read", "pp_edge_variant")
 
 
@@ -50,9 +50,11 @@ def load():
     lib.pp_plan_destroy.restype = None
     lib.pp_plan_set_clash_params.argtypes = [vp, f, vp, vp, vp]
     lib.pp_complex_prepare.argtypes = [vp, C.POINTER(PPBatch), vp, C.POINTER(vp)]
+    lib.pp_complex_prepare_packed.argtypes = [vp, C.POINTER(PPBatch), vp, i, i, i, vp, C.POINTER(vp)]
     lib.pp_ctx_destroy.argtypes = [vp]
     lib.pp_ctx_destroy.restype = None
     lib.pp_ctx_get_graph.argtypes = [vp, vp, vp, vp]
+    lib.pp_ctx_set_graph.argtypes = [vp, vp, vp]
     lib.pp_score.argtypes = [vp, vp, f, vp, vp, vp]
     lib.pp_sample.argtypes = [vp, vp, vp, i, i, vp, vp]
     lib.pp_atom14.argtypes = [vp, vp, vp, vp]
@@ -156,7 +158,19 @@ class Context:
         pb = PPBatch(self.B, self.L, *[(self._t[k].data_ptr() if self._t[k] is not None else None)
                                        for k, _ in _BATCH_SPEC])
         h = C.c_void_p()
-        _check(lib.pp_complex_prepare(plan.handle, C.byref(pb), _stream(dev), C.byref(h)), "pp_complex_prepare")
+        seg = batch.get("seg_offsets") if hasattr(batch, "get") else getattr(batch, "seg_offsets", None)
+        if seg is None:
+            _check(lib.pp_complex_prepare(plan.handle, C.byref(pb), _stream(dev), C.byref(h)), "pp_complex_prepare")
+        else:
+            # ragged batch without padding rows (batch.pack): [1, sum of lengths, ...] + the complexes' first rows
+            lens = (seg[1:] - seg[:-1]).tolist()
+            if self.B != 1 or int(seg[-1]) != self.L or int(seg[0]) != 0 or min(lens) < 1:
+                raise RuntimeError("seg_offsets does not describe this batch")
+            self._t["seg_offsets"] = seg.to(device=dev, dtype=torch.int32).contiguous()
+            self.K = min(32, min(lens))
+            _check(lib.pp_complex_prepare_packed(plan.handle, C.byref(pb), self._t["seg_offsets"].data_ptr(), len(lens),
+                                                 min(lens), max(lens), _stream(dev), C.byref(h)),
+                   "pp_complex_prepare_packed")
         self.handle = h
 
     def _new(self, *shape, dtype=torch.float32):
@@ -171,6 +185,11 @@ class Context:
         hE = self._new(self.B, self.L, self.K, 128)
         _check(load().pp_ctx_get_graph(self.handle, _ptr(E), _ptr(hE), _stream(self.plan.device)), "pp_ctx_get_graph")
         return E, hE
+
+    def set_graph(self, E_idx):
+        """Use the caller's neighbour lists [B, L, K] (per-complex numbering) instead of the built-in search."""
+        E = E_idx.to(device=self.plan.device, dtype=torch.int64).reshape(self.B, self.L, self.K).contiguous()
+        _check(load().pp_ctx_set_graph(self.handle, _ptr(E), _stream(self.plan.device)), "pp_ctx_set_graph")
 
     def score(self, chi, t: float):
         chi = self._chi(chi)

@@ -131,6 +131,15 @@ class TDiffusionModule:
             self._ctx_key = key
         return self._ctx
 
+    def _geometry_context(self, batch) -> Context:
+        """The batch's network context if it is the cached one, else a weight-free one (atom14 needs no graph or edge
+        embedding: metrics of many small complexes must not pay a network preparation each)."""
+        X = batch["X"]
+        if (X.data_ptr(), tuple(X.shape), batch["residue_mask"].data_ptr()) == self._ctx_key:
+            return self._ctx
+        from .functional import _ctx_for
+        return _ctx_for(batch)
+
     @staticmethod
     def _t_to_sigma(t):
         lo, hi = np.log(SIGMA_MIN), np.log(SIGMA_MAX)
@@ -166,8 +175,12 @@ class TDiffusionModule:
         SC_D_sample, _ = self.add_sc_noise(batch, t)
         n_steps = len(self.schedule) - 1
         if cfg.mode == "sde" and sde_noise is None:
-            # the reference draws torch.normal twice per step from the device generator (schedule.py:225)
-            sde_noise = torch.randn(n_steps, 2, batch.num_proteins * batch.max_size, 4, device=self.device)
+            # the reference draws torch.normal(size=[B*L, 4], device=...) inside the loop, once per schedule and step, the
+            # 1pi schedule first (schedule.py:225, TorsionalDiffusion.py:271-274): the same calls in the same order, so a
+            # seed gives the stream it gives the reference on this device (one [n, 2, N, 4] draw would not)
+            shape = (batch.num_proteins * batch.max_size, 4)
+            sde_noise = torch.stack([torch.stack([torch.normal(mean=0, std=1, size=shape, device=self.device)
+                                                  for _ in range(2)]) for _ in range(n_steps)])
         SC_D_sample = self._context(batch).sample(SC_D_sample, self.schedule, cfg.mode, sde_noise)
         if not use_proximal:
             return SC_D_sample
@@ -178,6 +191,11 @@ class TDiffusionModule:
         if loss_list[-1] < loss_list[0]:
             return SC_D_resample_list[-1]
         return SC_D_sample
+
+    def sample_from(self, batch, SC_D_init, sde_noise=None):
+        """The reverse-diffusion loop of ``sampling`` from given initial noised angles (parity runs inject the reference's
+        own draw; the packed multi-complex path injects per-complex draws)."""
+        return self._context(batch).sample(SC_D_init, self.schedule, self.hparams.sample_cfg.mode, sde_noise)
 
     def compute_rmsd(self, true_coords, pred_coords, atom_mask, residue_mask):
         w = atom_mask * residue_mask[..., None]
@@ -196,9 +214,9 @@ class TDiffusionModule:
             metric[f"chi_{i}_ae_rad"] = ae.sum() / n
             metric[f"chi_{i}_ae_deg"] = (ae * 180 / np.pi).sum() / n
             metric[f"chi_{i}_acc"] = acc.sum() / n
-        pred = self._context(batch).atom14(SC_D_sample)
+        pred = self._geometry_context(batch).atom14(SC_D_sample)
         metric["atom_rmsd"] = self.compute_rmsd(batch.X, pred, batch.atom_mask, batch.residue_mask)
         return metric
 
     def get_atom14_coords(self, batch, SC_D):
-        return self._context(batch).atom14(SC_D)
+        return self._geometry_context(batch).atom14(SC_D)

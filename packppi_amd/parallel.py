@@ -57,18 +57,56 @@ def gather_metric_rows(ids: torch.Tensor, rows: torch.Tensor, group=None) -> Tup
     return all_rows[:, 0].to(torch.int64), all_rows[:, 1:]
 
 
-def sample_sharded(model, complexes, use_proximal=False, group=None):
-    """Run ``model.sampling`` + ``analyze_samples`` on this rank's share of ``complexes`` (list of B=1 batches
-    already on the rank's device) and gather every complex's metric row on every rank.
+def sample_sharded(model, complexes, use_proximal=False, group=None, init_chi=None, max_rows=200_000):
+    """Run the sampling path on this rank's share of ``complexes`` (list of B = 1 batches already on the rank's device)
+    and gather every complex's metric row on every rank.
+
+    The shard is sampled as ragged PACKED batches (``batch.pack``: no padding rows are launched; complexes shorter than 32
+    residues go alone because K = min(32, L)), at most ``max_rows`` residues per batch; the proximal stage, which the
+    reference defines for one complex at a time (optimize.py:27), and the metrics then run per complex.
+    ``init_chi`` (optional, {complex id: [1, L, 4]}) injects the initial noised angles instead of drawing them.
     Returns (chi per local complex id, ids_all, rows_all)."""
+    from .batch import pack, unpack
+    from .functional import proximal_optimizer
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     mine = shard_complexes([int(c["max_size"]) for c in complexes], world)[rank]
-    chis, rows = {}, []
+    cfg = model.hparams.sample_cfg
+    groups, cur, rows_in = [], [], 0
     for i in mine:
-        chi = model.sampling(complexes[i], use_proximal=use_proximal)
-        chis[i] = chi
-        rows.append(metrics_to_row(model.analyze_samples(complexes[i], chi)))
+        n = int(complexes[i]["residue_mask"].sum())
+        if n < 32:
+            groups.append([i])
+            continue
+        if cur and rows_in + n > max_rows:
+            groups.append(cur)
+            cur, rows_in = [], 0
+        cur.append(i)
+        rows_in += n
+    if cur:
+        groups.append(cur)
+    chis = {}
+    for grp in groups:
+        pb = pack([complexes[i] for i in grp])
+        if init_chi is not None:
+            offs = pb["seg_offsets"].tolist()
+            x0 = torch.cat([init_chi[i][:, :b - a] for i, a, b in zip(grp, offs[:-1], offs[1:])], 1).to(model.device)
+            out = model.sample_from(pb, x0)
+        else:
+            out = model.sampling(pb)
+        for i, chi in zip(grp, unpack(pb, out)):
+            L = int(complexes[i]["max_size"])
+            full = torch.zeros(1, L, 4, device=chi.device, dtype=chi.dtype)
+            full[:, :chi.shape[1]] = chi
+            chis[i] = full
+    rows = []
+    for i in mine:
+        if use_proximal:
+            lst, losses = proximal_optimizer(complexes[i], chis[i], cfg.violation_tolerance_factor,
+                                             cfg.clash_overlap_tolerance, cfg.lamda, cfg.num_steps)
+            if losses[-1] < losses[0]:
+                chis[i] = lst[-1]
+        rows.append(metrics_to_row(model.analyze_samples(complexes[i], chis[i])))
     dev = model.device
     ids = torch.tensor(mine, device=dev, dtype=torch.int64)
     rows_t = torch.stack(rows).to(dev) if rows else torch.zeros(0, len(METRIC_KEYS), device=dev)

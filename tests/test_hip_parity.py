@@ -3,6 +3,8 @@
 Tolerances (BASELINE.json north_star): chi within 1e-4 rad, atom_rmsd within 1e-3 A^2 of the reference
 CPU path on identical initial noise.  Intermediate tensors are held to "fp32, different summation order".
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -54,14 +56,12 @@ def test_graph(name, model):
     def by_neighbour(h, perm):
         return torch.gather(h, 2, perm[..., None].expand(-1, -1, -1, 128))
 
-    # the j == i edge carries exactly-zero dihedrals here: compare with that oracle variant tightly,
-    # and with the reference's own tensor at the size of its arccos rounding noise
-    from oracle import ref_cpu as O
-    E_o, hE_o = O.encode_static(model.state_dict(), b, zero_self_dihedral=True)
+    # the embedded edges against the REFERENCE's own tensor.  The two pair dihedrals are sgn * arccos(n1 . n2) without a
+    # clamp: on coplanar atoms (every j == i edge) the value is rounding noise of up to pi, so the kernel rounds the way
+    # the reference's ATen ops do (pp_internal.h) and agrees with it there as well
     hm = by_neighbour(hE, perm_m)
     real = (torch.gather(b.residue_mask[:, None].expand(-1, E.shape[1], -1), 2, mine_sorted) > 0) & valid[..., None]
-    assert (hm - by_neighbour(hE_o, E_o.sort(-1)[1]))[real].abs().max() < 2e-5
-    assert (hm - by_neighbour(g["hE0"], perm_r))[real].abs().max() < 5e-3
+    assert (hm - by_neighbour(g["hE0"], perm_r))[real].abs().max() < 2e-5
 
 
 @pytest.mark.parametrize("name", OPS)
@@ -74,12 +74,13 @@ def test_network(name, model):
     for tval, tn in ((1.0, "t1"), (0.5, "t05"), (1.0 / 30, "t30")):
         t = torch.tensor([tval]).repeat_interleave(B * L)
         score, hV = model.network(gb, chi.to(DEV), t)
-        assert (hV.cpu() - g[f"hV_{tn}"])[valid].abs().max() < 2e-3, tn
-        assert (score.cpu() - g[f"score_{tn}"])[valid].abs().max() < 1e-3, tn
-    # against the oracle with the same self-edge convention the agreement is at fp32 rounding level
+        assert (hV.cpu() - g[f"hV_{tn}"])[valid].abs().max() < 1e-4, tn           # vs the reference's own tensors
+        assert (score.cpu() - g[f"score_{tn}"])[valid].abs().max() < 5e-5, tn
+    # h_V at t = 0 is what PackPPI-AP consumes (AffinityPrediction.py:108-122); no reference tensor is stored for it, the
+    # oracle (pinned to the reference at the three times above) stands in
     from oracle import ref_cpu as O
-    t = torch.tensor([0.5]).repeat_interleave(B * L)
-    s_o, h_o = O.network(model.state_dict(), b, chi, t, zero_self_dihedral=True)
+    t = torch.zeros(B * L)
+    s_o, h_o = O.network(model.state_dict(), b, chi, t)
     score, hV = model.network(gb, chi.to(DEV), t)
     assert (hV.cpu() - h_o)[valid].abs().max() < 1e-4
     assert (score.cpu() - s_o)[valid].abs().max() < 5e-5
@@ -146,31 +147,118 @@ def test_sampling_sde(weights):
     assert d.max() < 1e-4, float(d.max())
 
 
-@pytest.mark.parametrize("name", ["g3_proximal_L64", "g3_proximal_L120"])
-def test_proximal(name, model):
+# ---- proximal stage (optimize.py:21-73) -----------------------------------------------------------------------------
+# The objective is a sum of HINGES (clash.py:139-149) minimised by Adam.  A hinge's gradient is discontinuous, so two
+# trajectories that differ by rounding stay together (~1e-6 rad) until the first atom pair whose overlap r_a + r_b - tol - d
+# passes through zero between them, and then separate by O(lr) at once.  Measured (tools/debug/prox_arbiter.py and the
+# step-by-step comparison recorded in DESIGN.md): on g3_proximal_L120 the pair (residue 23 atom 6, residue 93 atom 11) has
+# overlap -7.2e-6 A on this path's iterate 18 and +2.1e-6 / +2.8e-6 A on the reference's fp32 / fp64 iterates: from step 19
+# on those two residues differ by 7e-4 .. 4.5e-3 rad although every gradient evaluated at the reference's own iterates
+# agrees to 4e-8.  The reference does the same to itself: its fp32 and fp64 runs end 3.0e-3 rad apart on L64 and 2.4e-3
+# on T1124 (this path: 7.9e-4 and 2.5e-3 from the fp64 run).  Hence three kinds of assertion:
+#   (a) trajectory-independent and tight: clash value and analytic gradient AT the reference's own iterates 1..50;
+#   (b) the trajectory itself, tight while no hinge can have flipped (10 steps), the loss curve over all 50 steps, and the
+#       accepted sample's atom_rmsd;
+#   (c) after 50 steps, against the fp64 ARBITER: this path may be no farther from the reference's fp64 run than twice the
+#       farthest the reference's own fp32 run gets from it on any fixture (REF_FP32_VS_FP64_WORST).
+PROX_STEPS = (1, 5, 10, 20, 50)
+REF_FP32_VS_FP64_WORST = 3.0e-3      # rad; max over g6_prox_{L64, L120, T1124} of |ref32 - ref64| after 50 steps (L64)
+
+
+def _g6(tag):
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", f"g6_prox_{tag}.npz"))
+    b, g = load_golden(str(z["source_fixture"]))
+    return z, b, g[str(z["chi0_key"])].float()
+
+
+@pytest.mark.parametrize("tag", ["L64", "L120", "T1124", "S1500"])
+def test_clash_gradient_at_reference_iterates(tag):
+    """(a): per-residue clash and d(mean clash)/dchi at the reference's own fp32 proximal iterates vs its autograd."""
+    from packppi_amd.functional import _ctx_for
+    z, b, _ = _g6(tag)
+    ctx = _ctx_for(_gpu(b))
+    for n in PROX_STEPS:
+        x = torch.from_numpy(z[f"chi32_step{n}"]).float().to(DEV)
+        pr, dchi = ctx.clash(x, 12.0, 0.5, need_grad=True)
+        ref_pr, ref_g = z[f"per_res32_step{n}"], z[f"grad32_step{n}"]
+        assert np.abs(pr.cpu().numpy() - ref_pr).max() < 5e-5, (tag, n)                   # values up to ~20: 2e-6 relative
+        # fp32 rounding of the geometry (coordinates ~50 A) bounds both implementations' gradients in absolute terms: the
+        # reference's own fp32 autograd is 1.1e-7 from its fp64 gradient on these fixtures
+        assert np.abs(dchi.cpu().numpy() - ref_g).max() < 3e-7, (tag, n)
+        # a chi that moves no clashing atom has gradient exactly 0 in the reference's autograd; Adam would turn any
+        # rounding residue there into a full-size step
+        assert not np.any((ref_g == 0) & (dchi.cpu().numpy() != 0)), (tag, n)
+
+
+@pytest.mark.parametrize("tag", ["L64", "L120", "T1124", "S1500"])
+def test_proximal(tag):
+    """(b) + (c): 50 Adam steps from the reference's own starting angles; T1124 and S1500 are BASELINE configs 2 and 3."""
     from packppi_amd.functional import find_clash_mask, proximal_optimizer
+    z, b, chi0 = _g6(tag)
+    gb, chi0 = _gpu(b), chi0.to(DEV)
+    chis, losses = proximal_optimizer(gb, chi0, 12.0, 0.5, 1.0, 50)
+    assert len(chis) == 50 and len(losses) == 50
+    assert np.allclose(np.array(losses), z["losses32"], rtol=5e-5, atol=1e-7), np.abs(np.array(losses) / z["losses32"] - 1).max()
+    for n in (1, 5, 10):
+        d = wrapped_absdiff(chis[n - 1].cpu(), torch.from_numpy(z[f"chi32_step{n}"]))
+        assert d.max() < 2e-5, (tag, n, float(d.max()))
+    mask = find_clash_mask(gb, chi0, 12.0, 0.5)
+    assert torch.equal(chis[-1][~mask], chi0[~mask])                  # only residues above the mean clash move
+    last = chis[-1].cpu()
+    ref = torch.from_numpy(z["chi64_step50"] if "chi64_step50" in z else z["chi32_step50"])
+    d = wrapped_absdiff(last, ref)
+    assert d.max() <= 2 * REF_FP32_VS_FP64_WORST, (tag, float(d.max()))
+    # a flipped hinge moves the residues of that atom pair (and, through later flips, a few neighbours)
+    assert (d > 1e-4).sum() <= 0.1 * int(mask.sum()), (tag, int((d > 1e-4).sum()), int(mask.sum()))
+    # the accepted sample (TorsionalDiffusion.py:296-298) and its metric
+    assert (losses[-1] < losses[0]) == bool(z["losses32"][-1] < z["losses32"][0])
+    from packppi_amd.module import TDiffusionModule
+    accepted = chis[-1] if losses[-1] < losses[0] else chi0
+    m = TDiffusionModule.analyze_samples(_Metrics(), gb, accepted)
+    assert abs(float(m["atom_rmsd"]) - float(z["metric32.atom_rmsd"])) < 1e-3, (tag, float(m["atom_rmsd"]))
+
+
+class _Metrics:
+    """analyze_samples without a network plan (the proximal CLI path: src/proximal_optimize.py needs no checkpoint)."""
+    NUM_CHI_ANGLES, eps = 4, 1e-6
+
+    def _geometry_context(self, batch):
+        from packppi_amd.functional import _ctx_for
+        return _ctx_for(batch)
+
+    def compute_rmsd(self, *a):
+        from packppi_amd.module import TDiffusionModule
+        return TDiffusionModule.compute_rmsd(self, *a)
+
+
+def test_sde_device_rng_order(weights):
+    """sde mode without injected noise: the device generator is consumed exactly as the reference consumes it -- two
+    torch.normal([B*L, 4]) draws per step inside the loop, 1pi schedule first (schedule.py:225)."""
+    from packppi_amd.module import TDiffusionModule
+    b, g = load_golden("g3_sampling_sde_L33")
+    m = TDiffusionModule(weights, sample_cfg=dict(mode="sde"), device=DEV)
+    gb, init = _gpu(b), g["init_chi_seed11"].to(DEV)
+    m.add_sc_noise = lambda batch, t: (init.clone(), None)
+    torch.manual_seed(99)
+    auto = m.sampling(gb)
+    torch.manual_seed(99)
+    N = b.residue_type.numel()
+    noise = torch.stack([torch.stack([torch.normal(mean=0, std=1, size=(N, 4), device=DEV) for _ in range(2)])
+                         for _ in range(len(m.schedule) - 1)])
+    assert torch.equal(auto, m.sample_from(gb, init, noise))
+
+
+@pytest.mark.parametrize("name", ["g3_proximal_L64", "g3_proximal_L120"])
+def test_sampling_with_proximal(name, model):
+    """sampling(use_proximal=True) end to end (30 steps, injected noise) + the first 5 Adam steps of the stored run."""
+    from packppi_amd.functional import proximal_optimizer
     b, g = load_golden(name)
     gb = _gpu(b)
     init = g["init_chi_seed11"].to(DEV)
-    # The optimisation is a non-smooth (hinge) objective driven by Adam's g/sqrt(v) normalisation: perturbations
-    # grow ~1.2-1.4x per step.  Measured on these fixtures: the REFERENCE ITSELF moves by 2.8e-4 (L=64) / 3.7e-5
-    # (L=120) rad between fp32 and fp64 after 50 steps, this path by 7.6e-4 / 4.5e-3 from the fp32 reference, while
-    # both agree to <4e-6 rad through step 10 and the analytic gradient is as close to the fp64 gradient as the
-    # reference's fp32 autograd is (1.6e-7 vs 1.1e-7 abs).  So: tight bound on the early steps and on the loss
-    # curve, statistical bound on the 50-step angles (DESIGN.md "Proximal parity").
-    for n in (5, 50):
-        chis, losses = proximal_optimizer(gb, init, 12.0, 0.5, 1.0, n)
-        assert len(chis) == n and len(losses) == n
-        assert np.allclose(np.array(losses), g[f"prox_losses_{n}"].numpy(), rtol=2e-4, atol=1e-6)
-        assert wrapped_absdiff(chis[0].cpu(), g[f"prox_chi_first_{n}"]).max() < 1e-5
-        d = wrapped_absdiff(chis[-1].cpu(), g[f"prox_chi_last_{n}"])
-        mask = find_clash_mask(gb, init, 12.0, 0.5)
-        if n == 5:
-            assert d.max() < 1e-5
-        else:
-            assert d.max() < 2e-2 and (d > 1e-4).sum() <= 0.1 * mask.sum(), (float(d.max()), int((d > 1e-4).sum()))
-        assert torch.equal(chis[-1][~mask], init[~mask])
-    # sampling(use_proximal=True) end to end, 30 steps, injected noise
+    chis, losses = proximal_optimizer(gb, init, 12.0, 0.5, 1.0, 5)
+    assert np.allclose(np.array(losses), g["prox_losses_5"].numpy(), rtol=2e-5, atol=1e-7)
+    assert wrapped_absdiff(chis[0].cpu(), g["prox_chi_first_5"]).max() < 1e-5
+    assert wrapped_absdiff(chis[-1].cpu(), g["prox_chi_last_5"]).max() < 1e-5
     model.schedule = torch.linspace(1, 0, 31)
     orig = model.add_sc_noise
     model.add_sc_noise = lambda batch, t: (init.clone(), None)
@@ -179,7 +267,7 @@ def test_proximal(name, model):
     finally:
         model.add_sc_noise = orig
     d = wrapped_absdiff(res, g["chi_ode_30_proximal"])[b.SC_D_mask.bool()]
-    assert (d > 2e-4).float().mean() < 0.1 and d.max() < 2e-2, float(d.max())
+    assert d.max() <= 2 * REF_FP32_VS_FP64_WORST and (d > 1e-4).float().mean() < 0.1, float(d.max())
 
 
 def test_T1124_100_steps(model):
@@ -296,3 +384,93 @@ def test_context_workspace_reuse(weights):
     ref = {L: run(TDiffusionModule(weights, device=DEV), L, False) for L in set(seq)}
     for L, o in zip(seq, got):
         assert torch.equal(o, ref[L]), (L, float((o - ref[L]).abs().max()))
+
+
+# ---- ragged batches without padding rows (batch.pack / pp_complex_prepare_packed) ---------------------------------------
+def test_packed_batch_equals_per_complex(weights):
+    """Complexes of different lengths packed back to back (no padding rows launched) give every complex the angles it
+    gets on its own: graph, clash partners and E_idx numbering stay inside each complex."""
+    from packppi_amd import synth
+    from packppi_amd.batch import pack, unpack
+    from packppi_amd.featurize import protein_to_batch
+    from packppi_amd.module import TDiffusionModule
+    m = TDiffusionModule(weights, device=DEV)
+    cs = [protein_to_batch(synth.make_complex(n, 70 + n)).to(DEV) for n in (45, 33, 118, 64)]
+    pb = pack(cs)
+    assert pb.seg_offsets.tolist() == [0, 45, 78, 196, 260] and pb.X.shape == (1, 260, 14, 3)
+    g = torch.Generator().manual_seed(5)
+    init = ((torch.rand(1, 260, 4, generator=g) * 2 - 1) * 3.0).to(DEV) * pb.SC_D_mask
+    sched = torch.linspace(1, 0, 9)
+    ctx = m._context(pb)
+    E, _ = ctx.graph()
+    joint = ctx.sample(init, sched)
+    pr_joint = ctx.clash(joint, 12.0, 0.5)
+    for c, chi_j, init_c, E_c, pr_c in zip(cs, unpack(pb, joint), unpack(pb, init), unpack(pb, E), unpack(pb, pr_joint)):
+        solo_ctx = m._context(c)
+        solo = solo_ctx.sample(init_c, sched)
+        assert torch.equal(solo_ctx.graph()[0], E_c)                    # same neighbours, per-complex numbering
+        assert wrapped_absdiff(chi_j.cpu(), solo.cpu()).max() < 2e-5
+        assert (solo_ctx.clash(solo, 12.0, 0.5) - pr_c).abs().max() < 2e-5
+    # proximal needs one complex per context, as in the reference (optimize.py:27)
+    with pytest.raises(RuntimeError):
+        ctx.proximal(joint, 12.0, 0.5, 1.0, 2)
+    # a complex shorter than 32 residues has K = L: it cannot share a context with longer ones
+    short = protein_to_batch(synth.make_complex(20, 7)).to(DEV)
+    with pytest.raises(RuntimeError):
+        m._context(pack([cs[0], short]))
+
+
+def test_c5_shard_matches_reference(weights):
+    """BASELINE config 4's per-GPU share (32 synthetic ~300-residue complexes): sampled as ONE packed ragged batch through
+    parallel.sample_sharded, 100 steps, every complex against the reference's own CPU output on the same noise."""
+    path = os.path.join(os.path.dirname(__file__), "golden", "g7_c5_rank0.npz")
+    if not os.path.exists(path):
+        pytest.skip("g7_c5_rank0 fixture not generated")
+    from packppi_amd import synth
+    from packppi_amd.featurize import protein_to_batch
+    from packppi_amd.module import TDiffusionModule
+    from packppi_amd.parallel import METRIC_KEYS, sample_sharded
+    z = np.load(path)
+    lens = [int(x) for x in z["lengths"]]
+    assert lens == synth.c5_lengths(256)[:32]
+    m = TDiffusionModule(weights, device=DEV)
+    m.schedule = torch.linspace(1, 0, 101)
+    cs = [protein_to_batch(synth.make_complex(lens[i], 10000 + i)).to(DEV) for i in range(32)]
+    init = {i: torch.from_numpy(z[f"init_{i}"]) for i in range(32)}
+    chis, ids, rows = sample_sharded(m, cs, init_chi=init)
+    assert ids.tolist() == list(range(32)) and rows.shape == (32, len(METRIC_KEYS)) and torch.isfinite(rows).all()
+    # kNN membership ties: where the CA distances at rank 32 and 33 of a row are EXACTLY equal, which residue is a
+    # neighbour is unspecified in the reference (torch.topk; its CPU and GPU paths differ) -- this library takes the lower
+    # index.  Complex 12 of this set has one (row 8: residues 209 and 224, both 8.1029396 A away).  Such a complex is held
+    # to the reference with the reference's own choice handed in through pp_ctx_set_graph, all others as they are.
+    from oracle import ref_cpu as O
+    tied = []
+    for i, c in enumerate(cs):
+        ca = c.X[0, :, 1, :].cpu()
+        d = torch.sqrt(((ca[:, None] - ca[None]) ** 2).sum(-1) + 1e-6).sort(dim=-1)[0]
+        if bool((d[:, 31] == d[:, 32]).any()):
+            tied.append(i)
+    assert tied == [12]
+    worst = 0.0
+    for i in range(32):
+        if i in tied:
+            continue
+        d = wrapped_absdiff(chis[i].cpu(), torch.from_numpy(z[f"chi_ode_100_{i}"]))[cs[i].SC_D_mask.cpu().bool()]
+        worst = max(worst, float(d.max()))
+    assert worst < 1e-4, worst
+    for i in tied:
+        ref = torch.from_numpy(z[f"chi_ode_100_{i}"])
+        mask = cs[i].SC_D_mask.cpu().bool()
+        ctx = m._context(cs[i])
+        E_mine = ctx.graph()[0].cpu()
+        E_ref = O.knn_graph(cs[i].X[:, :, 1, :].cpu(), cs[i].residue_mask.cpu())            # torch.topk, as the reference
+        rows_differ = torch.nonzero((E_mine.sort(-1)[0] != E_ref.sort(-1)[0]).any(-1)[0]).flatten().tolist()
+        assert rows_differ == [8]                                                          # only the tied row, one member
+        assert len(set(E_mine[0, 8].tolist()) ^ set(E_ref[0, 8].tolist())) == 2
+        mine = ctx.sample(init[i].to(DEV), m.schedule).cpu()
+        assert wrapped_absdiff(mine, ref)[mask].max() > 1e-3                               # the tie matters ...
+        ctx.set_graph(E_ref)
+        given = ctx.sample(init[i].to(DEV), m.schedule).cpu()
+        assert wrapped_absdiff(given, ref)[mask].max() < 1e-4                              # ... and nothing else does
+        with pytest.raises(RuntimeError):
+            ctx.set_graph(torch.full_like(E_ref, 10_000))

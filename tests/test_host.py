@@ -167,3 +167,37 @@ def test_cli_flags_match_reference():
             assert f'"{flag}"' in src, (mod.__name__, flag)
     with pytest.raises(SystemExit):
         eval_diffusion.main(["--outdir", "x"])
+
+
+def test_pack_unpack_roundtrip():
+    """batch.pack: complexes back to back without padding rows; unpack splits per-row results again."""
+    from packppi_amd import synth
+    from packppi_amd.batch import TENSOR_KEYS, collate, pack, split, unpack
+    from packppi_amd.featurize import protein_to_batch, protein_to_data
+    ds = [protein_to_data(synth.make_complex(n, 3 + n)) for n in (40, 33, 57)]
+    pb = pack(ds)
+    assert pb.seg_offsets.tolist() == [0, 40, 73, 130] and pb.num_proteins == 1 and pb.max_size == 130
+    for k in TENSOR_KEYS:
+        parts = unpack(pb, pb[k])
+        for d, part in zip(ds, parts):
+            assert torch.equal(part[0], d[k])
+    # B = 1 batches and padded batches (via split) pack to the same thing: padding rows are dropped
+    assert torch.equal(pack([protein_to_batch(synth.make_complex(n, 3 + n)) for n in (40, 33, 57)]).X, pb.X)
+    assert torch.equal(pack(split(collate(ds))).X, pb.X)
+    with pytest.raises(ValueError):
+        pack([collate(ds)])
+
+
+def test_add_sc_noise_matches_reference_draw():
+    """TDiffusionModule.add_sc_noise (the product function, torch glue) == the reference's own draw under the same CPU
+    seed (TorsionalDiffusion.py:111-124, schedule.py:176-196): two randn_like draws, 1pi mask first."""
+    import types
+    from packppi_amd.module import TDiffusionModule
+    from .conftest import load_golden
+    for name in ("g2_ops_L8", "g2_ops_L33", "g2_ops_L64", "g2_ops_B3"):
+        b, g = load_golden(name)
+        B, L = b.residue_type.shape
+        stub = types.SimpleNamespace(_t_to_sigma=TDiffusionModule._t_to_sigma)
+        torch.manual_seed(7)
+        x, score = TDiffusionModule.add_sc_noise.__wrapped__(stub, b, torch.ones(B * L))
+        assert torch.equal(x, g["init_chi_seed7"]) and score.shape == x.shape

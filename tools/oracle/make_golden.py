@@ -213,6 +213,20 @@ def main():
         print(f"  S1500 ode 100 steps {time.time() - t0:.1f}s", flush=True)
         save("g5_S1500", **out)
 
+    # ---- g7: the first GPU's share of BASELINE config 4 (32 of the 256 synthetic ~300-residue complexes), 100 steps each ------
+    if want("g7"):
+        lens = synth.c5_lengths(256)
+        out = {"lengths": np.array(lens[:32], np.int64)}
+        t0 = time.time()
+        for i in range(32):
+            b = synth_batch(lens[i], 10000 + i)
+            rb = ref_batch(b)
+            init = seeded_init(model, rb, 20000 + i)
+            out[f"init_{i}"] = init
+            out[f"chi_ode_100_{i}"] = run_sampling(model, rb, init, 100)
+            print(f"  c5[{i}] L={lens[i]} {time.time() - t0:.0f}s", flush=True)
+        save("g7_c5_rank0", **out)
+
     # ---- g3p: proximal optimiser ------------------------------------------------------------------
     if want("g3p"):
         for tag, b in (("L64", synth_batch(64, 164)), ("L120", synth_batch(120, 1120))):

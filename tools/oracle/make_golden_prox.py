@@ -57,6 +57,9 @@ def main():
     ap.add_argument("--only", default="L64,L120,T1124,S1500")
     ap.add_argument("--no64", default="S1500", help="cases without the fp64 run (host memory)")
     ap.add_argument("--threads", type=int, default=6)
+    ap.add_argument("--append-grads", action="store_true",
+                    help="load the existing g6 files and add the reference's clash value and autograd gradient at its own fp32 "
+                         "iterates (per_res32_stepN, grad32_stepN): the trajectory-independent check of the analytic gradient")
     args = ap.parse_args()
     torch.set_num_threads(args.threads)
     from src.models.components.optimize import proximal_optimizer
@@ -64,6 +67,24 @@ def main():
 
     cases = {"L64": ("g3_proximal_L64", "init_chi_seed11"), "L120": ("g3_proximal_L120", "init_chi_seed11"),
              "T1124": ("g4_T1124", "chi_ode_100"), "S1500": ("g5_S1500", "chi_ode_100")}
+    if args.append_grads:
+        from src.models.components.clash import compute_residue_clash
+        for tag in args.only.split(","):
+            path = os.path.join(GOLD, f"g6_prox_{tag}.npz")
+            old = dict(np.load(path))
+            _, b = load_fixture(cases[tag][0])
+            rb = ref_batch(b)
+            for n in KEEP:
+                t0 = time.time()
+                x = torch.from_numpy(old[f"chi32_step{n}"]).float().requires_grad_(True)
+                pr = compute_residue_clash(rb, x, 12., 0.5)
+                pr.mean().backward()
+                old[f"per_res32_step{n}"] = pr.detach().numpy()
+                old[f"grad32_step{n}"] = x.grad.numpy()
+                print(f"  {tag} step {n}: clash mean {float(pr.mean()):.6f}  {time.time() - t0:.1f}s", flush=True)
+            np.savez_compressed(path, **old)
+            print(f"  rewrote {os.path.basename(path)} {os.path.getsize(path) / 1e6:.2f} MB", flush=True)
+        return
     for tag in args.only.split(","):
         fx, key = cases[tag]
         z, b = load_fixture(fx)
