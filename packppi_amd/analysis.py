@@ -12,7 +12,7 @@ from pathlib import Path
 import numpy as np
 import torch
 
-from .featurize import protein_to_batch
+from .featurize import chain_numbers_and_offset_index, protein_to_batch
 from .functional import get_atom14_coords
 from .pdb_io import from_pdb_file
 
@@ -94,7 +94,13 @@ class ProteinAnalysis:
         protein = from_pdb_file(Path(pdb), mse_to_met=True)
         data = protein_to_batch(protein)
         if get_interface:
-            im = interface_mask(protein, pdb)
+            # Reference behaviour kept: prot_to_data shifts the residue numbers of every chain after the first IN PLACE in the
+            # protein dict it is given (complex_dataset.py:79,91: torch.from_numpy(...).to(int64) shares memory with the
+            # int64 array the PDB reader returns), and get_interface_mask, called after it (protein_analysis.py:106-108),
+            # compares those shifted numbers with the file's own numbering -- so only residues of the first chain (and
+            # accidental number matches) can enter the interface mask, and interface_acc is an accuracy over them.
+            shifted = dict(protein, residue_index=chain_numbers_and_offset_index(protein)[1].numpy())
+            im = interface_mask(shifted, pdb)
             rm = data.residue_mask[0]
             data["interface_mask"] = ((im * rm) if im is not None else torch.zeros_like(rm)).unsqueeze(0)
         return data

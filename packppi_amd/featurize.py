@@ -53,27 +53,31 @@ def sidechain_dihedrals(X: torch.Tensor, aatype: torch.Tensor):
     return chi, (chi != 0.0).float()
 
 
+def chain_numbers_and_offset_index(protein: Dict):
+    """(chain number 1.. in order of first appearance, residue_index with every later chain pushed +100 past the already
+    shifted end of the previous one) -- complex_dataset.py:80-93.  The protein dict is left untouched."""
+    L = len(protein["aaindex"])
+    rindex = torch.from_numpy(np.asarray(protein["residue_index"])).long().clone()
+    seen = {}
+    chain_np = np.empty(L, np.int64)
+    for i, c in enumerate(list(protein["chain_id"])):
+        chain_np[i] = seen.setdefault(c, len(seen) + 1)
+    chain = torch.from_numpy(chain_np)
+    if len(seen) > 1:
+        shift = 0
+        for c in range(1, len(seen)):
+            shift += int(rindex[chain == c].max()) + 100
+            rindex[chain == c + 1] += shift
+    return chain, rindex
+
+
 def protein_to_data(protein: Dict) -> Batch:
     """Per-complex tensors (no batch axis), as ``prot_to_data`` lays them out."""
     X = torch.from_numpy(np.asarray(protein["atom_positions"])).float()
     L = X.shape[0]
     rtype = torch.from_numpy(np.asarray(protein["aaindex"])).long()
     amask = torch.from_numpy(np.asarray(protein["atom_mask"])).float()
-    rindex = torch.from_numpy(np.asarray(protein["residue_index"])).long().clone()
-
-    # chains numbered 1.. in order of first appearance
-    seen = {}
-    chain_np = np.empty(L, np.int64)
-    for i, c in enumerate(list(protein["chain_id"])):
-        chain_np[i] = seen.setdefault(c, len(seen) + 1)
-    chain = torch.from_numpy(chain_np)
-
-    # later chains are pushed +100 past the (already shifted) end of the previous one
-    if len(seen) > 1:
-        shift = 0
-        for c in range(1, len(seen)):
-            shift += int(rindex[chain == c].max()) + 100
-            rindex[chain == c + 1] += shift
+    chain, rindex = chain_numbers_and_offset_index(protein)
 
     rmask = torch.isfinite(X[:, :4].sum(dim=(-1, -2))).float()
     bb, bb_mask = backbone_dihedrals(X, rindex)

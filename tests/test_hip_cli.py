@@ -78,3 +78,27 @@ def test_padded_batch_equals_per_complex(weights):
         solo = m._context(bi).sample(init[i:i + 1, :L].to("cuda:0"), sched).cpu()
         assert (joint[i, :L] - solo[0]).abs().max() < 2e-5
         assert float(joint[i, L:].abs().sum()) == 0.0
+
+
+def test_get_metric_matches_reference(tmp_path):
+    """ProteinAnalysis.get_metric on a written true / predicted pair vs the reference's own get_metric on the same files
+    (protein_analysis.py:36-91; fixture tools/oracle/make_golden_io.py: chi recomputed from the 3-decimal files, accuracies,
+    interface accuracy, atom_rmsd; the clashscore is an external MolProbity call, a constant on both sides)."""
+    import os
+    import numpy as np
+    from packppi_amd.analysis import ProteinAnalysis
+    from packppi_amd.pdb_io import to_pdb
+    gold = os.path.join(os.path.dirname(__file__), "golden")
+    z = np.load(os.path.join(gold, "g8_io.npz"))
+    g0 = np.load(os.path.join(gold, "g0_protein_1BRS.npz"))
+    prot = {k[5:]: g0[k] for k in g0.files if k.startswith("prot.")}
+    pred = dict(prot, atom_positions=z["pred.atom_positions"])
+    (tmp_path / "true.pdb").write_text(to_pdb(prot))
+    (tmp_path / "pred.pdb").write_text(to_pdb(pred))
+    pa = ProteinAnalysis(None, str(tmp_path / "work"), device="cuda:0")
+    pa.get_clashscore = lambda pdb: 12.34
+    m = pa.get_metric(str(tmp_path / "true.pdb"), str(tmp_path / "pred.pdb"))
+    keys = [k[7:] for k in z.files if k.startswith("metric.")]
+    assert sorted(m) == sorted(keys)
+    for k in keys:
+        assert abs(float(m[k]) - float(z["metric." + k])) < 2e-5 * max(1.0, abs(float(z["metric." + k]))), (k, float(m[k]))

@@ -201,3 +201,45 @@ def test_add_sc_noise_matches_reference_draw():
         torch.manual_seed(7)
         x, score = TDiffusionModule.add_sc_noise.__wrapped__(stub, b, torch.ones(B * L))
         assert torch.equal(x, g["init_chi_seed7"]) and score.shape == x.shape
+
+
+def _g0_prot(tag):
+    z = np.load(os.path.join(GOLD, f"g0_protein_{tag}.npz"))
+    return {k[5:]: z[k] for k in z.files if k.startswith("prot.")}
+
+
+def test_to_pdb_is_byte_exact():
+    """The writer against the reference's own output (src/utils/protein.py:207-314; tools/oracle/make_golden_io.py)."""
+    import hashlib
+    z = np.load(os.path.join(GOLD, "g8_io.npz"))
+    for tag in ("1BRS", "2FTL"):
+        text = to_pdb(_g0_prot(tag))
+        assert hashlib.sha256(text.encode()).hexdigest() == str(z[f"sha256.{tag}"]), tag
+    assert to_pdb(_g0_prot("1BRS")).encode() == z["text.1BRS"].tobytes()
+    # keep_chains (protein.py:241-248)
+    only_a = to_pdb(_g0_prot("1BRS"), keep_chains=["A"])
+    assert {ln[21] for ln in only_a.splitlines() if ln.startswith("ATOM")} == {"A"}
+
+
+def test_interface_mask_matches_reference(tmp_path):
+    """ProteinAnalysis.get_prot's interface mask on a written complex == the reference's own get_prot (helper.py:104-128 fed by
+    the brute-force form of interface.py:11-56's 10 A residue search; fixture tools/oracle/make_golden_io.py) -- including
+    the reference's quirk that chains after the first are compared under shifted residue numbers (see analysis.get_prot);
+    and the residue search itself (KD-tree) against its definition."""
+    from packppi_amd.analysis import ProteinAnalysis, interface_residues
+    z = np.load(os.path.join(GOLD, "g8_io.npz"))
+    prot = _g0_prot("1BRS")
+    pdb = tmp_path / "true.pdb"
+    pdb.write_text(to_pdb(prot))
+    data = ProteinAnalysis(None, str(tmp_path / "w"), device="cpu").get_prot(str(pdb), get_interface=True)
+    assert torch.equal(data.interface_mask, torch.from_numpy(z["interface_mask"]))
+    assert 0 < int(data.interface_mask.sum()) < data.interface_mask.numel()
+    # the search: residues of either chain with an atom within 10 A of the other chain, by brute force
+    xyz = prot["atom_positions"][prot["atom_mask"] > 0.5]
+    owner = np.repeat(np.arange(len(prot["aaindex"])), (prot["atom_mask"] > 0.5).sum(1))
+    xyz = np.round(xyz.astype(np.float64), 3)                                        # the file holds 3 decimals
+    d = np.linalg.norm(xyz[:, None] - xyz[None], axis=-1)
+    chain_of = prot["chain_id"][owner]
+    hit = ((d <= 10.0) & (chain_of[:, None] != chain_of[None])).any(1)
+    want = {c: sorted(set(prot["residue_index"][owner[hit & (chain_of == c)]].tolist())) for c in np.unique(prot["chain_id"])}
+    assert interface_residues(str(pdb)) == want

@@ -55,3 +55,83 @@ def test_gather_metric_rows_gloo_world2(lens):
         assert ids == list(range(len(lens)))
         for i, row in zip(ids, rows):
             assert row == [float(i) + 0.5 * k for k in range(len(METRIC_KEYS))]
+
+
+class _FakeModel:
+    """CPU stand-in for TDiffusionModule on the sharded path: 'sampling' is a fixed function of the packed rows, so the
+    packing, unpacking, shard assignment and gather can be checked without a GPU."""
+    device = torch.device("cpu")
+
+    def __init__(self):
+        from types import SimpleNamespace
+        self.hparams = SimpleNamespace(sample_cfg=SimpleNamespace(violation_tolerance_factor=12., clash_overlap_tolerance=0.5,
+                                                                  lamda=1., num_steps=2))
+        self.packed_shapes = []
+
+    def sample_from(self, batch, x0, sde_noise=None):
+        assert batch.num_proteins == 1 and x0.shape == (1, batch.max_size, 4)
+        self.packed_shapes.append((int(batch.max_size), batch.seg_offsets.tolist()))
+        return 0.5 * x0 + batch.residue_type[..., None].float() * 0.01
+
+    def analyze_samples(self, batch, chi):
+        d = {k: torch.tensor(0.0) for k in METRIC_KEYS}
+        d["atom_rmsd"] = chi.sum()
+        d["chi_0_acc"] = torch.tensor(float(batch.max_size))
+        return d
+
+
+def _sharded_worker(rank, world, port, q):
+    from packppi_amd import synth
+    from packppi_amd.featurize import protein_to_batch
+    from packppi_amd.parallel import sample_sharded
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lens = [40, 20, 57, 33, 64]                      # the 20-residue complex (K = 20) must go alone
+    cs = [protein_to_batch(synth.make_complex(n, 50 + n)) for n in lens]
+    g = torch.Generator().manual_seed(1)
+    init = {i: torch.rand(1, n, 4, generator=g) for i, n in enumerate(lens)}
+    model = _FakeModel()
+    chis, ids, rows = sample_sharded(model, cs, init_chi=init, max_rows=100)
+    expect = {i: 0.5 * init[i] + cs[i].residue_type[..., None].float() * 0.01 for i in chis}
+    ok = all(torch.equal(chis[i], expect[i]) for i in chis)
+    q.put((rank, sorted(chis), model.packed_shapes, ids.tolist(), rows[:, METRIC_KEYS.index("chi_0_acc")].tolist(), ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sample_sharded_packs_and_gathers_gloo_world2():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    lens = [40, 20, 57, 33, 64]
+    owned = []
+    for rank, mine, shapes, ids, sizes, ok in got:
+        assert ok and mine == shard_complexes(lens, world)[rank]
+        owned += mine
+        assert ids == list(range(5)) and sizes == [float(n) for n in lens]          # every rank sees every row
+        for total, offs in shapes:                                                  # packed groups: no padding rows
+            seg = [b - a for a, b in zip(offs[:-1], offs[1:])]
+            assert total == sum(seg) and (min(seg) >= 32 or len(seg) == 1) and (total <= 100 or len(seg) == 1)
+    assert sorted(owned) == list(range(5))
+
+
+def test_bench_refuses_a_rank_count_mismatch():
+    """bench.py --gpus N under a launcher with a different WORLD_SIZE exits non-zero before touching any GPU."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True,
+                       timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=3" in (r.stderr + r.stdout)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "0"], env=env, capture_output=True, text=True,
+                       timeout=120)
+    assert r.returncode != 0

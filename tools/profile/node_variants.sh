@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 for v in $1; do
   OUT=$ROOT/gpurun_out/nv_$v; mkdir -p $OUT
   if [ "$v" = base ]; then export PACKPPI_LIB=$ROOT/packppi_amd/csrc/libpackppi_hip.so; else export PACKPPI_LIB=$ROOT/packppi_amd/csrc/libpackppi_hip.$v.so; fi
-  (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o run -- python3 $ROOT/bench.py --steps 2 --warmup 1 --cpu-steps 0 --workload ${WORKLOAD:-t1124} > $OUT/bench.json 2> $OUT/err.txt)
+  (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o run -- python3 $ROOT/bench.py --steps 2 --warmup 1 --cpu-steps 0 --no-secondary --workload ${WORKLOAD:-t1124} > $OUT/bench.json 2> $OUT/err.txt)
   f=$(find $OUT -name "*kernel_stats.csv" | head -1)
   echo "== $v"; python3 - "$f" <<'PY'
 import csv, sys

@@ -8,7 +8,7 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-BENCH="python3 $ROOT/bench.py --steps 2 --warmup 1 --cpu-steps 0"
+BENCH="python3 $ROOT/bench.py --steps 2 --warmup 1 --cpu-steps 0 --no-secondary"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o run -- $BENCH > $OUT/stats.json 2> $OUT/stats.err
 echo "stats pass done"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o run -- $BENCH > $OUT/fetch.json 2> $OUT/fetch.err

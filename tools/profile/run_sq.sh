@@ -6,7 +6,7 @@ OUT=$ROOT/gpurun_out/sq
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-BENCH="python3 $ROOT/bench.py --steps 1 --warmup 1 --cpu-steps 0"
+BENCH="python3 $ROOT/bench.py --steps 1 --warmup 1 --cpu-steps 0 --no-secondary"
 i=0
 for SET in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" \
            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC" \

@@ -12,7 +12,7 @@ import os
 import sys
 from collections import defaultdict
 
-ROUND = os.environ.get("GRAFT_ROUND", "r01")
+ROUND = os.environ.get("GRAFT_ROUND", "r02")
 
 
 def short(name):
@@ -65,7 +65,7 @@ def main(out, tag):
         traffic[k] = {"launches": n, "fetch_size_kib_raw": fk, "write_size_kib_raw": wk,
                       "fetch_bytes": 2.0 * fk * 1024.0, "write_bytes": wk * 1024.0,
                       "hbm_bytes": 2.0 * fk * 1024.0 + wk * 1024.0}
-    meta = {"command": "python3 bench.py --steps 2 --warmup 1 --cpu-steps 0",
+    meta = {"command": "python3 bench.py --steps 2 --warmup 1 --cpu-steps 0 --no-secondary",
             "correction": "FETCH_SIZE KiB x1024 x2 (gfx950 tallies 128-B requests at 64 B); WRITE_SIZE KiB x1024",
             "kernels": traffic}
     with open(os.path.join(prof, f"{ROUND}_{tag}_pmc_traffic.json"), "w") as fh:
