@@ -55,18 +55,35 @@ def build_library(force=False, verbose=True, extra_flags=(), tag=""):
     return lib_path
 
 
-def compile_alternate(verbose=True):
-    """Compile (not link) the edge-kernel source the library was NOT built from, so that both variants are known to build."""
-    src = "pp_edge.hip" if EDGE_F16 else "pp_edge_f16.hip"
+def other_variant_path():
+    return LIB.replace(".so", ".f32.so" if EDGE_F16 else ".f16.so")
+
+
+def build_other_variant(verbose=True):
+    """Build the library of the edge-kernel variant the default one was NOT built from (``libpackppi_hip.f32.so`` next to
+    the default split-f16 build): every source is recompiled, since the weight packing and the edge embedding differ too.
+    The GPU tests run the end-to-end parity cases on it as well (PACKPPI_LIB)."""
+    out = other_variant_path()
+    tag = "f32" if EDGE_F16 else "f16"
+    sources = ["pp_api.hip", "pp_prepare.hip", "pp_node.hip", "pp_edge.hip" if EDGE_F16 else "pp_edge_f16.hip", "pp_clash.hip"]
     flags = [f for f in FLAGS if f != "-DPP_EDGE_F16"] + ([] if EDGE_F16 else ["-DPP_EDGE_F16"])
-    obj = os.path.join(CSRC, src.replace(".hip", ".alt.o"))
-    if os.path.exists(obj) and os.path.getmtime(obj) > os.path.getmtime(os.path.join(CSRC, src)):
-        return obj
-    cmd = [_hipcc(), *flags, "-c", os.path.join(CSRC, src), "-o", obj]
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
+    if os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps):
+        return out
+    hipcc = _hipcc()
+    objs = []
+    for src in sources:
+        obj = os.path.join(CSRC, src.replace(".hip", f".{tag}.o"))
+        cmd = [hipcc, *flags, "-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+        objs.append(obj)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, *objs]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
-    return obj
+    return out
 
 
 if __name__ == "__main__":

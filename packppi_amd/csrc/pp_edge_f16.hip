@@ -118,6 +118,8 @@ struct EdgeArgs {
     const float *pts2, *PA2, *PC2, *b_mid2;   // fused edge update: node-level inputs / bias of the NEXT node message
     float *Znm, *Zem;          // k_edge_static outputs
     float *dbg;                // diagnostics: [N][4 waves][64 lanes][8] or null
+    int n_pairs;               // k_edge_update_mix: workgroups with two residues (the rest have one)
+    int mix_mode;
 };
 enum { P_BMID = 0, P_BOUT = 128, P_FOB = 256, P_G2 = 384, P_BE2 = 512, P_FIB = 640 };
 
@@ -445,14 +447,14 @@ __device__ __forceinline__ void geometry_share(const float *__restrict__ pts_i, 
     AOp AR[NRING];                                                                                             \
     _Pragma("unroll") for (int pk = 0; pk < PP_WDEPTH && pk < (NCH); pk++) gload_A(wq, pk, AR[pk]);
 
-// The R residues of workgroup b are rows b R .. b R + R - 1.  `live` = in range and not masked; a dead slot computes on
+// The R residues of a workgroup are rows res0 .. res0 + R - 1.  `live` = in range and not masked; a dead slot computes on
 // a live residue's inputs (no garbage enters the pipes) and stores nothing.  All of it is wave-uniform.
 #define GROUP_SETUP()                                                                          \
     int n[R];                                                                                  \
     bool live[R], inr[R];                                                                      \
     int first = -1;                                                                            \
     _Pragma("unroll") for (int r = 0; r < R; r++) {                                            \
-        const int nr = blockIdx.x * R + r;                                                     \
+        const int nr = res0 + r;                                                               \
         inr[r] = nr < A.N;                                                                     \
         n[r] = inr[r] ? nr : A.N - 1;                                                          \
         live[r] = inr[r] && A.rmask[n[r]] != 0.f;                                              \
@@ -501,9 +503,7 @@ __device__ __forceinline__ float ln_merge(const float *st, int j, float &mean_ou
 // node message: S[i] = (1/K) sum_j mask_ij relu(W_mid relu(W_in [..]) + b), msum[i] = (1/K) sum_j mask_ij
 // ---------------------------------------------------------------------------------------------
 template <int R, bool ST0>
-__global__ void __launch_bounds__(ET, R == 1 ? PP_WGS : PP_WGS2)
-k_node_message(EdgeArgs A) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+__device__ __forceinline__ void node_message_body(const EdgeArgs &A, const int res0, float *smem) {
     constexpr int NXB = R == 1 ? PP_NXB_R1 : 1;
     float *const xb0 = smem;
     float *xbuf = xb0;
@@ -578,6 +578,13 @@ k_node_message(EdgeArgs A) {
     }
 }
 
+template <int R, bool ST0>
+__global__ void __launch_bounds__(ET, R == 1 ? PP_WGS : PP_WGS2)
+k_node_message(EdgeArgs A) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    node_message_body<R, ST0>(A, blockIdx.x * R, smem);
+}
+
 // ---------------------------------------------------------------------------------------------
 // edge update: h_E <- mask * LN3(x1 + FFN(x1)),  x1 = LN2(h_E + mask * MLP3([..]))
 // ---------------------------------------------------------------------------------------------
@@ -600,9 +607,7 @@ k_node_message(EdgeArgs A) {
 // holds; the node-level inputs PA2 / PC2 / pts2 were written by the node update that ran before this kernel): one
 // launch, one prologue and one read of h_E less per layer.
 template <int R, bool ST0, bool FUSE>
-__global__ void __launch_bounds__(ET, R == 1 ? PP_WGS : PP_WGS2)
-k_edge_update(EdgeArgs A) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+__device__ __forceinline__ void edge_update_body(const EdgeArgs &A, const int res0, float *smem) {
     constexpr int NXB = R == 1 ? PP_NXB_R1 : 1;
     float *const xb0 = smem;
     float *xbuf = xb0, *x1buf = smem + NXB * R * XBUF_FLOATS, *stat = x1buf + R * XBUF_FLOATS,
@@ -801,6 +806,37 @@ k_edge_update(EdgeArgs A) {
 #endif
 }
 
+template <int R, bool ST0, bool FUSE>
+__global__ void __launch_bounds__(ET, R == 1 ? PP_WGS : PP_WGS2)
+k_edge_update(EdgeArgs A) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    edge_update_body<R, ST0, FUSE>(A, blockIdx.x * R, smem);
+}
+
+// MIXED launch for one complex that fills the chip once (2 < residues per CU <= 3).  Every workgroup streams the layer's
+// whole weight set through its CU's vector memory path (64 B/clk): with three one-residue workgroups per CU that is 2.8 MB
+// per CU and launch, ~20 us -- longer than the matrix work (16 us).  Here a CU hosts TWO workgroups, one with two residues
+// (each weight fetch feeds two accumulator chains) and one with one: the same three residues and the same MFMA work per CU
+// for two passes of the stream instead of three.  Workgroups 0 .. n_pairs - 1 take residues (2 b, 2 b + 1), the others one
+// residue each; in dispatch order the first half lands on distinct CUs, so a CU mostly gets one of each kind (placement is
+// the hardware's choice: it only affects speed).  A residue's kind is a function of (index, N): results are reproducible.
+template <bool ST0, bool FUSE>
+__global__ void __launch_bounds__(ET, 2)
+k_edge_update_mix(EdgeArgs A) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int b = blockIdx.x;
+    int pair = -1, single = -1;
+    if (A.mix_mode == 2) {               // experiment: kinds interleaved in dispatch order
+        const int ns = gridDim.x - A.n_pairs;
+        if (b < 2 * ns) { if (b & 1) single = b >> 1; else pair = b >> 1; }
+        else pair = b - ns;
+    } else {
+        if (b < A.n_pairs) pair = b; else single = b - A.n_pairs;
+    }
+    if (pair >= 0) edge_update_body<2, ST0, FUSE>(A, 2 * pair, smem);
+    else edge_update_body<1, ST0, FUSE>(A, 2 * A.n_pairs + single, smem);
+}
+
 // ---------------------------------------------------------------------------------------------
 // once per complex: Z_nm = W_B(node message, layer 0) h_E0 and Z_em = W_B(edge message, layer 0) h_E0.  h_E0 never
 // changes during sampling, so the layer-0 kernels skip four of their stages and start from these tiles.
@@ -996,6 +1032,8 @@ static EdgeArgs edge_args(pp_ctx *c, int layer, bool edge) {
     const LayerOff &o = p->off.layer[layer];
     EdgeArgs A;
     A.N = c->N; A.K = c->K; A.inv_K = 1.0f / (float)c->K;
+    A.n_pairs = 0;
+    A.mix_mode = 0;
     A.rmask = c->b.residue_mask;
     A.eidx = c->eidx; A.mask_att = c->mask_att; A.frames = c->frames;
     A.pts = edge ? c->ptsE : c->ptsN;
@@ -1064,6 +1102,8 @@ static bool edge_attrs() {
             for (int st0 = 0; st0 < 2 && ok; st0++)
                 ok = set(reinterpret_cast<const void *>(nm_kernel_r(R, st0)), MAX_SMEM) &&
                      set(reinterpret_cast<const void *>(eu_kernel_r(R, st0)), MAX_SMEM);
+        ok = ok && set(reinterpret_cast<const void *>(k_edge_update_mix<true, PP_FUSED>), MAX_SMEM) &&
+             set(reinterpret_cast<const void *>(k_edge_update_mix<false, PP_FUSED>), MAX_SMEM);
         int dev = 0;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
@@ -1087,6 +1127,17 @@ static int pick_R(int N) {
     }
     if (g_forced_R >= 1 && g_forced_R <= PP_RMAX) return g_forced_R;
     return N > PP_WGS * g_num_cu ? 2 : 1;
+}
+
+// mixed launch (k_edge_update_mix): when one-residue workgroups would sit three to a CU in a single round
+static int g_mix = -1;
+static bool use_mix(int N) {
+    if (g_mix < 0) {
+        const char *e = getenv("PP_EDGE_MIX");
+        g_mix = e ? atoi(e) : 1;
+    }
+    if (g_forced_R >= 1 || !g_mix) return false;
+    return N > 2 * g_num_cu && N <= 3 * g_num_cu;
 }
 
 // resident workgroups per CU the runtime predicts for the two kernels (measurement aid)
@@ -1130,6 +1181,16 @@ pp_status pp_launch_edge_update(pp_ctx *c, int layer, hipStream_t s) {
     if (layer < 0 || layer > 1) { pp_set_error("pp_launch_edge_update: layer must be 0 or 1"); return PP_ERR_INVALID; }
     EdgeArgs A = edge_args(c, layer, true);
     const int R = pick_R(c->N);
+    if (use_mix(c->N)) {
+        // three residues per CU as one two-residue and one one-residue workgroup
+        A.n_pairs = (c->N + 2) / 3;
+        A.mix_mode = g_mix;
+        const int singles = c->N - 2 * A.n_pairs > 0 ? c->N - 2 * A.n_pairs : 0;
+        PP_LAUNCH(c, (layer == 0 ? k_edge_update_mix<true, PP_FUSED> : k_edge_update_mix<false, PP_FUSED>),
+                  dim3(A.n_pairs + singles), dim3(ET), eu_smem(2) > eu_smem(1) ? eu_smem(2) : eu_smem(1), s, A);
+        PP_HIP_CHECK(hipGetLastError());
+        return PP_OK;
+    }
     PP_LAUNCH(c, eu_kernel_r(R, layer == 0), dim3((c->N + R - 1) / R), dim3(ET), eu_smem(R), s, A);
     PP_HIP_CHECK(hipGetLastError());
     return PP_OK;

@@ -474,3 +474,32 @@ def test_c5_shard_matches_reference(weights):
         assert wrapped_absdiff(given, ref)[mask].max() < 1e-4                              # ... and nothing else does
         with pytest.raises(RuntimeError):
             ctx.set_graph(torch.full_like(E_ref, 10_000))
+
+
+# ---- the other build of the edge kernels (exact-fp32 MFMA, csrc/pp_edge.hip -> libpackppi_hip.f32.so) -----------------
+def test_library_variant_is_the_requested_one():
+    """PACKPPI_EXPECT_VARIANT (set by test_fp32_variant_library's child run): the loaded library really is that build."""
+    from packppi_amd import lib as L
+    want = os.environ.get("PACKPPI_EXPECT_VARIANT")
+    got = L.load().pp_edge_variant()
+    assert got in (0, 1) and (want is None or got == int(want))
+
+
+def test_fp32_variant_library():
+    """The end-to-end parity cases once more on the exact-fp32 edge kernels (one child test run with PACKPPI_LIB)."""
+    import subprocess
+    import sys
+    from packppi_amd.build import other_variant_path
+    lib = other_variant_path()
+    if os.environ.get("PACKPPI_LIB"):
+        pytest.skip("already a child run")
+    if not os.path.exists(lib):
+        pytest.skip(f"{os.path.basename(lib)} not built (__graft_entry__.build() builds it)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PACKPPI_LIB=lib, PACKPPI_EXPECT_VARIANT="0" if lib.endswith(".f32.so") else "1")
+    sel = ("test_library_variant_is_the_requested_one or test_graph or test_network or test_sampling_ode or test_sampling_sde "
+           "or test_T1124_100_steps or test_S1500_100_steps or test_sampling_is_bit_reproducible or test_packed_batch")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_hip_parity.py"), "-q", "-x", "-m", "gpu",
+                        "-k", sel, "-p", "no:cacheprovider"], env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+    assert " passed" in r.stdout
