@@ -522,6 +522,7 @@ static pp_status prepare_impl(pp_plan *plan, const pp_batch *b, const int32_t *s
     ALLOC(px, N * 4); ALLOC(pm, N * 4); ALLOC(pv, N * 4); ALLOC(pz, N * 4); ALLOC(pxeff, N * 4); ALLOC(pmask, N);
     ALLOC(scal, 64);
     ALLOC(seg, N);
+    ALLOC(prox_part, (size_t)PP_PROX_CHUNK * ((N + 15) / 16));
     c->max_steps = 1 << 20;
 #undef ALLOC
     c->last_stream = static_cast<hipStream_t>(stream);

@@ -63,6 +63,18 @@ __device__ __forceinline__ float sel8(const float (&v)[8], int g) {
 // every lane up to its group), lane 14 walks the whole chain and emits the four chi axes, and the per-residue
 // reductions (bounding spheres, side-chain atom count) are 16-lane butterflies.  (One thread per residue took 26 us
 // at T1124 -- a 3000-instruction dependent chain on 12 waves; this layout takes ~5.)
+// One Adam step of the proximal optimiser on the block's own residues, fused in front of the reconstruction that needs its
+// result (UPD instances of k_atom14): loss_t is reduced per block into `loss_part` and summed in block order afterwards
+// (k_prox_losses), so the loss curve does not depend on arrival order.
+struct ProxUpd {
+    int t, nblocks;
+    float lamda, step_size, bc2s, inv_n;
+    const float *per_res, *dchi, *chi0, *z;
+    const uint8_t *mask;
+    float *x, *m, *v, *xeff, *traj, *last, *loss_part;
+};
+
+template <bool UPD>
 __global__ void __launch_bounds__(256)
 k_atom14(int N, const float *__restrict__ X, const int64_t *__restrict__ rtype,
          const float *__restrict__ BB_D, const float *__restrict__ chi,
@@ -71,7 +83,7 @@ k_atom14(int N, const float *__restrict__ X, const int64_t *__restrict__ rtype,
          const float *__restrict__ atom_exists, const float *__restrict__ between_radius,
          const int64_t *__restrict__ rindex,
          float *__restrict__ xyz, float *__restrict__ axes, float *__restrict__ brad,
-         float4 *__restrict__ rec) {
+         float4 *__restrict__ rec, ProxUpd U) {
     const int a = threadIdx.x & 15;
     const int nraw = blockIdx.x * 16 + (threadIdx.x >> 4);
     const bool live = nraw < N;
@@ -96,10 +108,50 @@ k_atom14(int N, const float *__restrict__ X, const int64_t *__restrict__ rtype,
 #pragma unroll
     for (int r = 0; r < 3; r++) { G.R.m[3 * r] = av[r]; G.R.m[3 * r + 1] = bv[r]; G.R.m[3 * r + 2] = cv[r]; G.t[r] = ca[r]; }
 
+    const float *df = default_frames + (size_t)S * 8 * 16;
+    const int g = a < 14 ? a2g[S * 14 + a] : (a == 14 ? 7 : 0);     // lane 14 walks the full chi chain
+    // (everything above is independent of the angles: its loads are in flight while the Adam step below runs)
+    if constexpr (UPD) {
+        // loss_t = mean_n [sum_k (xeff - z)^2 + lamda per_res] at the incoming iterate; then torch.optim.Adam defaults
+        // (lr 1e-2, betas (0.9, 0.999), eps 1e-8, bias-corrected; step_size = lr / (1 - beta1^t) and bc2s = sqrt(1 - beta2^t)
+        // come from the host in double); outputs as optimize.py:66-71.  Lane k < 4 of a residue's 16 lanes owns chi_k.
+        __shared__ float s_q[16];
+        const int k = threadIdx.x & 15, grp = threadIdx.x >> 4, nn = blockIdx.x * 16 + grp;
+        float q = 0.f;
+        if (nn < N && k < 4) {
+            const size_t e = (size_t)nn * 4 + k;
+            const float d = U.xeff[e] - U.z[e];
+            q = fabsf(d) * fabsf(d);
+            const bool mk = U.mask[nn] != 0;
+            const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
+            float g = 0.f;
+            if (mk) g = 2.f * (U.x[e] - U.z[e]) * U.inv_n + U.lamda * U.dchi[e];
+            const float mm = U.m[e] + (g - U.m[e]) * (1.f - b1);             // exp_avg.lerp_(grad, 1 - beta1)
+            const float vv = U.v[e] * b2 + (1.f - b2) * (g * g);
+            const float denom = sqrtf(vv) / U.bc2s + eps;
+            const float xn = U.x[e] - U.step_size * (mm / denom);
+            U.m[e] = mm; U.v[e] = vv; U.x[e] = xn;
+            const float outv = mk ? xn : U.chi0[e];
+            U.xeff[e] = outv;
+            if (U.traj) U.traj[(size_t)U.t * N * 4 + e] = outv;
+            if (U.last) U.last[e] = outv;
+        }
+        q += __shfl_xor(q, 1, 16);
+        q += __shfl_xor(q, 2, 16);
+        if (k == 0) s_q[grp] = nn < N ? q + U.lamda * U.per_res[nn] : 0.f;
+        __syncthreads();                      // the block's new angles (read below through `chi`) and its loss terms
+        if (threadIdx.x == 0) {
+            float tt = 0.f;
+            for (int i = 0; i < 16; i++) tt += s_q[i];
+            U.loss_part[(size_t)U.t * U.nblocks + blockIdx.x] = tt;
+        }
+    }
     // the 7 angles as normalised (sin, cos): lane k < 7 evaluates angle k (phi-like 0..2, chi 3..6); group g uses angle g-1
     float my_s = 0.f, my_c = 1.f;
     if (a < 7) {
-        const float ang = a < 3 ? BB_D[(size_t)n * 3 + a] : chi[(size_t)n * 4 + (a - 3)];
+        // (UPD: the angles this block has just written; not through the __restrict__ input pointer)
+        const float *ch = UPD ? static_cast<const float *>(U.xeff) : chi;
+        const float ang = a < 3 ? BB_D[(size_t)n * 3 + a] : ch[(size_t)n * 4 + (a - 3)];
         const float s0 = sinf(ang), c0 = cosf(ang);
         const float den = sqrtf(fmaxf(s0 * s0 + c0 * c0, 1e-12f));
         my_s = s0 / den; my_c = c0 / den;
@@ -109,8 +161,6 @@ k_atom14(int N, const float *__restrict__ X, const int64_t *__restrict__ rtype,
 #pragma unroll
     for (int g = 1; g < 8; g++) { sn[g] = __shfl(my_s, g - 1, 16); cs[g] = __shfl(my_c, g - 1, 16); }
 
-    const float *df = default_frames + (size_t)S * 8 * 16;
-    const int g = a < 14 ? a2g[S * 14 + a] : (a == 14 ? 7 : 0);     // lane 14 walks the full chi chain
     const int g0 = g < 4 ? g : 4;
     Rig chain = torsion_frame(df, g0, sel8(sn, g0), sel8(cs, g0));
     const bool axis_lane = a == 14 && axes != nullptr && live;
@@ -388,58 +438,22 @@ k_prox_init(int N, const float *__restrict__ per_res, const float *__restrict__ 
     }
 }
 
-// loss_t = mean_n sum_k (xeff - z)^2 + lamda * mean_n per_res ; then one Adam step on x ; then outputs
-__global__ void __launch_bounds__(1024)
-k_prox_step(int N, int t, float lamda, float step_size, float bc2s, const float *__restrict__ per_res, const float *__restrict__ dchi,
-            const float *__restrict__ chi0, const uint8_t *__restrict__ mask, const float *__restrict__ z,
-            float *__restrict__ x, float *__restrict__ m, float *__restrict__ v, float *__restrict__ xeff,
-            float *__restrict__ losses, float *__restrict__ traj, float *__restrict__ last) {
-    __shared__ float s_part[16];
-    const float inv_n = 1.f / (float)N;
+// losses[t0 + t] = (1 / N) sum over blocks, in block order, of the partial sums the UPD kernels left
+__global__ void k_prox_losses(int nt, int nblocks, float inv_n, const float *__restrict__ part, float *__restrict__ losses) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nt) return;
     float s = 0.f;
-    for (int n = threadIdx.x; n < N; n += 1024) {
-        float q = 0.f;
-        for (int k = 0; k < 4; k++) {
-            float d = xeff[(size_t)n * 4 + k] - z[(size_t)n * 4 + k];
-            q += fabsf(d) * fabsf(d);
-        }
-        s += q + lamda * per_res[n];
-    }
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        float tt = 0.f;
-        for (int w = 0; w < 16; w++) tt += s_part[w];
-        losses[t] = tt * inv_n;
-    }
-    // torch.optim.Adam defaults: lr 1e-2, betas (0.9, 0.999), eps 1e-8, bias-corrected
-    // (step_size = lr / (1 - beta1^t) and bc2s = sqrt(1 - beta2^t) come from the host in double)
-    const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
-    for (int e = threadIdx.x; e < N * 4; e += 1024) {
-        const int n = e >> 2;
-        const bool mk = mask[n] != 0;
-        float g = 0.f;
-        if (mk) g = 2.f * (x[e] - z[e]) * inv_n + lamda * dchi[e];
-        float mm = m[e] + (g - m[e]) * (1.f - b1);             // exp_avg.lerp_(grad, 1 - beta1)
-        float vv = v[e] * b2 + (1.f - b2) * (g * g);
-        float denom = sqrtf(vv) / bc2s + eps;
-        float xn = x[e] - step_size * (mm / denom);
-        m[e] = mm; v[e] = vv; x[e] = xn;
-        const float outv = mk ? xn : chi0[e];
-        xeff[e] = outv;
-        if (traj) traj[(size_t)t * N * 4 + e] = outv;
-        if (last) last[e] = outv;
-    }
+    for (int b = 0; b < nblocks; b++) s += part[(size_t)t * nblocks + b];
+    losses[t] = s * inv_n;
 }
 
 pp_status pp_launch_atom14(pp_ctx *c, const float *chi, float *xyz, hipStream_t s) {
     const pp_plan *p = c->plan;
     // the packed records feed k_clash; they need the residue numbering, which geometry-only batches may not carry
     float4 *rec = c->b.residue_index ? reinterpret_cast<float4 *>(c->rec) : nullptr;
-    hipLaunchKernelGGL(k_atom14, dim3((c->N + 15) / 16), dim3(256), 0, s, c->N, c->b.X, c->b.residue_type, c->b.BB_D, chi,
+    hipLaunchKernelGGL(k_atom14<false>, dim3((c->N + 15) / 16), dim3(256), 0, s, c->N, c->b.X, c->b.residue_type, c->b.BB_D, chi,
                        p->default_frames, p->atom14_to_group, p->atom14_mask, p->lit_positions, c->b.atom_mask,
-                       p->between_radius, c->b.residue_index, xyz, c->axes, c->brad, rec);
+                       p->between_radius, c->b.residue_index, xyz, c->axes, c->brad, rec, ProxUpd{});
     PP_HIP_CHECK(hipGetLastError());
     return PP_OK;
 }
@@ -457,18 +471,36 @@ pp_status pp_launch_clash(pp_ctx *c, const float *xyz, float *per_res, float *dc
 pp_status pp_launch_proximal(pp_ctx *c, const float *chi, float lamda, int nsteps, float *traj, float *chi_last,
                              float *losses, hipStream_t s) {
     pp_status st;
+    const pp_plan *p = c->plan;
     // clash mask at the incoming angles (optimize.py:5-18)
     if ((st = pp_launch_atom14(c, chi, c->xyz, s)) != PP_OK) return st;
     if ((st = pp_launch_clash(c, c->xyz, c->per_res, nullptr, s)) != PP_OK) return st;
     hipLaunchKernelGGL(k_prox_init, dim3(1), dim3(1024), 0, s, c->N, c->per_res, chi, c->pmask, c->pz, c->px, c->pm,
                        c->pv, c->pxeff);
+    // Per Adam step two launches: [step t on the block's residues + reconstruction at the new angles] and [clash + gradient
+    // there].  Loss terms are parked per block and reduced in block order, PP_PROX_CHUNK steps at a time.
+    const int nblocks = (c->N + 15) / 16;
+    float4 *rec = reinterpret_cast<float4 *>(c->rec);
+    if ((st = pp_launch_atom14(c, c->pxeff, c->xyz, s)) != PP_OK) return st;
+    if ((st = pp_launch_clash(c, c->xyz, c->per_res, c->dchi, s)) != PP_OK) return st;
     for (int t = 0; t < nsteps; t++) {
-        if ((st = pp_launch_atom14(c, c->pxeff, c->xyz, s)) != PP_OK) return st;
-        if ((st = pp_launch_clash(c, c->xyz, c->per_res, c->dchi, s)) != PP_OK) return st;
         const double bc1 = 1.0 - pow(0.9, (double)(t + 1)), bc2 = 1.0 - pow(0.999, (double)(t + 1));
-        hipLaunchKernelGGL(k_prox_step, dim3(1), dim3(1024), 0, s, c->N, t, lamda, (float)(1e-2 / bc1),
-                           (float)sqrt(bc2), c->per_res, c->dchi, chi, c->pmask,
-                           c->pz, c->px, c->pm, c->pv, c->pxeff, losses, traj, chi_last);
+        ProxUpd U;
+        U.t = t; U.nblocks = nblocks;
+        U.lamda = lamda; U.step_size = (float)(1e-2 / bc1); U.bc2s = (float)sqrt(bc2); U.inv_n = 1.0f / (float)c->N;
+        U.per_res = c->per_res; U.dchi = c->dchi; U.chi0 = chi; U.z = c->pz; U.mask = c->pmask;
+        U.x = c->px; U.m = c->pm; U.v = c->pv; U.xeff = c->pxeff; U.traj = traj; U.last = chi_last;
+        U.loss_part = c->prox_part;
+        U.t = t % PP_PROX_CHUNK;
+        float *traj_t = traj ? traj + (size_t)(t - U.t) * c->N * 4 : nullptr;     // U.t indexes within the chunk
+        U.traj = traj_t;
+        hipLaunchKernelGGL(k_atom14<true>, dim3(nblocks), dim3(256), 0, s, c->N, c->b.X, c->b.residue_type, c->b.BB_D, c->pxeff,
+                           p->default_frames, p->atom14_to_group, p->atom14_mask, p->lit_positions, c->b.atom_mask,
+                           p->between_radius, c->b.residue_index, c->xyz, c->axes, c->brad, rec, U);
+        const bool chunk_end = U.t == PP_PROX_CHUNK - 1 || t == nsteps - 1;
+        if (chunk_end)
+            hipLaunchKernelGGL(k_prox_losses, dim3(1), dim3(64), 0, s, U.t + 1, nblocks, U.inv_n, c->prox_part, losses + (t - U.t));
+        if (t + 1 < nsteps && (st = pp_launch_clash(c, c->xyz, c->per_res, c->dchi, s)) != PP_OK) return st;
     }
     PP_HIP_CHECK(hipGetLastError());
     return PP_OK;

@@ -12,6 +12,7 @@
 #define PP_H 128          // hidden width
 #define PP_MSG_IN 456     // message MLP input width
 #define PP_NPTS 8         // invariant points per node
+#define PP_PROX_CHUNK 64   // proximal steps whose loss terms are parked before one reduction
 
 // ---------------------------------------------------------------------------------------------
 // Offsets (in floats) into the concatenated weight buffer, order of weights.py::weight_spec().
@@ -140,6 +141,7 @@ struct pp_ctx {
     float *dchi;              // [N][4]
     float *px, *pm, *pv, *pz, *pxeff;   // proximal: param, Adam moments, anchor, effective chi  [N][4]
     uint8_t *pmask;           // [N]
+    float *prox_part;         // [PP_PROX_CHUNK][ceil(N / 16)] per-block loss terms of the proximal steps
     float *scal;              // small scalar scratch
     // in-situ kernel timing (pp_profile_kernel): every launch of one hot kernel carries a start / stop event pair
     // (hipExtLaunchKernelGGL: the dispatch's own begin / end timestamps, what rocprofv3's kernel trace reports)
