@@ -183,100 +183,6 @@ static void put_chunk(std::vector<float> &arena, const float *W, int ld, int row
 }
 static void put_geo_chunk(std::vector<float> &arena, const float *W, int C) { put_chunk(arena, W, 456, 0, 384 + 24 * C, 24); }
 #endif
-#ifdef PP_EDGE_F16
-// ---- slot streams of the one-residue-per-wave edge kernels (pp_edge_m.inc) -------------------------------------------
-// A slot = the operand of ONE 16-deep k-step of v_mfma_f32_32x32x16_f16 for 32 weight rows: [hi 1 KB | lo 1 KB], each
-// [lane 64][8 halves], lane = (row & 31, half h) holding W[row0 + row][col(h, i)].  A wave computes ALL 128 output features
-// of its residue, tile by tile (tile-major: the finished tile is split for the next layer while the next tile's MFMAs run),
-// so a stream is: for every output tile, the k-steps of its whole input.  Streams are padded to chunks of 8 slots (16 KB),
-// the unit in which a workgroup moves them into its LDS ring.
-template <typename ColMap>
-static void put_slot_m(std::vector<float> &arena, const float *W, int ld, int row0, ColMap colmap) {
-    size_t at = arena.size();
-    arena.resize(at + 512, 0.f);
-    uint16_t *d = reinterpret_cast<uint16_t *>(arena.data() + at);
-    for (int lane = 0; lane < 64; lane++)
-        for (int i = 0; i < 8; i++) {
-            const int row = row0 + (lane & 31), h = lane >> 5;
-            const int col = colmap(h, i);
-            const float w = col >= 0 ? W[(size_t)row * ld + col] : 0.f;
-            const uint16_t hi = f2h(w);
-            d[lane * 8 + i] = hi;
-            d[512 + lane * 8 + i] = f2h(w - h2f(hi));
-        }
-}
-// k-step ks (0..7) of a 128-wide input that arrives as accumulator tiles: feature 32 (ks >> 1) + 8 (2 (ks & 1) + (i >> 2)) + 4 h + (i & 3)
-static void put_kstep_m(std::vector<float> &arena, const float *W, int ld, int row0, int col0, int ks) {
-    put_slot_m(arena, W, ld, row0, [=](int h, int i) { return col0 + 32 * (ks >> 1) + 8 * (2 * (ks & 1) + (i >> 2)) + 4 * h + (i & 3); });
-}
-// geometry k-step S5 (0..4) of a message MLP's first layer (same feature order as put_geo_chunk)
-static void put_geo_kstep_m(std::vector<float> &arena, const float *W, int row0, int S5) {
-    put_slot_m(arena, W, 456, row0, [=](int h, int i) {
-        int f;
-        if (S5 < 4) {
-            const int pt = 4 * h + S5;
-            if (i < 3) f = 3 * pt + i;
-            else if (i == 3) f = 24 + pt;
-            else if (i < 7) f = 32 + 3 * pt + (i - 4);
-            else f = 56 + pt;
-        } else if (i < 4) {
-            f = 64 + 4 * h + i;
-        } else {
-            return -1;
-        }
-        return 384 + f;
-    });
-}
-static void put_first_layer_m(std::vector<float> &arena, const float *win, bool skip_wb) {
-    for (int t = 0; t < 4; t++) {
-        if (!skip_wb)
-            for (int ks = 0; ks < 8; ks++) put_kstep_m(arena, win, 456, 32 * t, 128, ks);
-        for (int S5 = 0; S5 < 5; S5++) put_geo_kstep_m(arena, win, 32 * t, S5);
-    }
-}
-static void put_square_m(std::vector<float> &arena, const float *W) {
-    for (int t = 0; t < 4; t++)
-        for (int ks = 0; ks < 8; ks++) put_kstep_m(arena, W, 128, 32 * t, 0, ks);
-}
-static void pad_chunk_m(std::vector<float> &arena, size_t at) {
-    const size_t chunk = 8 * 512;
-    arena.resize(at + ((arena.size() - at + chunk - 1) / chunk) * chunk, 0.f);
-}
-// edge update of layer l (+ node message of layer l + 1); returns the offset, *nslots the number of slots before padding
-static size_t put_edge_stream_m(std::vector<float> &arena, const float *w, const LayerOff &L, const LayerOff *Ln, bool st0) {
-    size_t at = (arena.size() + 3) & ~size_t(3);
-    arena.resize(at);
-    put_first_layer_m(arena, w + L.em_in_w, st0);
-    put_square_m(arena, w + L.em_mid_w);
-    put_square_m(arena, w + L.em_out_w);
-    // FFN, software-pipelined over the 16 hidden tiles: W1(0), then W1(ht + 1), W2(ht) for every ht
-    auto put_w1 = [&](int ht) { for (int ks = 0; ks < 8; ks++) put_kstep_m(arena, w + L.ed_in_w, 128, 32 * ht, 0, ks); };
-    put_w1(0);
-    for (int ht = 0; ht < 16; ht++) {
-        if (ht + 1 < 16) put_w1(ht + 1);
-        for (int t = 0; t < 4; t++)
-            for (int s2 = 0; s2 < 2; s2++)
-                put_slot_m(arena, w + L.ed_out_w, 512, 32 * t,
-                           [=](int h, int i) { return 32 * ht + 8 * (2 * s2 + (i >> 2)) + 4 * h + (i & 3); });
-    }
-    if (Ln) {
-        put_first_layer_m(arena, w + Ln->nm_in_w, false);
-        put_square_m(arena, w + Ln->nm_mid_w);
-    }
-    pad_chunk_m(arena, at);
-    return at;
-}
-// node message of layer 0 on its own (W_B h_E0 precomputed)
-static size_t put_nm0_stream_m(std::vector<float> &arena, const float *w, const LayerOff &L) {
-    size_t at = (arena.size() + 3) & ~size_t(3);
-    arena.resize(at);
-    put_first_layer_m(arena, w + L.nm_in_w, true);
-    put_square_m(arena, w + L.nm_mid_w);
-    pad_chunk_m(arena, at);
-    return at;
-}
-#endif
-
 // chunk stream of one message MLP: [W_in[:,128:256] x4 unless `skip_wb`,] W_in[:,384:456] x3 (24 cols), W_mid x4
 // [, W_out x4, FFN blocks].  Layer 0 skips the W_B chunks: its W_B h_E0 is precomputed once per complex (k_edge_static).
 static size_t put_stream(std::vector<float> &arena, const float *w, const LayerOff &L, bool edge, bool skip_wb) {
@@ -433,7 +339,7 @@ extern "C" pp_status pp_plan_create(const float *weights, size_t n_weights, cons
     if ((st = upload(&p->w, weights, off.total)) != PP_OK) return st;
 
     std::vector<float> arena;
-    arena.reserve(6u << 20);
+    arena.reserve(3u << 20);
     size_t o_node_emb = put_T(arena, weights + off.node_emb_w, 128, 51, 0, 51);
     size_t o_edge_emb = put_T(arena, weights + off.edge_emb_w, 128, 468, 0, 468);
     size_t o_l[3][14];
@@ -456,11 +362,7 @@ extern "C" pp_status pp_plan_create(const float *weights, size_t n_weights, cons
         o_l[l][13] = put_node_params(arena, weights, off, l);
     }
     size_t o_static = put_static_stream(arena, weights, off.layer[0]);
-#ifdef PP_EDGE_F16
-    size_t o_em_m[2], o_nm0_m;
-    for (int l = 0; l < 2; l++) o_em_m[l] = put_edge_stream_m(arena, weights, off.layer[l], &off.layer[l + 1], l == 0);
-    o_nm0_m = put_nm0_stream_m(arena, weights, off.layer[0]);
-#endif
+
 #ifdef PP_EDGE_F16
     // edge embedding, RBF block (input columns 65..464 of encoder.edge_embedding.weight): 13 chunks of two 16-deep k-steps,
     // k-step S = atom pair S, lane half h = RBFs 8h .. 8h+7 of that pair
@@ -491,10 +393,7 @@ extern "C" pp_status pp_plan_create(const float *weights, size_t n_weights, cons
         t.nu_stream = p->wT + o_l[l][12]; t.nu_params = p->wT + o_l[l][13];
     }
     p->static_stream = p->wT + o_static;
-#ifdef PP_EDGE_F16
-    for (int l = 0; l < 2; l++) p->lt[l].em_stream_m = p->wT + o_em_m[l];
-    p->lt[0].nm_stream_m = p->wT + o_nm0_m;
-#endif
+
 #ifdef PP_EDGE_F16
     p->embed_stream = p->wT + o_embed;
 #endif

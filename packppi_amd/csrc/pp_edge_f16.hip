@@ -1027,8 +1027,6 @@ pp_status pp_launch_edge_embed_f16(pp_ctx *c, hipStream_t s) {
 
 static float *g_dbg = nullptr;
 extern "C" void pp_debug_set_dbg(float *p) { g_dbg = p; }
-#include "pp_edge_m.inc"
-
 static EdgeArgs edge_args(pp_ctx *c, int layer, bool edge) {
     const pp_plan *p = c->plan;
     const LayerOff &o = p->off.layer[layer];
@@ -1131,16 +1129,6 @@ static int pick_R(int N) {
     return N > PP_WGS * g_num_cu ? 2 : 1;
 }
 
-// PP_EDGE_IMPL=m: the one-residue-per-wave kernels (pp_edge_m.inc) instead of the feature-split workgroups
-static int g_impl_m = -1;
-static bool use_impl_m() {
-    if (g_impl_m < 0) {
-        const char *e = getenv("PP_EDGE_IMPL");
-        g_impl_m = (e && e[0] == 'm') ? 1 : 0;
-    }
-    return g_impl_m == 1;
-}
-
 // mixed launch (k_edge_update_mix): when one-residue workgroups would sit three to a CU in a single round
 static int g_mix = -1;
 static bool use_mix(int N) {
@@ -1178,13 +1166,6 @@ pp_status pp_launch_node_message(pp_ctx *c, int layer, hipStream_t s) {
     EDGE_ATTR_CHECK()
     EdgeArgs A = edge_args(c, layer, false);
     const int R = pick_R(c->N);
-    if (use_impl_m() && layer == 0) {
-        A.wstream = c->plan->lt[0].nm_stream_m;
-        if (c->N <= 4 * g_num_cu) PP_LAUNCH(c, (k_node_message_m<true, 1>), dim3((c->N + 3) / 4), dim3(ET), M_SMEM, s, A);
-        else PP_LAUNCH(c, (k_node_message_m<true, 2>), dim3((c->N + 3) / 4), dim3(ET), M_SMEM, s, A);
-        PP_HIP_CHECK(hipGetLastError());
-        return PP_OK;
-    }
     PP_LAUNCH(c, nm_kernel_r(R, layer == 0), dim3((c->N + R - 1) / R), dim3(ET), nm_smem(R), s, A);
     PP_HIP_CHECK(hipGetLastError());
     return PP_OK;
@@ -1200,17 +1181,6 @@ pp_status pp_launch_edge_update(pp_ctx *c, int layer, hipStream_t s) {
     if (layer < 0 || layer > 1) { pp_set_error("pp_launch_edge_update: layer must be 0 or 1"); return PP_ERR_INVALID; }
     EdgeArgs A = edge_args(c, layer, true);
     const int R = pick_R(c->N);
-    if (use_impl_m()) {
-        A.wstream = c->plan->lt[layer].em_stream_m;
-        // one workgroup (four residues) per CU fills the chip up to 4 x CUs residues: those launches may use the whole
-        // register file (one wave per SIMD); beyond, two workgroups per CU
-        const bool one = c->N <= 4 * g_num_cu;
-        edge_kernel_t k = layer == 0 ? (one ? k_edge_update_m<true, PP_FUSED, 1> : k_edge_update_m<true, PP_FUSED, 2>)
-                                     : (one ? k_edge_update_m<false, PP_FUSED, 1> : k_edge_update_m<false, PP_FUSED, 2>);
-        PP_LAUNCH(c, k, dim3((c->N + 3) / 4), dim3(ET), M_SMEM, s, A);
-        PP_HIP_CHECK(hipGetLastError());
-        return PP_OK;
-    }
     if (use_mix(c->N)) {
         // three residues per CU as one two-residue and one one-residue workgroup
         A.n_pairs = (c->N + 2) / 3;

@@ -42,7 +42,6 @@ struct LayerT {
     const float *nd_in_T;                            // [128][512]
     const float *nd_out_T;                           // [512][128]
     const float *nm_stream, *em_stream;              // MFMA weight chunks packed in consumption order (pp_edge.hip)
-    const float *em_stream_m = nullptr, *nm_stream_m = nullptr;   // slot streams of the one-residue-per-wave kernels (pp_edge_m.inc)
     const float *em_params;                          // edge kernel small vectors, one block
     const float *nu_stream;                          // k_node_update: split-f16 weight slots, [wave][slot] (pp_api.hip put_node_stream)
     const float *nu_params;                          // k_node_update: small per-layer vectors, one block (NU_P_* offsets)
