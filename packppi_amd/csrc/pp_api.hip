@@ -461,7 +461,7 @@ __global__ void k_fill_seg(int2 *__restrict__ seg, int N, int L) {
     if (n < N) seg[n] = make_int2((n / L) * L, L);
 }
 // ... or complexes packed back to back, rows off[s] .. off[s + 1] - 1 (pp_complex_prepare_packed)
-__global__ void k_fill_seg_packed(int2 *__restrict__ seg, int N, const int32_t *__restrict__ off, int n_seg) {
+__global__ void k_fill_seg_packed(int2 *__restrict__ seg, int N, const int32_t *__restrict__ off, int n_seg, int max_len) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
     int lo = 0, hi = n_seg - 1;                   // last s with off[s] <= n
@@ -469,7 +469,14 @@ __global__ void k_fill_seg_packed(int2 *__restrict__ seg, int N, const int32_t *
         const int mid = (lo + hi + 1) >> 1;
         if (off[mid] <= n) lo = mid; else hi = mid - 1;
     }
-    seg[n] = make_int2(off[lo], off[lo + 1] - off[lo]);
+    // the launches are sized by the caller's max_len (LDS of the neighbour search): a segment table that disagrees with it
+    // is clamped to stay inside the batch and the LDS, its results are meaningless
+    int start = off[lo], len = off[lo + 1] - off[lo];
+    start = start < 0 ? 0 : (start > n ? n : start);
+    len = len > max_len ? max_len : len;
+    if (start + len > N) len = N - start;
+    if (n >= start + len) len = n - start + 1 <= max_len ? n - start + 1 : max_len;
+    seg[n] = make_int2(start, len);
 }
 
 static pp_status prepare_impl(pp_plan *plan, const pp_batch *b, const int32_t *seg_offsets, int n_seg, int min_len,
@@ -552,7 +559,7 @@ static pp_status prepare_impl(pp_plan *plan, const pp_batch *b, const int32_t *s
     }
     if (st == PP_OK) {
         hipStream_t s_ = static_cast<hipStream_t>(stream);
-        if (packed) hipLaunchKernelGGL(k_fill_seg_packed, dim3((c->N + 255) / 256), dim3(256), 0, s_, c->seg, c->N, seg_offsets, n_seg);
+        if (packed) hipLaunchKernelGGL(k_fill_seg_packed, dim3((c->N + 255) / 256), dim3(256), 0, s_, c->seg, c->N, seg_offsets, n_seg, c->L);
         else hipLaunchKernelGGL(k_fill_seg, dim3((c->N + 255) / 256), dim3(256), 0, s_, c->seg, c->N, c->L);
         if (hipGetLastError() != hipSuccess) { pp_set_error("segment table launch failed"); st = PP_ERR_HIP; }
     }

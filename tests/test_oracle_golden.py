@@ -162,3 +162,45 @@ def test_T1124_100_steps(weights):
     assert abs(float(m["atom_rmsd"]) - float(g["metric.atom_rmsd"])) < 1e-4
     pr = O.residue_clash(b, g["chi_ode_100"], 12.0, 0.5)
     assert (pr - g["clash_final"]).abs().max() < 1e-5
+
+
+@pytest.mark.parametrize("tag", ["L64", "L120"])
+def test_proximal_arbiter_fixture(tag):
+    """The oracle against the round-2 proximal fixtures (g6): gradient and clash value at the reference's own iterates, the
+    loss curve and the first ten steps of the trajectory; and the fixture's own statement of how far the reference's fp32 run
+    ends from its fp64 run (the bound the GPU test uses)."""
+    import os
+    from .conftest import GOLD
+    z = np.load(os.path.join(GOLD, f"g6_prox_{tag}.npz"))
+    b, g = load_golden(str(z["source_fixture"]))
+    chi0 = g[str(z["chi0_key"])].float()
+    for n in (1, 10, 50):
+        x = torch.from_numpy(z[f"chi32_step{n}"]).float()
+        pr, grad = O.clash_and_grad(b, x, 12.0, 0.5)
+        assert (pr - torch.from_numpy(z[f"per_res32_step{n}"])).abs().max() < 2e-5
+        assert (grad - torch.from_numpy(z[f"grad32_step{n}"])).abs().max() < 3e-7
+    chis, losses = O.proximal_optimizer(b, chi0.clone(), 12.0, 0.5, 1.0, 10)
+    assert np.allclose(np.array(losses), z["losses32"][:10], rtol=2e-5)
+    for n in (1, 5, 10):
+        assert wrapped_absdiff(chis[n - 1], torch.from_numpy(z[f"chi32_step{n}"])).max() < 2e-5
+    d = wrapped_absdiff(torch.from_numpy(z["chi32_step50"]), torch.from_numpy(z["chi64_step50"])).max()
+    assert d <= 3.0e-3 + 1e-6            # REF_FP32_VS_FP64_WORST in tests/test_hip_parity.py is the L64 value
+
+
+def test_c5_complex_with_knn_tie(weights):
+    """Complex 12 of BASELINE config 4's set has an exact CA-distance tie at rank 32 / 33 (row 8): the oracle, which calls
+    torch.topk like the reference, reproduces the reference's 100-step output -- the fixture the GPU test leans on when it
+    hands the reference's neighbour lists to pp_ctx_set_graph."""
+    import os
+    from packppi_amd import synth
+    from packppi_amd.featurize import protein_to_batch
+    from .conftest import GOLD
+    z = np.load(os.path.join(GOLD, "g7_c5_rank0.npz"))
+    i = 12
+    b = protein_to_batch(synth.make_complex(int(z["lengths"][i]), 10000 + i))
+    ca = b.X[0, :, 1, :]
+    d = torch.sqrt(((ca[:, None] - ca[None]) ** 2).sum(-1) + 1e-6).sort(dim=-1)[0]
+    assert torch.nonzero(d[:, 31] == d[:, 32]).flatten().tolist() == [8]
+    with torch.no_grad():
+        chi = O.sampling(weights, b, torch.from_numpy(z[f"init_{i}"]), torch.linspace(1, 0, 101))
+    assert wrapped_absdiff(chi, torch.from_numpy(z[f"chi_ode_100_{i}"]))[b.SC_D_mask.bool()].max() < 2e-5
