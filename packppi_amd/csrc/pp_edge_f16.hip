@@ -153,7 +153,11 @@ enum { P_BMID = 0, P_BOUT = 128, P_FOB = 256, P_G2 = 384, P_BE2 = 512, P_FIB = 6
 #define PP_X_NOWLOAD_ false
 #endif
 
+#ifdef PP_X_E_NOMFMA     /* timing experiment (results are wrong): the matrix instructions are left out */
+#define MFMA16(a, b, c) (c)
+#else
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+#endif
 
 // A operands of one stage in registers: [s0 hi, s0 lo, s1 hi, s1 lo]
 struct AOp {
@@ -395,6 +399,21 @@ __device__ __forceinline__ void geometry_share(const float *__restrict__ pts_i, 
 // `bt` -- never as a whole 128-feature vector in registers (64 VGPRs): that is what lets three workgroups share a CU
 // (<= 168 VGPRs).  Buffers per residue: xbuf (the exchange buffer every layer publishes into) and, in the edge update,
 // x1buf (the LayerNorm-2 output, which all four FFN blocks and nobody else read) -- 16 KB each, split-f16 tiles.
+// -DPP_X_PRIO=n: wave priority experiments (1/2: static per workgroup kind in the mixed launch, 3: raised inside the MFMA
+// blocks, 4: raised outside them)
+#ifndef PP_X_PRIO
+#define PP_X_PRIO 0
+#endif
+#if PP_X_PRIO == 3
+#define MF_BEGIN() __builtin_amdgcn_s_setprio(2);
+#define MF_END() __builtin_amdgcn_s_setprio(0);
+#elif PP_X_PRIO == 4
+#define MF_BEGIN() __builtin_amdgcn_s_setprio(0);
+#define MF_END() __builtin_amdgcn_s_setprio(2);
+#else
+#define MF_BEGIN()
+#define MF_END()
+#endif
 #ifdef PP_X_DRAIN
 #define MFMA_DRAIN() asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory")
 #else
@@ -409,6 +428,7 @@ __device__ __forceinline__ void geometry_share(const float *__restrict__ pts_i, 
         (mfma_h<R, SWAP>(AK, bt[(T) & 1], ACC));                                  \
     })
 #define XLAYER(k0, NCH, ACC, BUF, SWAP)                                           \
+    MF_BEGIN()                                                                    \
     BT_FETCH(BUF, 0, 0)                                                           \
     XSTAGE((k0) + 0, NCH, ACC, BUF, 0, SWAP)                                      \
     XSTAGE((k0) + 1, NCH, ACC, BUF, 1, SWAP)                                      \
@@ -421,6 +441,7 @@ __device__ __forceinline__ void geometry_share(const float *__restrict__ pts_i, 
 #define NEXT_XBUF()   { if constexpr (NXB == 2) xbuf = xbuf == xb0 ? xb0 + R * XBUF_FLOATS : xb0; }
 #define PRE_PUBLISH() { if constexpr (NXB == 1) __syncthreads(); NEXT_XBUF() }
 #define PUBLISH_RELU()                                                            \
+    MF_END()                                                                      \
     MFMA_DRAIN();                                                                 \
     PRE_PUBLISH()                                                                 \
     _Pragma("unroll") for (int r = 0; r < R; r++) {                               \
@@ -437,6 +458,7 @@ __device__ __forceinline__ void geometry_share(const float *__restrict__ pts_i, 
     if constexpr (!ST0) {                                                         \
         XLAYER(0, NCH, acc, xbuf, false)                                          \
     }                                                                             \
+    MF_BEGIN()                                                                    \
     WSTAGE(C0 + 0, NCH, acc, (mfma_geo<R, 0>(AK, gbuf, lane, acc)))                        \
     WSTAGE(C0 + 1, NCH, acc, (mfma_geo<R, 1>(AK, gbuf, lane, acc)))                        \
     WSTAGE(C0 + 2, NCH, acc, (mfma_geo<R, 2>(AK, gbuf, lane, acc)))                        \
@@ -554,7 +576,7 @@ __device__ __forceinline__ void node_message_body(const EdgeArgs &A, const int r
 #pragma unroll
         for (int q = 0; q < 16; q++) acc[r][q] = bmid;
     XLAYER(C0 + 3, NCH, acc, xbuf, true)
-    MFMA_DRAIN();
+    MF_END() MFMA_DRAIN();
 #pragma unroll
     for (int r = 0; r < R; r++) {
         // rows (registers) are edges e = 8 (r>>2) + 4 h + (r&3); mask and reduce over them
@@ -692,7 +714,7 @@ __device__ __forceinline__ void edge_update_body(const EdgeArgs &A, const int re
     XLAYER(C0 + 7, NCH, acc, xbuf, false)
     TS(4)
     // ---- x1 = LN2(h_E + mask * m): own tile only, statistics merged across the four waves ---------------
-    MFMA_DRAIN();
+    MF_END() MFMA_DRAIN();
 #pragma unroll
     for (int r = 0; r < R; r++) {
 #pragma unroll
@@ -727,7 +749,7 @@ __device__ __forceinline__ void edge_update_body(const EdgeArgs &A, const int re
     FFN_BLOCK(3)
     TS(10)
     // ---- h_E = mask * LN3(x1 + ffn) ---------------------------------------------------------------------
-    MFMA_DRAIN();
+    MF_END() MFMA_DRAIN();
 #pragma unroll
     for (int r = 0; r < R; r++) ln_partial(out[r], stat + r * STAT_FLOATS, wave, j, h);
     __syncthreads();
@@ -776,7 +798,7 @@ __device__ __forceinline__ void edge_update_body(const EdgeArgs &A, const int re
         TS(15)
         XLAYER(NEU + 7, NCH, acc, xbuf, true)
         TS(16)
-        MFMA_DRAIN();
+        MF_END() MFMA_DRAIN();
 #pragma unroll
         for (int r = 0; r < R; r++) {
             // rows (registers) are edges e = 8 (r>>2) + 4 h + (r&3); mask and reduce over them
@@ -833,6 +855,11 @@ k_edge_update_mix(EdgeArgs A) {
     } else {
         if (b < A.n_pairs) pair = b; else single = b - A.n_pairs;
     }
+#if PP_X_PRIO == 1
+    if (pair >= 0) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+#elif PP_X_PRIO == 2
+    if (pair >= 0) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1);
+#endif
     if (pair >= 0) edge_update_body<2, ST0, FUSE>(A, 2 * pair, smem);
     else edge_update_body<1, ST0, FUSE>(A, 2 * A.n_pairs + single, smem);
 }
