@@ -25,7 +25,7 @@ def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h", ".inc"))]
     deps.append(os.path.join(CSRC, "..", "..", "include", "packppi_hip.h"))
     return any(os.path.getmtime(d) > t for d in deps)
 
@@ -67,7 +67,7 @@ def build_other_variant(verbose=True):
     tag = "f32" if EDGE_F16 else "f16"
     sources = ["pp_api.hip", "pp_prepare.hip", "pp_node.hip", "pp_edge.hip" if EDGE_F16 else "pp_edge_f16.hip", "pp_clash.hip"]
     flags = [f for f in FLAGS if f != "-DPP_EDGE_F16"] + ([] if EDGE_F16 else ["-DPP_EDGE_F16"])
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h", ".inc"))]
     if os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps):
         return out
     hipcc = _hipcc()
