@@ -381,61 +381,6 @@ __device__ __forceinline__ void geometry_share(const float *__restrict__ pts_i, 
     }
 }
 
-// the same in two steps: the loads (inputs of a node message are known when the kernel starts) and the arithmetic
-struct GeoIn {
-    float l[3], g[3], jv[3], fr[12];
-};
-__device__ __forceinline__ void geo_load(const float *__restrict__ pts_i, const float *__restrict__ fr,
-                                         const float *__restrict__ pts_j, int h, int q, GeoIn &o) {
-    const float *pl = pts_i + 12 * h + 3 * q, *pg = pts_i + 24 + 12 * h + 3 * q, *pj = pts_j + 24 + 12 * h + 3 * q;
-#pragma unroll
-    for (int i = 0; i < 3; i++) { o.l[i] = pl[i]; o.g[i] = pg[i]; o.jv[i] = pj[i]; }
-#pragma unroll
-    for (int i = 0; i < 12; i++) o.fr[i] = fr[i];
-}
-// same arithmetic and LDS layout as geometry_share
-__device__ __forceinline__ void geo_compute(const GeoIn &gi, int wave, int lane, float *gbuf) {
-    const int q = wave;
-    const float lx = gi.l[0], ly = gi.l[1], lz = gi.l[2];
-    const float gx = gi.g[0], gy = gi.g[1], gz = gi.g[2];
-    const float jx = gi.jv[0], jy = gi.jv[1], jz = gi.jv[2];
-    const float *fr = gi.fr;
-    float v[10];
-    v[0] = lx; v[1] = ly; v[2] = lz;
-    v[3] = sqrtf(lx * lx + ly * ly + lz * lz + 1e-8f);
-    const float dx = jx - fr[9], dy = jy - fr[10], dz = jz - fr[11];
-    const float nx = fr[0] * dx + fr[3] * dy + fr[6] * dz;
-    const float ny = fr[1] * dx + fr[4] * dy + fr[7] * dz;
-    const float nz = fr[2] * dx + fr[5] * dy + fr[8] * dz;
-    v[4] = nx; v[5] = ny; v[6] = nz;
-    v[7] = sqrtf(nx * nx + ny * ny + nz * nz + 1e-8f);
-    const float ex = gx - jx, ey = gy - jy, ez = gz - jz;
-    v[8] = sqrtf(ex * ex + ey * ey + ez * ez + 1e-8f);
-    v[9] = 0.f;
-    h8 vh, vl;
-    h2v dh, dl;
-#pragma unroll
-    for (int i = 0; i < 10; i += 2) {
-        const f32x2v x = {v[i], v[i + 1]};
-        const h2v hh = cvt2(x);
-        const f32x2v d = {fmaf((float)hh[0], -1.0f, x[0]), fmaf((float)hh[1], -1.0f, x[1])};
-        const h2v ll = cvt2(d);
-        if (i < 8) { vh[i] = hh[0]; vh[i + 1] = hh[1]; vl[i] = ll[0]; vl[i + 1] = ll[1]; }
-        else { dh = hh; dl = ll; }
-    }
-    h8 *gv = reinterpret_cast<h8 *>(gbuf);
-    gv[(2 * q) * 64 + lane] = vh;
-    gv[(2 * q + 1) * 64 + lane] = vl;
-    _Float16 *gh = reinterpret_cast<_Float16 *>(gbuf);
-    gh[((2 * 4) * 64 + lane) * 8 + q] = dh[0];
-    gh[((2 * 4 + 1) * 64 + lane) * 8 + q] = dl[0];
-    {                       // padding elements 4..7 of k-step 4: every wave writes the same zeros (no branch)
-        const f32x2v z = {0.f, 0.f};
-        *reinterpret_cast<f32x2v *>(gh + ((2 * 4) * 64 + lane) * 8 + 4) = z;
-        *reinterpret_cast<f32x2v *>(gh + ((2 * 4 + 1) * 64 + lane) * 8 + 4) = z;
-    }
-}
-
 // ACC names the accumulator array the stage's MFMAs chain on: the empty asm at the end uses one element of every chain,
 // which keeps the MFMAs inside their stage (they are pure, and instruction selection would otherwise let them sink past
 // the following stages' fetches, keeping every operand set alive).
@@ -919,8 +864,6 @@ k_edge_update_mix(EdgeArgs A) {
     else edge_update_body<1, ST0, FUSE>(A, 2 * A.n_pairs + single, smem);
 }
 
-#include "pp_edge_rot.inc"
-
 // ---------------------------------------------------------------------------------------------
 // once per complex: Z_nm = W_B(node message, layer 0) h_E0 and Z_em = W_B(edge message, layer 0) h_E0.  h_E0 never
 // changes during sampling, so the layer-0 kernels skip four of their stages and start from these tiles.
@@ -1188,12 +1131,6 @@ static bool edge_attrs() {
                      set(reinterpret_cast<const void *>(eu_kernel_r(R, st0)), MAX_SMEM);
         ok = ok && set(reinterpret_cast<const void *>(k_edge_update_mix<true, PP_FUSED>), MAX_SMEM) &&
              set(reinterpret_cast<const void *>(k_edge_update_mix<false, PP_FUSED>), MAX_SMEM);
-        ok = ok && set(reinterpret_cast<const void *>(k_edge_update_rot<3, true, PP_FUSED>), MAX_SMEM) &&
-             set(reinterpret_cast<const void *>(k_edge_update_rot<3, false, PP_FUSED>), MAX_SMEM) &&
-             set(reinterpret_cast<const void *>(k_edge_update_rot<2, true, PP_FUSED>), MAX_SMEM) &&
-             set(reinterpret_cast<const void *>(k_edge_update_rot<2, false, PP_FUSED>), MAX_SMEM) &&
-             set(reinterpret_cast<const void *>(k_edge_update_mixrot<true, PP_FUSED>), MAX_SMEM) &&
-             set(reinterpret_cast<const void *>(k_edge_update_mixrot<false, PP_FUSED>), MAX_SMEM);
         int dev = 0;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
@@ -1228,18 +1165,6 @@ static bool use_mix(int N) {
     }
     if (g_forced_R >= 1 || !g_mix) return false;
     return N > 2 * g_num_cu && N <= 3 * g_num_cu;
-}
-
-// rotation launches (pp_edge_rot.inc), PP_EDGE_ROT = 1: three residues per workgroup, one workgroup per CU; 2: two and two;
-// 3: two and two, and in the mixed launch's size range its two-residue workgroups in rotation
-static int g_rot = -1;
-extern "C" void pp_debug_set_edge_rot(int on) { g_rot = on; }
-static int use_rot(int N) {
-    if (g_rot < 0) {
-        const char *e = getenv("PP_EDGE_ROT");
-        g_rot = e ? atoi(e) : 0;
-    }
-    return g_forced_R < 1 ? g_rot : 0;
 }
 
 // resident workgroups per CU the runtime predicts for the two kernels (measurement aid)
@@ -1283,28 +1208,6 @@ pp_status pp_launch_edge_update(pp_ctx *c, int layer, hipStream_t s) {
     if (layer < 0 || layer > 1) { pp_set_error("pp_launch_edge_update: layer must be 0 or 1"); return PP_ERR_INVALID; }
     EdgeArgs A = edge_args(c, layer, true);
     const int R = pick_R(c->N);
-    const int rot = use_rot(c->N);
-    if (rot == 3 && use_mix(c->N)) {
-        A.n_pairs = (c->N + 2) / 3;
-        const int singles = c->N - 2 * A.n_pairs > 0 ? c->N - 2 * A.n_pairs : 0;
-        const size_t sm = ROT_LDS_FLOATS(2) * sizeof(float) > eu_smem(1) ? ROT_LDS_FLOATS(2) * sizeof(float) : eu_smem(1);
-        PP_LAUNCH(c, (layer == 0 ? k_edge_update_mixrot<true, PP_FUSED> : k_edge_update_mixrot<false, PP_FUSED>),
-                  dim3(A.n_pairs + singles), dim3(ET), sm, s, A);
-        PP_HIP_CHECK(hipGetLastError());
-        return PP_OK;
-    }
-    if (rot == 1) {
-        PP_LAUNCH(c, (layer == 0 ? k_edge_update_rot<3, true, PP_FUSED> : k_edge_update_rot<3, false, PP_FUSED>),
-                  dim3((c->N + 2) / 3), dim3(ET), ROT_LDS_FLOATS(3) * sizeof(float), s, A);
-        PP_HIP_CHECK(hipGetLastError());
-        return PP_OK;
-    }
-    if (rot >= 2) {
-        PP_LAUNCH(c, (layer == 0 ? k_edge_update_rot<2, true, PP_FUSED> : k_edge_update_rot<2, false, PP_FUSED>),
-                  dim3((c->N + 1) / 2), dim3(ET), ROT_LDS_FLOATS(2) * sizeof(float), s, A);
-        PP_HIP_CHECK(hipGetLastError());
-        return PP_OK;
-    }
     if (use_mix(c->N)) {
         // three residues per CU as one two-residue and one one-residue workgroup
         A.n_pairs = (c->N + 2) / 3;
