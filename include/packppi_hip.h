@@ -167,6 +167,15 @@ pp_status pp_profile_read(pp_ctx *ctx, float *total_ms, int *launches);
  * (PACKPPI_EDGE=f32, csrc/pp_edge.hip). */
 int pp_edge_variant(void);
 
+/* f16 operand range check (no reference counterpart).  The default kernels run the dense layers on two-way f16 splits:
+ * hidden activations saturate at 65504 and every other operand is assumed to be far below that.  A library built with
+ * -DPP_CHECK_RANGE (libpackppi_hip.chk.so; `python -m packppi_amd.rangecheck`) counts every fp32 value at or beyond the
+ * limit (or not finite) that its kernels were about to split: pp_range_check waits for the device, returns the events since
+ * the last reset and optionally resets.  In any other build pp_has_range_check() is 0 and pp_range_check returns
+ * PP_ERR_UNSUPPORTED.  (pp_plan_create rejects weights that are not finite or outside the f16 range in every build.) */
+int pp_has_range_check(void);
+pp_status pp_range_check(unsigned long long *events, int reset);
+
 /* The library also exports a few undocumented pp_debug_* entry points (single-kernel launches and internal-buffer
  * copies) used only by tools/debug/ to test kernels for run-to-run reproducibility.  They are not part of the
  * drop-in boundary and may change. */

@@ -86,6 +86,21 @@ def build_other_variant(verbose=True):
     return out
 
 
+def check_variant_path():
+    return LIB.replace(".so", ".chk.so")
+
+
+def build_check_variant(verbose=True):
+    """``libpackppi_hip.chk.so``: the default kernels with -DPP_CHECK_RANGE (every value about to be split into f16 operands is
+    compared with the f16 limit and counted; packppi_amd/rangecheck.py runs a checkpoint through it)."""
+    out = check_variant_path()
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h", ".inc"))]
+    if os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps):
+        return out
+    os.environ.pop("PACKPPI_VARIANT_SOURCES", None)
+    return build_library(force=True, verbose=verbose, extra_flags=["-DPP_CHECK_RANGE"], tag="chk")
+
+
 if __name__ == "__main__":
     # python -m packppi_amd.build [--force] [--tag NAME -DFLAG ...]   (a tagged build is a variant library for experiments)
     argv = sys.argv[1:]

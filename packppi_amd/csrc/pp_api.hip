@@ -312,6 +312,27 @@ static pp_status upload(T **dst, const T *src, size_t n) {
     return PP_OK;
 }
 
+// f16 operand range check (pp_internal.h): events counted since the last reset by the kernels of a -DPP_CHECK_RANGE build
+extern "C" int pp_has_range_check(void) {
+#ifdef PP_CHECK_RANGE
+    return 1;
+#else
+    return 0;
+#endif
+}
+extern "C" pp_status pp_range_check(unsigned long long *events, int reset) {
+    if (!events) FAIL(PP_ERR_INVALID, "pp_range_check: null argument");
+#ifdef PP_CHECK_RANGE
+    PP_HIP_CHECK(hipDeviceSynchronize());
+    *events = (unsigned long long)pp_edge_range_hits(reset) + (unsigned long long)pp_node_range_hits(reset);
+    return PP_OK;
+#else
+    *events = 0;
+    FAIL(PP_ERR_UNSUPPORTED, "pp_range_check: this library was built without -DPP_CHECK_RANGE (use libpackppi_hip.chk.so: "
+                             "python -m packppi_amd.rangecheck)");
+#endif
+}
+
 extern "C" pp_status pp_plan_create(const float *weights, size_t n_weights, const pp_tables *tables, int device,
                                     pp_plan **out) {
     if (!tables || !out) FAIL(PP_ERR_INVALID, "pp_plan_create: null argument");
@@ -320,6 +341,11 @@ extern "C" pp_status pp_plan_create(const float *weights, size_t n_weights, cons
     if (has_net && (n_weights != off.total || off.total != PP_N_WEIGHTS))
         FAIL(PP_ERR_INVALID, "pp_plan_create: expected " + std::to_string(off.total) + " weights, got " +
                                  std::to_string(n_weights));
+    if (has_net)      // the dense layers run on two-way f16 splits of the weights: every weight must be finite and inside the f16 range
+        for (size_t i = 0; i < n_weights; i++)
+            if (!(std::fabs(weights[i]) < 65504.f))
+                FAIL(PP_ERR_INVALID, "pp_plan_create: weight " + std::to_string(i) + " is not finite or outside the f16 range (" +
+                                         std::to_string(weights[i]) + ")");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) FAIL(PP_ERR_NO_DEVICE, "pp_plan_create: no HIP device visible");
     if (device < 0 || device >= ndev) FAIL(PP_ERR_INVALID, "pp_plan_create: bad device index");

@@ -17,6 +17,9 @@
 // Measured (MI355X, T1124, 100 steps): 45.5 k residues/s against 26.6 k for pp_edge.hip.
 #include "pp_internal.h"
 
+PP_RANGE_COUNTER
+PP_RANGE_READER(pp_edge_range_hits)
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
@@ -72,6 +75,7 @@ __device__ __forceinline__ void split_tile(const f32x16 &v, HT &o) {
 #pragma unroll
         for (int i = 0; i < 8; i += 2) {
             f32x2v x = {v[8 * s + i], v[8 * s + i + 1]};
+            PP_RANGE(RELU ? fmaxf(x[0], 0.f) : x[0]) PP_RANGE(RELU ? fmaxf(x[1], 0.f) : x[1])
             if (RELU) {
                 x[0] = __builtin_amdgcn_fmed3f(x[0], 0.f, 65504.f);
                 x[1] = __builtin_amdgcn_fmed3f(x[1], 0.f, 65504.f);
@@ -362,6 +366,7 @@ __device__ __forceinline__ void geometry_share(const float *__restrict__ pts_i, 
 #pragma unroll
     for (int i = 0; i < 10; i += 2) {
         const f32x2v x = {v[i], v[i + 1]};
+        PP_RANGE(x[0]) PP_RANGE(x[1])
         const h2v hh = cvt2(x);
         const f32x2v d = {fmaf((float)hh[0], -1.0f, x[0]), fmaf((float)hh[1], -1.0f, x[1])};
         const h2v ll = cvt2(d);

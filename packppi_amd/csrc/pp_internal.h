@@ -161,6 +161,34 @@ void pp_set_error(const std::string &msg);
         }                                                                                    \
     } while (0)
 
+// ---- f16 operand range check (-DPP_CHECK_RANGE: the libpackppi_hip.chk.so build; packppi_amd/rangecheck.py) -----------------
+// The split-f16 kernels saturate hidden activations at the f16 maximum (65504) and assume every other operand is far below it.
+// That holds by orders of magnitude for the seeded fixtures; a trained checkpoint is checked, not trusted: in this build every
+// fp32 value that is about to be split into f16 operands is compared with the limit and counted (per translation unit; atomics:
+// this build is for checking, not for timing).  The default build compiles none of it.
+#ifdef PP_CHECK_RANGE
+#define PP_RANGE_COUNTER static __device__ unsigned int g_range_hits;
+#define PP_RANGE(x)                                                                                    \
+    {                                                                                                  \
+        const float rx_ = (x);                                                                         \
+        if (!(__builtin_fabsf(rx_) < 65504.f)) atomicAdd(&g_range_hits, 1u);                           \
+    }
+#define PP_RANGE_READER(name)                                                                          \
+    unsigned int name(int reset) {                                                                     \
+        unsigned int v = 0, z = 0;                                                                     \
+        (void)hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_range_hits), sizeof(v));                            \
+        if (reset) (void)hipMemcpyToSymbol(HIP_SYMBOL(g_range_hits), &z, sizeof(z));                   \
+        return v;                                                                                      \
+    }
+#else
+#define PP_RANGE_COUNTER
+#define PP_RANGE(x)
+#define PP_RANGE_READER(name) \
+    unsigned int name(int) { return 0; }
+#endif
+unsigned int pp_edge_range_hits(int reset);
+unsigned int pp_node_range_hits(int reset);
+
 // next (start, stop) event pair of an armed profiling run; false when profiling is off for this launch
 bool pp_prof_take(pp_ctx *c, hipEvent_t *e0, hipEvent_t *e1);
 #define PP_LAUNCH(c, kernel, grid, block, shmem, s, ...)                                              \

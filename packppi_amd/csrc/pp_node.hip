@@ -18,6 +18,9 @@
 
 #include "pp_internal.h"
 
+PP_RANGE_COUNTER
+PP_RANGE_READER(pp_node_range_hits)
+
 #define NT 512
 #ifndef PP_NODE_GROUPS
 #define PP_NODE_GROUPS 1
@@ -386,6 +389,7 @@ __device__ __forceinline__ void ldB(const _Float16 *hi, const _Float16 *lo, int 
 __device__ __forceinline__ void split2(float x0, float x1, unsigned &hp, unsigned &lp) {
     unsigned a, b, c, d;
     float fa, fb;
+    PP_RANGE(x0) PP_RANGE(x1)
     asm("v_cvt_f16_f32 %0, %1" : "=v"(a) : "v"(x0));
     asm("v_cvt_f16_f32 %0, %1" : "=v"(b) : "v"(x1));
     asm("v_cvt_f32_f16 %0, %1" : "=v"(fa) : "v"(a));

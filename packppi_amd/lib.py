@@ -17,7 +17,7 @@ _lib = None
 
 SYMBOLS = ("pp_version", "pp_last_error", "pp_plan_create", "pp_plan_destroy", "pp_plan_set_clash_params",
            "pp_complex_prepare", "pp_complex_prepare_packed", "pp_ctx_destroy", "pp_ctx_get_graph", "pp_ctx_set_graph", "pp_score", "pp_sample", "pp_atom14",
-           "pp_clash", "pp_proximal", "pp_time_kernel", "pp_profile_kernel", "pp_profile_read", "pp_edge_variant")
+           "pp_clash", "pp_proximal", "pp_time_kernel", "pp_profile_kernel", "pp_profile_read", "pp_edge_variant", "pp_has_range_check", "pp_range_check")
 
 
 class PPTables(C.Structure):
@@ -64,6 +64,9 @@ def load():
     lib.pp_profile_kernel.argtypes = [vp, i]
     lib.pp_profile_read.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int)]
     lib.pp_edge_variant.argtypes = []
+    lib.pp_has_range_check.argtypes = []
+    lib.pp_has_range_check.restype = C.c_int
+    lib.pp_range_check.argtypes = [C.POINTER(C.c_ulonglong), i]
     lib.pp_edge_variant.restype = C.c_int
     _lib = lib
     return lib

@@ -1,0 +1,102 @@
+"""f16 operand range check of a checkpoint (no reference counterpart).
+
+The default kernels run every dense layer on two-way f16 splits of fp32 operands: accurate to fp32
+level as long as every operand stays inside the f16 range; hidden activations beyond 65504 saturate.  The seeded fixtures
+are orders of magnitude inside; a trained checkpoint is checked, not trusted:
+
+    python -m packppi_amd.rangecheck --ckpt_path model.ckpt --input complex.pdb      (or --length 300 for a synthetic complex)
+
+runs the score network (and a few sampling steps) through ``libpackppi_hip.chk.so`` -- the same kernels built with
+``-DPP_CHECK_RANGE``, which count every value at or beyond the limit that was about to be split -- and prints the number of
+events.  0 means the split-f16 library is safe for this checkpoint on this input; otherwise use the exact-fp32 library
+(``PACKPPI_LIB=.../libpackppi_hip.f32.so``).  The check library is loaded in a child process (one library per process).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+
+
+def _run(args):
+    import torch
+    from . import lib, synth
+    from .featurize import protein_to_batch
+    from .module import TDiffusionModule
+    from .weights import make_random_state_dict
+    L = lib.load()
+    if not L.pp_has_range_check():
+        raise RuntimeError("this library was built without -DPP_CHECK_RANGE")
+    dev = args.device
+    if args.ckpt_path:
+        model = TDiffusionModule.load_from_checkpoint(args.ckpt_path, map_location=dev, strict=False)
+    else:
+        sd = make_random_state_dict(args.seed)
+        for spec in args.scale or []:                      # name=factor: testing aid
+            name, f = spec.split("=")
+            sd[name] = sd[name] * float(f)
+        model = TDiffusionModule(sd, device=dev)
+    if args.input:
+        from .pdb_io import from_pdb_file
+        batch = protein_to_batch(from_pdb_file(args.input))
+    else:
+        batch = protein_to_batch(synth.make_complex(args.length, 5))
+    batch = batch.to(dev)
+    n = batch.X.shape[1]
+    ev = C.c_ulonglong(0)
+    assert L.pp_range_check(C.byref(ev), 1) == 0
+    g = torch.Generator().manual_seed(0)
+    chi = ((torch.rand(1, n, 4, generator=g) * 2 - 1) * torch.pi).to(dev) * batch.SC_D_mask
+    report = {}
+    for t in (1.0, 0.5, 0.02):
+        model.network(batch, chi, torch.full((n,), t, device=dev))
+        assert L.pp_range_check(C.byref(ev), 1) == 0
+        report[f"network t={t}"] = int(ev.value)
+    model.schedule = torch.linspace(1.0, 0.0, args.steps + 1)
+    model.sampling(batch)
+    assert L.pp_range_check(C.byref(ev), 1) == 0
+    report[f"sampling {args.steps} steps"] = int(ev.value)
+    report["total"] = sum(report.values())
+    print("RANGECHECK " + json.dumps(report))
+    return report
+
+
+def check(argv):
+    """Run the check in a child process on the chk library; returns the report dict."""
+    from .build import check_variant_path
+    path = check_variant_path()
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} is missing: build it with `python -c 'from packppi_amd.build import build_check_variant as b; b()'`")
+    env = dict(os.environ, PACKPPI_LIB=path, PACKPPI_RANGECHECK_CHILD="1")
+    r = subprocess.run([sys.executable, "-m", "packppi_amd.rangecheck", *argv], env=env, capture_output=True, text=True)
+    for line in r.stdout.splitlines():
+        if line.startswith("RANGECHECK "):
+            return json.loads(line[len("RANGECHECK "):])
+    raise RuntimeError("range check failed:\n" + r.stdout[-2000:] + r.stderr[-2000:])
+
+
+def main(argv=None):
+    p = argparse.ArgumentParser(description="f16 operand range check of a checkpoint on one complex")
+    p.add_argument("--ckpt_path", type=str, default=None, help="Lightning checkpoint (else seeded stand-in weights).")
+    p.add_argument("--input", type=str, default=None, help="PDB file (else a synthetic complex of --length residues).")
+    p.add_argument("--length", type=int, default=300)
+    p.add_argument("--steps", type=int, default=10, help="sampling steps run after the three network evaluations")
+    p.add_argument("--seed", type=int, default=20251003)
+    p.add_argument("--scale", action="append", help="NAME=FACTOR: scale one seeded weight (testing aid)")
+    p.add_argument("--device", type=str, default="cuda:0")
+    argv = sys.argv[1:] if argv is None else argv
+    args = p.parse_args(argv)
+    if os.environ.get("PACKPPI_RANGECHECK_CHILD"):
+        _run(args)
+        return 0
+    rep = check(argv)
+    for k, v in rep.items():
+        print(f"{k:24s} {v}")
+    print("f16 operand range: OK" if rep["total"] == 0 else
+          "f16 operand range EXCEEDED: use the exact-fp32 library (PACKPPI_LIB=.../libpackppi_hip.f32.so)")
+    return 0 if rep["total"] == 0 else 2
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -47,3 +47,33 @@ def test_weight_offsets_match_python_spec(lib_path):
     import numpy as np
     total = sum(int(np.prod(s)) for _, s in weight_spec())
     assert total == 1439172 and len(weight_spec()) == 112
+
+
+def test_range_check_is_a_build_variant(lib_path):
+    """The default library has no f16 range counters (pp_range_check -> PP_ERR_UNSUPPORTED, no device call); the check
+    variant, when built, says so."""
+    lib = ctypes.CDLL(lib_path)
+    lib.pp_last_error.restype = ctypes.c_char_p
+    assert lib.pp_has_range_check() == 0
+    ev = ctypes.c_ulonglong(7)
+    assert lib.pp_range_check(ctypes.byref(ev), 0) == 3 and ev.value == 0
+    assert b"PP_CHECK_RANGE" in lib.pp_last_error()
+    from packppi_amd.build import check_variant_path
+    if os.path.exists(check_variant_path()):
+        assert ctypes.CDLL(check_variant_path()).pp_has_range_check() == 1
+
+
+def test_plan_create_rejects_weights_outside_the_f16_range(lib_path):
+    """Checked before any device call: a non-finite weight or one beyond 65504 cannot be split into f16 operands."""
+    import numpy as np
+    from packppi_amd.lib import PPTables
+    lib = ctypes.CDLL(lib_path)
+    lib.pp_last_error.restype = ctypes.c_char_p
+    lib.pp_plan_create.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(PPTables), ctypes.c_int,
+                                   ctypes.POINTER(ctypes.c_void_p)]
+    for bad in (np.inf, np.nan, 7.0e4):
+        w = np.zeros(1439172, dtype=np.float32)
+        w[12345] = bad
+        out = ctypes.c_void_p()
+        st = lib.pp_plan_create(w.ctypes.data_as(ctypes.c_void_p), w.size, ctypes.byref(PPTables()), 0, ctypes.byref(out))
+        assert st == 1 and b"weight 12345" in lib.pp_last_error() and not out.value

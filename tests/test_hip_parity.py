@@ -539,3 +539,18 @@ def test_weight_range_envelope():
         s, h = TDiffusionModule(sd, device=DEV).network(_gpu(b), chi.to(DEV), t)
         assert float((h.cpu() - h_o).abs().max() / h_o.abs().max()) < 5e-6, name
         assert float((s.cpu() - s_o).abs().max() / s_o.abs().max()) < 1e-5, name
+
+
+def test_f16_range_check_build():
+    """libpackppi_hip.chk.so (-DPP_CHECK_RANGE) counts operands at or beyond the f16 limit: none with the seeded weights, many
+    once a hidden layer's weights are scaled until its activations saturate (child processes: one library per process)."""
+    from packppi_amd import rangecheck
+    from packppi_amd.build import check_variant_path
+    if not os.path.exists(check_variant_path()):
+        pytest.skip("libpackppi_hip.chk.so not built (__graft_entry__.build() builds it)")
+    rep = rangecheck.check(["--length", "96", "--steps", "3"])
+    assert rep["total"] == 0, rep
+    rep = rangecheck.check(["--length", "96", "--steps", "3", "--scale", "mpnn.mpnn_layers.1.edge_dense.W_in.weight=3e5"])
+    assert rep["network t=0.5"] > 1000, rep
+    rep = rangecheck.check(["--length", "96", "--steps", "3", "--scale", "mpnn.mpnn_layers.2.node_dense.W_in.weight=3e5"])
+    assert rep["network t=0.5"] > 100, rep
