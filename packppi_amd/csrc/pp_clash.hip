@@ -232,8 +232,10 @@ k_atom14(int N, const float *__restrict__ X, const int64_t *__restrict__ rtype,
 // ---------------------------------------------------------------------------------------------
 // clash: one wave per residue.  lane = 16 * slot + a,  a = own atom (0..13), slot = 0..3 partner stripe
 // ---------------------------------------------------------------------------------------------
+#ifndef CL_WAVES
 #define CL_WAVES 4
-#define CL_MAXC 2048     // candidate list capacity per wave (entries beyond are handled by re-scanning)
+#endif
+#define CL_MAXC (8192 / CL_WAVES)     // candidate list capacity per wave (entries beyond are handled by re-scanning)
 
 __global__ void __launch_bounds__(64 * CL_WAVES)
 k_clash(int N, const int2 *__restrict__ seg, const float *__restrict__ xyz, const float4 *__restrict__ rec, const float *__restrict__ exists,
@@ -300,6 +302,12 @@ k_clash(int N, const int2 *__restrict__ seg, const float *__restrict__ xyz, cons
 #endif
         for (int c = slot; c < cnt; c += 4) {
             const int jg = list[c];
+            // all of the partner's records first, unconditionally: inside the branches below the compiler may not hoist them,
+            // and fourteen dependent round trips per candidate were 13 of this kernel's 20 us at T1124 (fetching the next
+            // candidate's records one iteration ahead on top of this gains nothing)
+            float4 pbr[14];
+#pragma unroll
+            for (int bb = 0; bb < 14; bb++) pbr[bb] = rec[(size_t)jg * 16 + bb];
             const float4 mj = rec[(size_t)jg * 16 + 15];
             const int rj = __float_as_int(mj.y);
             const bool i_low = ri < rj;
@@ -308,7 +316,7 @@ k_clash(int N, const int2 *__restrict__ seg, const float *__restrict__ xyz, cons
             if (own && ea != 0.f) {
 #pragma unroll
                 for (int bb = 0; bb < 14; bb++) {
-                    const float4 pb = rec[(size_t)jg * 16 + bb];
+                    const float4 pb = pbr[bb];
                     bool ok = pb.w != 0.f && !(a < 4 && bb < 4) && !(a == 5 && bb == 5);
                     if (adjacent) {
                         // peptide bond C(lower) - N(higher)

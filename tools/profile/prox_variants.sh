@@ -1,0 +1,18 @@
+#!/bin/bash
+# GPU box: kernel-trace stats of the proximal bench for each prebuilt variant library.  Usage: bash tools/profile/prox_variants.sh "base tag ..."
+ROOT=$(pwd)
+export TMPDIR=/tmp
+for v in $1; do
+  OUT=$ROOT/gpurun_out/pv_$v; mkdir -p $OUT
+  if [ "$v" = base ]; then export PACKPPI_LIB=$ROOT/packppi_amd/csrc/libpackppi_hip.so; else export PACKPPI_LIB=$ROOT/packppi_amd/csrc/libpackppi_hip.$v.so; fi
+  (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o run -- python3 $ROOT/bench.py --steps 2 --warmup 1 --cpu-steps 0 --no-secondary --proximal --workload ${WORKLOAD:-t1124} > $OUT/bench.json 2> $OUT/err.txt)
+  f=$(find $OUT -name "*kernel_stats.csv" | head -1)
+  echo "== $v"; python3 - "$f" <<'PY'
+import csv, sys
+for r in csv.DictReader(open(sys.argv[1])):
+    n = r["Name"].split("(")[0]
+    if "k_clash" in n or "k_atom14" in n or "k_prox" in n:
+        print(f'  {n[:60]:60s} calls {r["Calls"]:>5s} avg {float(r["AverageNs"])/1e3:8.2f} us  {r["Percentage"]}%')
+PY
+  find $OUT -type f ! -name "*stats.csv" ! -name "bench.json" -delete
+done
