@@ -38,13 +38,20 @@ __device__ __forceinline__ Rig compose(const Rig &a, const Rig &b) {
 }
 
 // default frame g of residue type S composed with the torsion rotation about x:  D_g * Rx(sin, cos)
-__device__ __forceinline__ Rig torsion_frame(const float *__restrict__ df, int g, float sn, float cs) {
+// rows 0..2 of default frame g (4x4, row-major): three 16-byte loads, issued where this is called
+struct DF {
+    float4 r[3];
+};
+__device__ __forceinline__ DF load_df(const float *__restrict__ df, int g) {
+    const float4 *p = reinterpret_cast<const float4 *>(df + g * 16);
+    return DF{{p[0], p[1], p[2]}};
+}
+__device__ __forceinline__ Rig torsion_frame(const DF &f, float sn, float cs) {
     Rig D, o;
 #pragma unroll
     for (int i = 0; i < 3; i++) {
-#pragma unroll
-        for (int jx = 0; jx < 3; jx++) D.R.m[3 * i + jx] = df[g * 16 + 4 * i + jx];
-        D.t[i] = df[g * 16 + 4 * i + 3];
+        D.R.m[3 * i] = f.r[i].x; D.R.m[3 * i + 1] = f.r[i].y; D.R.m[3 * i + 2] = f.r[i].z;
+        D.t[i] = f.r[i].w;
     }
     const M3 Rx = {{1.f, 0.f, 0.f, 0.f, cs, -sn, 0.f, sn, cs}};
     o.R = mul33(D.R, Rx);
@@ -110,7 +117,23 @@ k_atom14(int N, const float *__restrict__ X, const int64_t *__restrict__ rtype,
 
     const float *df = default_frames + (size_t)S * 8 * 16;
     const int g = a < 14 ? a2g[S * 14 + a] : (a == 14 ? 7 : 0);     // lane 14 walks the full chi chain
+    // per-atom table entries: fetched here, unconditionally (lanes 14, 15 mirror atom 13), not inside the branches that use them
+    const int ac = a < 14 ? a : 13;
+    const float *lp_ = lit + ((size_t)S * 14 + ac) * 3;
+    const float lp[3] = {lp_[0], lp_[1], lp_[2]};
+    const float am = amask14[S * 14 + ac];
+    const float ex_t = atom_exists ? atom_exists[(size_t)n * 14 + ac] : 1.f;
+    const float br_t = between_radius[S * 14 + ac];
+    // the default frames of the lane's own chain: group min(g, 4) and the chi2..chi4 groups 5..7 (every memory round trip of
+    // this kernel starts here, before the Adam step; fetched where they are used they were four dependent waits)
+    const int g0 = g < 4 ? g : 4;
+    const DF f0 = load_df(df, g0), f5 = load_df(df, 5), f6 = load_df(df, 6), f7 = load_df(df, 7);
+    const float xa_t[3] = {x[3 * (a < 4 ? a : 3)], x[3 * (a < 4 ? a : 3) + 1], x[3 * (a < 4 ? a : 3) + 2]};
+    const float bbd_t = BB_D[(size_t)n * 3 + (a < 3 ? a : 2)];
+    float chi_t = 0.f;
+    if constexpr (!UPD) chi_t = chi[(size_t)n * 4 + (a >= 3 && a < 7 ? a - 3 : 0)];
     // (everything above is independent of the angles: its loads are in flight while the Adam step below runs)
+    __shared__ float s_chi[16][4];            // UPD: the block's new angles (reconstruction reads them here, not from memory)
     if constexpr (UPD) {
         // loss_t = mean_n [sum_k (xeff - z)^2 + lamda per_res] at the incoming iterate; then torch.optim.Adam defaults
         // (lr 1e-2, betas (0.9, 0.999), eps 1e-8, bias-corrected; step_size = lr / (1 - beta1^t) and bc2s = sqrt(1 - beta2^t)
@@ -118,27 +141,31 @@ k_atom14(int N, const float *__restrict__ X, const int64_t *__restrict__ rtype,
         __shared__ float s_q[16];
         const int k = threadIdx.x & 15, grp = threadIdx.x >> 4, nn = blockIdx.x * 16 + grp;
         float q = 0.f;
+        const float pr_t = U.per_res[nn < N ? nn : N - 1];
         if (nn < N && k < 4) {
             const size_t e = (size_t)nn * 4 + k;
-            const float d = U.xeff[e] - U.z[e];
-            q = fabsf(d) * fabsf(d);
+            // every operand first (read whether masked or not): one memory round trip for the whole update
+            const float xe = U.xeff[e], ze = U.z[e], xo = U.x[e], dch = U.dchi[e], mo = U.m[e], vo = U.v[e], c0v = U.chi0[e];
             const bool mk = U.mask[nn] != 0;
+            const float d = xe - ze;
+            q = fabsf(d) * fabsf(d);
             const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
             float g = 0.f;
-            if (mk) g = 2.f * (U.x[e] - U.z[e]) * U.inv_n + U.lamda * U.dchi[e];
-            const float mm = U.m[e] + (g - U.m[e]) * (1.f - b1);             // exp_avg.lerp_(grad, 1 - beta1)
-            const float vv = U.v[e] * b2 + (1.f - b2) * (g * g);
+            if (mk) g = 2.f * (xo - ze) * U.inv_n + U.lamda * dch;
+            const float mm = mo + (g - mo) * (1.f - b1);             // exp_avg.lerp_(grad, 1 - beta1)
+            const float vv = vo * b2 + (1.f - b2) * (g * g);
             const float denom = sqrtf(vv) / U.bc2s + eps;
-            const float xn = U.x[e] - U.step_size * (mm / denom);
+            const float xn = xo - U.step_size * (mm / denom);
             U.m[e] = mm; U.v[e] = vv; U.x[e] = xn;
-            const float outv = mk ? xn : U.chi0[e];
+            const float outv = mk ? xn : c0v;
             U.xeff[e] = outv;
+            s_chi[grp][k] = outv;
             if (U.traj) U.traj[(size_t)U.t * N * 4 + e] = outv;
             if (U.last) U.last[e] = outv;
         }
         q += __shfl_xor(q, 1, 16);
         q += __shfl_xor(q, 2, 16);
-        if (k == 0) s_q[grp] = nn < N ? q + U.lamda * U.per_res[nn] : 0.f;
+        if (k == 0) s_q[grp] = nn < N ? q + U.lamda * pr_t : 0.f;
         __syncthreads();                      // the block's new angles (read below through `chi`) and its loss terms
         if (threadIdx.x == 0) {
             float tt = 0.f;
@@ -149,9 +176,12 @@ k_atom14(int N, const float *__restrict__ X, const int64_t *__restrict__ rtype,
     // the 7 angles as normalised (sin, cos): lane k < 7 evaluates angle k (phi-like 0..2, chi 3..6); group g uses angle g-1
     float my_s = 0.f, my_c = 1.f;
     if (a < 7) {
-        // (UPD: the angles this block has just written; not through the __restrict__ input pointer)
-        const float *ch = UPD ? static_cast<const float *>(U.xeff) : chi;
-        const float ang = a < 3 ? BB_D[(size_t)n * 3 + a] : ch[(size_t)n * 4 + (a - 3)];
+        // (UPD: the angles this block has just written.  A group beyond N mirrors residue N - 1, which belongs to this same
+        // block -- N - 1 = 16 blockIdx.x + its group -- so its angles are in s_chi too)
+        float ang;
+        if (a < 3) ang = bbd_t;
+        else if (UPD) ang = s_chi[n - blockIdx.x * 16][a - 3];
+        else ang = chi_t;
         const float s0 = sinf(ang), c0 = cosf(ang);
         const float den = sqrtf(fmaxf(s0 * s0 + c0 * c0, 1e-12f));
         my_s = s0 / den; my_c = c0 / den;
@@ -161,40 +191,45 @@ k_atom14(int N, const float *__restrict__ X, const int64_t *__restrict__ rtype,
 #pragma unroll
     for (int g = 1; g < 8; g++) { sn[g] = __shfl(my_s, g - 1, 16); cs[g] = __shfl(my_c, g - 1, 16); }
 
-    const int g0 = g < 4 ? g : 4;
-    Rig chain = torsion_frame(df, g0, sel8(sn, g0), sel8(cs, g0));
+    Rig chain = torsion_frame(f0, sel8(sn, g0), sel8(cs, g0));
     const bool axis_lane = a == 14 && axes != nullptr && live;
-    if (axis_lane) {
+    float ax[4][6];                       // lane 14: the four chi axes in global coordinates (stored below, one branch)
+    {
         const Rig Fg = compose(G, chain);
-        float *o = axes + ((size_t)n * 4 + 0) * 6;
-        o[0] = Fg.R.m[0]; o[1] = Fg.R.m[3]; o[2] = Fg.R.m[6]; o[3] = Fg.t[0]; o[4] = Fg.t[1]; o[5] = Fg.t[2];
+        ax[0][0] = Fg.R.m[0]; ax[0][1] = Fg.R.m[3]; ax[0][2] = Fg.R.m[6]; ax[0][3] = Fg.t[0]; ax[0][4] = Fg.t[1]; ax[0][5] = Fg.t[2];
     }
 #pragma unroll
     for (int gg = 5; gg < 8; gg++) {
-        const Rig nx = compose(chain, torsion_frame(df, gg, sn[gg], cs[gg]));
-        if (gg <= g) chain = nx;
-        if (axis_lane) {
-            const Rig Fg = compose(G, chain);
-            float *o = axes + ((size_t)n * 4 + (gg - 4)) * 6;
-            o[0] = Fg.R.m[0]; o[1] = Fg.R.m[3]; o[2] = Fg.R.m[6]; o[3] = Fg.t[0]; o[4] = Fg.t[1]; o[5] = Fg.t[2];
-        }
+        const Rig nx = compose(chain, torsion_frame(gg == 5 ? f5 : gg == 6 ? f6 : f7, sn[gg], cs[gg]));
+        const bool take = gg <= g;        // selects, not a branch: the chain stays one basic block
+#pragma unroll
+        for (int q = 0; q < 9; q++) chain.R.m[q] = take ? nx.R.m[q] : chain.R.m[q];
+#pragma unroll
+        for (int q = 0; q < 3; q++) chain.t[q] = take ? nx.t[q] : chain.t[q];
+        const Rig Fg = compose(G, chain);
+        ax[gg - 4][0] = Fg.R.m[0]; ax[gg - 4][1] = Fg.R.m[3]; ax[gg - 4][2] = Fg.R.m[6];
+        ax[gg - 4][3] = Fg.t[0]; ax[gg - 4][4] = Fg.t[1]; ax[gg - 4][5] = Fg.t[2];
+    }
+    if (axis_lane) {
+#pragma unroll
+        for (int c4 = 0; c4 < 4; c4++)
+#pragma unroll
+            for (int q = 0; q < 6; q++) axes[((size_t)n * 4 + c4) * 6 + q] = ax[c4][q];
     }
     const Rig F = compose(G, chain);
     float p[3] = {0.f, 0.f, 0.f}, ex = 0.f, reff = 0.f;
     if (a < 14) {
         if (a < 4) {
 #pragma unroll
-            for (int k = 0; k < 3; k++) p[k] = x[3 * a + k];
+            for (int k = 0; k < 3; k++) p[k] = xa_t[k];
         } else {
-            const float *lp = lit + ((size_t)S * 14 + a) * 3;
-            const float am = amask14[S * 14 + a];
             float rp[3];
             rot3(F.R, lp, rp);
 #pragma unroll
             for (int k = 0; k < 3; k++) p[k] = (rp[k] + F.t[k]) * am;
         }
-        ex = atom_exists ? atom_exists[(size_t)n * 14 + a] : 1.f;
-        reff = ex * between_radius[S * 14 + a];
+        ex = ex_t;
+        reff = ex * br_t;
         if (live) {
 #pragma unroll
             for (int k = 0; k < 3; k++) xyz[((size_t)n * 14 + a) * 3 + k] = p[k];
