@@ -40,7 +40,7 @@ FP32_MFMA_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 F16_MFMA_PEAK_TFLOPS = 2500.0       # MI355X_MICROARCH.md, "Peak BF16/FP16 MFMA ~2.5 PF dense"
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md, "HBM3E peak BW 8.0 TB/s spec"
 CU_VMEM_PEAK_GBS = 64 * 2.4         # one CU's vector-memory path: 64 B/clk at 2.4 GHz
-PROFILE_TAG = "r02_v16"             # the committed rocprofv3 summaries of THIS command (profiles/<tag>_*.{csv,json})
+PROFILE_TAG = "r02_v17"             # the committed rocprofv3 summaries of THIS command (profiles/<tag>_*.{csv,json})
 
 
 def _load_fixture(name, init_key):
