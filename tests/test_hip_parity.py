@@ -218,6 +218,18 @@ def test_proximal(tag):
     assert abs(float(m["atom_rmsd"]) - float(z["metric32.atom_rmsd"])) < 1e-3, (tag, float(m["atom_rmsd"]))
 
 
+def test_proximal_is_bit_reproducible():
+    """The clash loss and its gradient are gathered per residue and reduced in a fixed order (no atomics): two runs of the
+    50-step optimisation agree bit for bit, losses included."""
+    from packppi_amd.functional import proximal_optimizer
+    z, b, chi0 = _g6("T1124")
+    gb, chi0 = _gpu(b), chi0.to(DEV)
+    c1, l1 = proximal_optimizer(gb, chi0, 12.0, 0.5, 1.0, 50)
+    c2, l2 = proximal_optimizer(gb, chi0, 12.0, 0.5, 1.0, 50)
+    assert l1 == l2
+    assert all(torch.equal(a, c) for a, c in zip(c1, c2))
+
+
 class _Metrics:
     """analyze_samples without a network plan (the proximal CLI path: src/proximal_optimize.py needs no checkpoint)."""
     NUM_CHI_ANGLES, eps = 4, 1e-6
