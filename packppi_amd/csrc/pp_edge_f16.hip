@@ -68,6 +68,15 @@ __device__ __forceinline__ h2v cvt2(f32x2v x) {
     return __builtin_bit_cast(h2v, r);
 }
 #endif
+// x - (float)hh for a packed pair: one v_fma_mix_f32 per value (the f16 half is an operand of the fp32 FMA; exact, like the
+// v_cvt_f32_f16 + v_sub_f32 pair it replaces -- a quarter of the split's VALU instructions)
+__device__ __forceinline__ f32x2v split_residual(h2v hh, f32x2v x) {
+    const unsigned hp = __builtin_bit_cast(unsigned, hh);
+    float d0, d1;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(d0) : "v"(hp), "v"(x[0]));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d1) : "v"(hp), "v"(x[1]));
+    return f32x2v{d0, d1};
+}
 template <bool RELU>
 __device__ __forceinline__ void split_tile(const f32x16 &v, HT &o) {
 #pragma unroll
@@ -81,7 +90,7 @@ __device__ __forceinline__ void split_tile(const f32x16 &v, HT &o) {
                 x[1] = __builtin_amdgcn_fmed3f(x[1], 0.f, 65504.f);
             }
             const h2v hh = cvt2(x);
-            const f32x2v d = {fmaf((float)hh[0], -1.0f, x[0]), fmaf((float)hh[1], -1.0f, x[1])};
+            const f32x2v d = split_residual(hh, x);
             const h2v ll = cvt2(d);
             o.hi[s][i] = hh[0]; o.hi[s][i + 1] = hh[1];
             o.lo[s][i] = ll[0]; o.lo[s][i + 1] = ll[1];
@@ -368,7 +377,7 @@ __device__ __forceinline__ void geometry_share(const float *__restrict__ pts_i, 
         const f32x2v x = {v[i], v[i + 1]};
         PP_RANGE(x[0]) PP_RANGE(x[1])
         const h2v hh = cvt2(x);
-        const f32x2v d = {fmaf((float)hh[0], -1.0f, x[0]), fmaf((float)hh[1], -1.0f, x[1])};
+        const f32x2v d = split_residual(hh, x);
         const h2v ll = cvt2(d);
         if (i < 8) { vh[i] = hh[0]; vh[i + 1] = hh[1]; vl[i] = ll[0]; vl[i + 1] = ll[1]; }
         else { dh = hh; dl = ll; }
