@@ -139,8 +139,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="t1124", choices=["t1124", "s1500", "c5"])
     ap.add_argument("--proximal", action="store_true", help="add the 50-step proximal optimisation (configs[2] / configs[3])")
-    ap.add_argument("--cpu-steps", type=int, default=20, help="diffusion steps of the CPU-baseline sample (0 = skip)")
-    ap.add_argument("--cpu-grad-steps", type=int, default=2, help="steps of the autograd-on CPU sample (0 = skip)")
+    ap.add_argument("--cpu-steps", type=int, default=50, help="diffusion steps of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-grad-steps", type=int, default=4, help="steps of the autograd-on CPU sample (0 = skip)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the configs[4] share (c5) figure")
     args = ap.parse_args()
 
