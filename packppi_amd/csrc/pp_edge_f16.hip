@@ -180,12 +180,7 @@ __device__ __forceinline__ void gload_A(const h8 *__restrict__ wq, int chunk, AO
     int off = chunk * 1024;                  // h8 units per 16 KB chunk
     asm volatile("" : "+s"(off));
     const h8 *p = wq + off;
-#ifdef PP_X_WNT          /* experiment: non-temporal weight loads */
-    a.r[0] = __builtin_nontemporal_load(p); a.r[1] = __builtin_nontemporal_load(p + 64);
-    a.r[2] = __builtin_nontemporal_load(p + 128); a.r[3] = __builtin_nontemporal_load(p + 192);
-#else
     a.r[0] = p[0]; a.r[1] = p[64]; a.r[2] = p[128]; a.r[3] = p[192];
-#endif
 }
 // R residues share the A operands (weights) of a stage: R independent accumulator chains, issued interleaved so that a
 // wave alone on its SIMD never waits on its own previous MFMA.  x[r][T] = input tile T of residue r.
@@ -428,11 +423,6 @@ __device__ __forceinline__ void geometry_share(const float *__restrict__ pts_i, 
 #define MF_BEGIN()
 #define MF_END()
 #endif
-#ifdef PP_X_DRAIN
-#define MFMA_DRAIN() asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory")
-#else
-#define MFMA_DRAIN()
-#endif
 #define BT_FETCH(BUF, t, set)                                                     \
     _Pragma("unroll") for (int r = 0; r < R; r++) xbuf_get_h((BUF) + r * XBUF_FLOATS, t, lane, bt[set][r]);
 // stage k: B operand = tile T of BUF (tile T+1 is requested first), SWAP as in mfma_h
@@ -456,7 +446,6 @@ __device__ __forceinline__ void geometry_share(const float *__restrict__ pts_i, 
 #define PRE_PUBLISH() { if constexpr (NXB == 1) __syncthreads(); NEXT_XBUF() }
 #define PUBLISH_RELU()                                                            \
     MF_END()                                                                      \
-    MFMA_DRAIN();                                                                 \
     PRE_PUBLISH()                                                                 \
     _Pragma("unroll") for (int r = 0; r < R; r++) {                               \
         HT ht;                                                                    \
@@ -590,7 +579,7 @@ __device__ __forceinline__ void node_message_body(const EdgeArgs &A, const int r
 #pragma unroll
         for (int q = 0; q < 16; q++) acc[r][q] = bmid;
     XLAYER(C0 + 3, NCH, acc, xbuf, true)
-    MF_END() MFMA_DRAIN();
+    MF_END()
 #pragma unroll
     for (int r = 0; r < R; r++) {
         // rows (registers) are edges e = 8 (r>>2) + 4 h + (r&3); mask and reduce over them
@@ -728,7 +717,7 @@ __device__ __forceinline__ void edge_update_body(const EdgeArgs &A, const int re
     XLAYER(C0 + 7, NCH, acc, xbuf, false)
     TS(4)
     // ---- x1 = LN2(h_E + mask * m): own tile only, statistics merged across the four waves ---------------
-    MF_END() MFMA_DRAIN();
+    MF_END()
 #pragma unroll
     for (int r = 0; r < R; r++) {
 #pragma unroll
@@ -763,7 +752,7 @@ __device__ __forceinline__ void edge_update_body(const EdgeArgs &A, const int re
     FFN_BLOCK(3)
     TS(10)
     // ---- h_E = mask * LN3(x1 + ffn) ---------------------------------------------------------------------
-    MF_END() MFMA_DRAIN();
+    MF_END()
 #pragma unroll
     for (int r = 0; r < R; r++) ln_partial(out[r], stat + r * STAT_FLOATS, wave, j, h);
     __syncthreads();
@@ -812,7 +801,7 @@ __device__ __forceinline__ void edge_update_body(const EdgeArgs &A, const int re
         TS(15)
         XLAYER(NEU + 7, NCH, acc, xbuf, true)
         TS(16)
-        MF_END() MFMA_DRAIN();
+        MF_END()
 #pragma unroll
         for (int r = 0; r < R; r++) {
             // rows (registers) are edges e = 8 (r>>2) + 4 h + (r&3); mask and reduce over them
