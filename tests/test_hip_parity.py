@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from .conftest import load_golden, wrapped_absdiff
+from .conftest import GOLD, load_golden, wrapped_absdiff
 
 pytestmark = pytest.mark.gpu
 
@@ -294,6 +294,24 @@ def test_T1124_100_steps(model):
     from packppi_amd.functional import compute_residue_clash
     pr = compute_residue_clash(gb, g["chi_ode_100"].to(DEV), 12.0, 0.5).cpu()
     assert (pr - g["clash_final"]).abs().max() < 2e-5
+
+
+def test_T1124_sde_100_steps(weights):
+    """T1124 in SDE mode, 100 steps: the reference drew its per-step noise from the global CPU generator seeded with 1124
+    right before the loop (schedule.py:225; the 1pi schedule's draw first); the same torch.normal calls are made here and
+    handed in.  The stochastic path amplifies rounding no more than the ODE path does."""
+    from packppi_amd.module import TDiffusionModule
+    b, g = load_golden("g4_T1124")
+    ref = np.load(os.path.join(GOLD, "g9_T1124_sde.npz"))["chi_sde_100_seed1124"]
+    m = TDiffusionModule(weights, sample_cfg=dict(mode="sde"), device=DEV)
+    n = 100
+    torch.manual_seed(1124)
+    N = b.residue_type.numel()
+    noise = torch.stack([torch.stack((torch.normal(mean=0, std=1, size=(N, 4)),
+                                      torch.normal(mean=0, std=1, size=(N, 4)))) for _ in range(n)])
+    chi = m._context(_gpu(b)).sample(g["init_chi_seed1124"].to(DEV), torch.linspace(1, 0, n + 1), "sde", noise).cpu()
+    d = wrapped_absdiff(chi, torch.from_numpy(ref))[b.SC_D_mask.bool()]
+    assert d.max() < 1e-4, float(d.max())
 
 
 def test_S1500_100_steps(model):

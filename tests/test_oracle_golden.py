@@ -2,13 +2,15 @@
 
 Every tolerance here is "same fp32 arithmetic, possibly a different summation order".
 """
+import os
+
 import numpy as np
 import pytest
 import torch
 
 from oracle import ref_cpu as O
 from packppi_amd import constants as rc
-from .conftest import load_golden, wrapped_absdiff
+from .conftest import GOLD, load_golden, wrapped_absdiff
 
 OPS = ["g2_ops_L8", "g2_ops_L33", "g2_ops_L64", "g2_ops_B3"]
 
@@ -128,6 +130,19 @@ def test_sampling_sde(weights):
         noise.append((torch.normal(mean=0, std=1, size=(N, 4)), torch.normal(mean=0, std=1, size=(N, 4))))
     chi = O.sampling(weights, b, g["init_chi_seed11"], torch.linspace(1, 0, n + 1), mode="sde", sde_noise=noise)
     d = wrapped_absdiff(chi, g["chi_sde_30_seed99"])[b.SC_D_mask.bool()]
+    assert d.max() < 5e-5, float(d.max())
+
+
+def test_T1124_sde_100_steps(weights):
+    """The oracle's SDE path at benchmark size against the reference's run (fixture g9: seed and result only)."""
+    b, g = load_golden("g4_T1124")
+    ref = torch.from_numpy(np.load(os.path.join(GOLD, "g9_T1124_sde.npz"))["chi_sde_100_seed1124"])
+    n = 100
+    torch.manual_seed(1124)
+    N = b.residue_type.numel()
+    noise = [(torch.normal(mean=0, std=1, size=(N, 4)), torch.normal(mean=0, std=1, size=(N, 4))) for _ in range(n)]
+    chi = O.sampling(weights, b, g["init_chi_seed1124"], torch.linspace(1, 0, n + 1), mode="sde", sde_noise=noise)
+    d = wrapped_absdiff(chi, ref)[b.SC_D_mask.bool()]
     assert d.max() < 5e-5, float(d.max())
 
 

@@ -201,6 +201,22 @@ def main():
         chi = run_sampling(sde_model, rb, init, 30)
         save("g3_sampling_sde_L33", **pack_batch(b), init_chi_seed11=init, chi_sde_30_seed99=chi)
 
+    # ---- g9: T1124 in SDE mode, 100 steps: the reference's own per-step draws from the global CPU generator seeded right
+    # before the loop (only the seed and the result are stored; the test redraws the same torch.normal calls) -------------
+    if want("g9"):
+        g4 = np.load(os.path.join(GOLD, "g4_T1124.npz"))
+        prot = from_pdb_file(os.path.join(refshim.REF, "data", "T1124_lig.pdb"))
+        b = protein_to_batch(prot)
+        rb = ref_batch(b)
+        sde_model = refshim.build_reference_module(0, mode="sde")
+        sde_model.load_state_dict(sd, strict=True)
+        init = torch.from_numpy(g4["init_chi_seed1124"])
+        torch.manual_seed(1124)
+        t0 = time.time()
+        chi = run_sampling(sde_model, rb, init, 100)
+        print(f"  T1124 sde 100 steps {time.time() - t0:.1f}s", flush=True)
+        save("g9_T1124_sde", chi_sde_100_seed1124=chi)
+
     # ---- g5: the 1500-residue synthetic complex of BASELINE config 3 (bench.py --workload s1500), 100 steps ----------
     if want("g5"):
         b = synth_batch(1500, 1500)
