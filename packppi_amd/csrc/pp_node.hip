@@ -304,10 +304,9 @@ typedef float nf2 __attribute__((ext_vector_type(2)));
 typedef unsigned nu2 __attribute__((ext_vector_type(2)));
 
 #ifndef PP_NU_DEPTH
-#define PP_NU_DEPTH 8
+#define PP_NU_DEPTH 8      // weight stages in flight per wave when a launch is one round of workgroups (<= one tile per CU)
 #endif
-#define NU_ND PP_NU_DEPTH
-#define NU_NRING (NU_ND + 1)
+#define PP_NU_DEPTH_MULTI 5   // ... when there are more tiles than CUs: 128 VGPRs or fewer, so that two workgroups share a CU
 #define NU_S128 144        // halves per residue row of a 128-feature operand image
 #define NU_S512 528        // ... of the 512-feature one
 #define NU_S32 48          // ... of the 32-feature one (node embedding inputs)
@@ -486,9 +485,10 @@ __device__ __forceinline__ nf4 ln128(float (*st)[16][2], int wv, int r, int g, c
 #else
 #define NU_X_NOLOAD false
 #endif
-template <int MODE>
+template <int MODE, int NU_ND>
 __global__ void __launch_bounds__(512)
 k_node_update(NUpdArgs A, float *chi, int step, int sde, const float *noise, int embed_next, StepScalars sp, TimeEmb te_next) {
+    constexpr int NU_NRING = NU_ND + 1;
     constexpr bool LAST = MODE != PP_NU_MID;
     constexpr int NSLOT = LAST ? PP_NU_SLOTS_LAST : PP_NU_SLOTS_MID;
     constexpr int NLOAD = MODE == PP_NU_SCORE ? 46 : NSLOT;       // slots this instance ever fetches
@@ -830,17 +830,29 @@ static PreW make_pre(const pp_plan *p, int layer, bool edge) {
     return w;
 }
 
+typedef void (*nu_kernel_t)(NUpdArgs, float *, int, int, const float *, int, StepScalars, TimeEmb);
+// mode 0 / 1 / 2 = PP_NU_MID / PP_NU_STEP / PP_NU_SCORE; multi: more tiles than CUs (shallower ring, two workgroups per CU)
+static nu_kernel_t nu_kernel(int mode, bool multi) {
+    if (multi)
+        return mode == 0 ? k_node_update<PP_NU_MID, PP_NU_DEPTH_MULTI> : mode == 1 ? k_node_update<PP_NU_STEP, PP_NU_DEPTH_MULTI>
+                                                                                    : k_node_update<PP_NU_SCORE, PP_NU_DEPTH_MULTI>;
+    return mode == 0 ? k_node_update<PP_NU_MID, PP_NU_DEPTH> : mode == 1 ? k_node_update<PP_NU_STEP, PP_NU_DEPTH>
+                                                                          : k_node_update<PP_NU_SCORE, PP_NU_DEPTH>;
+}
+static int g_nu_cus = 0;
 static pp_status node_attrs() {
     static bool done = false;
     if (!done) {
         PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_node_embed),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Smem)));
-        PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_node_update<PP_NU_MID>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SmemU)));
-        PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_node_update<PP_NU_STEP>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SmemU)));
-        PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_node_update<PP_NU_SCORE>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SmemU)));
+        for (int multi = 0; multi < 2; multi++)
+            for (int mode = 0; mode < 3; mode++)
+                PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(nu_kernel(mode, multi != 0)),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SmemU)));
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) g_nu_cus = prop.multiProcessorCount;
+        if (g_nu_cus <= 0) g_nu_cus = 256;
         done = true;
     }
     return PP_OK;
@@ -894,12 +906,9 @@ pp_status pp_launch_node_update(pp_ctx *c, int layer, int last_mode, float *chi,
     TimeEmb te = {};
     if (cur) sp = {cur->c_ode, cur->w, cur->c_drift, cur->c_diff};
     if (next) memcpy(te.v, next->temb, sizeof(te.v));
-    if (last_mode == PP_NU_MID)
-        PP_LAUNCH(c, k_node_update<PP_NU_MID>, grid, block, sizeof(SmemU), s, A, chi, step, sde, noise, embed_next, sp, te);
-    else if (last_mode == PP_NU_STEP)
-        PP_LAUNCH(c, k_node_update<PP_NU_STEP>, grid, block, sizeof(SmemU), s, A, chi, step, sde, noise, embed_next, sp, te);
-    else
-        PP_LAUNCH(c, k_node_update<PP_NU_SCORE>, grid, block, sizeof(SmemU), s, A, chi, step, sde, noise, embed_next, sp, te);
+    const bool multi = (int)grid.x > g_nu_cus;
+    const nu_kernel_t kern = nu_kernel(last_mode == PP_NU_MID ? 0 : last_mode == PP_NU_STEP ? 1 : 2, multi);
+    PP_LAUNCH(c, kern, grid, block, sizeof(SmemU), s, A, chi, step, sde, noise, embed_next, sp, te);
     PP_HIP_CHECK(hipGetLastError());
 #ifdef PP_X_NU_EMBED_LAUNCH
     if (embed_after) return pp_launch_node_embed(c, chi, *next, s);
