@@ -183,10 +183,13 @@ def main():
         inits = {i: (torch.rand(1, int(c["max_size"]), 4, generator=g) * 2 - 1) * np.pi * c.SC_D_mask.cpu()
                  for i, c in enumerate(complexes)}
 
+        # the initial noised angles of the packed rows: resident on the device before the timed region, like the batch
+        x0_packed = torch.cat([inits[i][:, : c.true_residues()] for i, c in enumerate(complexes)], 1).to(dev)
+
         def one_pass():
             if args.proximal:
                 raise SystemExit("--proximal with --workload c5: use the per-complex workloads")
-            return sample_sharded_local(model, complexes, inits)
+            return sample_sharded_local(model, complexes, x0_packed)
     else:
         batch, init, ref_chi = load_t1124() if args.workload == "t1124" else load_s1500()
         name = {"t1124": "data/T1124_lig.pdb (L=739, 738 true residues), 1 complex per GPU",
@@ -266,7 +269,8 @@ def main():
         g = torch.Generator().manual_seed(1000 + rank)
         c5_init = {i: (torch.rand(1, int(c["max_size"]), 4, generator=g) * 2 - 1) * np.pi * c.SC_D_mask.cpu()
                    for i, c in enumerate(c5)}
-        el5, _ = timed(lambda: sample_sharded_local(model, c5, c5_init), 3, 1)
+        c5_x0 = torch.cat([c5_init[i][:, : c.true_residues()] for i, c in enumerate(c5)], 1).to(dev)
+        el5, _ = timed(lambda: sample_sharded_local(model, c5, c5_x0), 3, 1)
         res5 = allsum(sum(c.true_residues() for c in c5))
         secondary = {"workload": "BASELINE configs[4] share: 32 synthetic complexes L~U{270..330} per GPU as one packed ragged "
                                  "batch (no padding rows), 100 steps, no proximal",
@@ -373,12 +377,12 @@ def main():
 
 def sample_sharded_local(model, complexes, inits):
     """The sampling part of parallel.sample_sharded for complexes this rank already owns (no metric gather): one packed
-    ragged batch, context prepared inside the timed pass like the single-complex workloads."""
+    ragged batch (packing and context preparation inside the timed pass, like the preparation of the single-complex
+    workloads); ``inits`` = the initial noised angles of the packed rows, already on the device."""
     from packppi_amd.batch import pack
     from packppi_amd.lib import Context
     pb = pack(complexes)
-    x0 = torch.cat([inits[i][:, : int(c["residue_mask"].sum())] for i, c in enumerate(complexes)], 1).to(model.device)
-    return Context(model._plan, pb).sample(x0, model.schedule)
+    return Context(model._plan, pb).sample(inits, model.schedule)
 
 
 if __name__ == "__main__":
