@@ -41,6 +41,10 @@ typedef struct pp_ctx pp_ctx;   /* one batch of complexes: cached graph, frames,
 #define PP_TOP_K 32
 #define PP_MODE_ODE 0
 #define PP_MODE_SDE 1
+/* What the neighbour search does where two CA distances of a row are exactly equal (pp_plan_set_knn_ties). */
+#define PP_KNN_TIES_LOWER_INDEX 0 /* the residue with the lower index first                                          */
+#define PP_KNN_TIES_ATEN_CPU 1    /* default: the choice AND order of torch.topk on CPU (the reference CPU path)       */
+#define PP_KNN_TIES_ATEN_MEMBER 2 /* that choice only where it decides membership (rank K == rank K+1), else lower index */
 
 /* Residue-chemistry tables (HOST pointers; values of src/utils/residue_constants.py:595-677). */
 typedef struct pp_tables {
@@ -71,6 +75,11 @@ typedef struct pp_batch {
 int pp_version(void);
 const char *pp_last_error(void);
 
+/* Build stamp: "<sources>-<flags>", two 16-digit hex prefixes of the SHA-256 of (a) every file of packppi_amd/csrc/*.hip|*.h
+ * plus this header, (b) the compiler flags, as computed by packppi_amd/build.py when the library was compiled.  The Python
+ * binding refuses a library whose <sources> part differs from the sources on disk (a stale prebuilt .so). */
+const char *pp_build_id(void);
+
 /* Replaces TDiffusionModule.__init__ + load_from_checkpoint (TorsionalDiffusion.py:22-82,
  * eval_diffusion.py:29-41).  `weights` is a HOST buffer holding the 112 state_dict tensors
  * concatenated in the order of packppi_amd/weights.py::weight_spec(), nn.Linear [out,in].
@@ -87,6 +96,19 @@ void pp_plan_destroy(pp_plan *plan);
  * (the one blocking call besides the measurement aids; it runs once per parameter set, not per batch). */
 pp_status pp_plan_set_clash_params(pp_plan *plan, float overlap_tolerance, const float *lower,
                                    const float *upper, void *stream);
+
+/* ProteinEncoder._dist takes torch.topk(D_adjust, K, largest=False) (encoder.py:105-118), which leaves the choice between
+ * exactly equal distances to the implementation -- and on ideal-geometry or 0.001-Angstrom-grid coordinates equal distances
+ * do occur (about one row in five of the synthetic complexes has an order tie, one complex in thirty a membership tie at rank
+ * K / K+1, which changes the graph).  PP_KNN_TIES_ATEN_CPU (the default) reproduces the reference CPU path: rows that hold a
+ * tie among their K+1 smallest values are redone on the device with the selection ATen's CPU topk makes (std::nth_element +
+ * std::sort, or std::partial_sort when 64 K <= L, of libstdc++ over (value, index) pairs with a value-only comparator;
+ * csrc/pp_topk_aten.h).  Applies to contexts prepared afterwards. */
+pp_status pp_plan_set_knn_ties(pp_plan *plan, int mode);
+
+/* HOST helper, no device call: idx_out[0..k-1] = torch.topk(values[0..n-1], k, largest=False) indices as ATen's CPU kernel
+ * returns them -- the same code the neighbour search runs on the device for rows with ties.  Returns PP_OK / PP_ERR_INVALID. */
+pp_status pp_topk_aten_host(const float *values, int n, int k, int32_t *idx_out);
 
 /* Replaces the timestep-invariant part of ProteinEncoder.forward (encoder.py:198-246):
  * kNN graph, 468-d edge features, edge embedding + LayerNorm, backbone frames.  The batch
@@ -114,11 +136,9 @@ pp_status pp_complex_prepare_packed(pp_plan *plan, const pp_batch *batch, const 
 pp_status pp_ctx_get_graph(pp_ctx *ctx, int64_t *E_idx, float *hE0, void *stream);
 
 /* Replace the ctx's neighbour lists by the caller's E_idx [B,L,K] (per-complex numbering, as
- * ProteinEncoder._dist returns them, encoder.py:105-118) and redo the edge embedding.  For callers who need
- * the reference's own choice where torch.topk leaves it open: when two CA distances at rank K and K+1 are
- * exactly equal, which of the two residues is a neighbour is unspecified in the reference (it differs between
- * its CPU and GPU paths); this library's search takes the lower index.  Validates the indices (one
- * read-back: the call waits for `stream`). */
+ * ProteinEncoder._dist returns them, encoder.py:105-118) and redo the edge embedding: for callers who want
+ * another tie convention than the two the search offers (e.g. the lists of the reference's GPU path).
+ * Validates the indices (one read-back: the call waits for `stream`). */
 pp_status pp_ctx_set_graph(pp_ctx *ctx, const int64_t *E_idx, void *stream);
 
 /* Replaces TDiffusionModule.network(batch, SC_D_noised, t) (TorsionalDiffusion.py:90-109) for a

@@ -88,24 +88,25 @@ def split(batch: Batch) -> List[Batch]:
 
 def pack(complexes: Iterable[Batch]) -> Batch:
     """Ragged batch WITHOUT padding rows: the complexes' rows back to back in one [1, sum of lengths, ...] batch, plus
-    ``seg_offsets`` (int32 [n + 1]: first row of every complex, then the total).
+    ``seg_offsets`` (int32 [n + 1]: first row of every complex, then the total; ``seg_offsets_host`` is the same as a list,
+    so that nothing has to be read back from the device).
 
     The reference pads to the longest complex and stacks (``collate``; complex_datamodule.py:196-226) and then computes on
     the padding rows as well; the path has no cross-complex term, so a packed batch gives every complex the result of
     running it alone (``lib.Context`` / ``pp_complex_prepare_packed``).  Accepts per-complex data (``protein_to_data``,
-    tensors [L, ...]) or B = 1 batches ([1, L, ...]); only true residues are kept (``residue_mask``)."""
+    tensors [L, ...]) or B = 1 batches ([1, L, ...]).  Only TRAILING padding is dropped: a complex keeps its rows up to the
+    last true residue, so a residue masked out in the middle of a chain (a missing backbone atom: featurize.py) stays in
+    place with its ``residue_mask`` 0, exactly as the reference carries it."""
     rows = {k: [] for k in TENSOR_KEYS}
     offs = [0]
     for c in complexes:
         lead = c["residue_type"].dim() == 2
         if lead and c["residue_type"].shape[0] != 1:
             raise ValueError("pack() takes single complexes (use split() on a padded batch first)")
-        keep = (c["residue_mask"][0] if lead else c["residue_mask"]) > 0
-        n = int(keep.sum())
-        if n == 0:
+        keep = ((c["residue_mask"][0] if lead else c["residue_mask"]) > 0).cpu()
+        if not bool(keep.any()):
             raise ValueError("empty complex")
-        if not bool(keep[:n].all()):
-            raise ValueError("residue_mask must be a prefix mask (padding at the end)")
+        n = int(torch.nonzero(keep).max()) + 1
         for k in TENSOR_KEYS:
             t = c[k][0] if lead else c[k]
             rows[k].append(t[:n])
@@ -113,11 +114,12 @@ def pack(complexes: Iterable[Batch]) -> Batch:
     out = Batch(num_proteins=1, max_size=offs[-1])
     for k in TENSOR_KEYS:
         out[k] = torch.cat(rows[k], 0).unsqueeze(0)
-    out["seg_offsets"] = torch.tensor(offs, dtype=torch.int32, device=out["X"].device)
+    out["seg_offsets"] = torch.tensor(offs, dtype=torch.int32).to(out["X"].device, non_blocking=True)
+    out["seg_offsets_host"] = offs
     return out
 
 
 def unpack(packed: Batch, t: torch.Tensor) -> List[torch.Tensor]:
     """Split a per-row result [1, sum of lengths, ...] of a packed batch into one [1, L_i, ...] tensor per complex."""
-    offs = [int(x) for x in packed["seg_offsets"].tolist()]
+    offs = packed.get("seg_offsets_host") or [int(x) for x in packed["seg_offsets"].tolist()]
     return [t[:, a:b] for a, b in zip(offs[:-1], offs[1:])]

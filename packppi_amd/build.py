@@ -1,5 +1,7 @@
 """Compile the HIP sources into ``csrc/libpackppi_hip.so`` (gfx950 only, in-tree)."""
+import hashlib
 import os
+import re
 import shutil
 import subprocess
 import sys
@@ -21,29 +23,55 @@ def _hipcc():
     raise RuntimeError("hipcc not found (set HIPCC or install ROCm)")
 
 
-def needs_build():
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h", ".inc"))]
-    deps.append(os.path.join(CSRC, "..", "..", "include", "packppi_hip.h"))
-    return any(os.path.getmtime(d) > t for d in deps)
+def _dep_files():
+    deps = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h", ".inc")))
+    deps.append(os.path.normpath(os.path.join(CSRC, "..", "..", "include", "packppi_hip.h")))
+    return deps
 
 
-def build_library(force=False, verbose=True, extra_flags=(), tag=""):
-    """Build the library; with ``tag`` a variant ``libpackppi_hip.<tag>.so`` (selected at run time by PACKPPI_LIB)."""
-    lib_path = LIB if not tag else LIB.replace(".so", f".{tag}.so")
-    if not tag and not force and not needs_build():
-        return LIB
+def source_hash():
+    """16 hex digits over the name and content of every kernel source, internal header and the public header."""
+    h = hashlib.sha256()
+    for d in _dep_files():
+        h.update(os.path.basename(d).encode() + b"\0")
+        h.update(open(d, "rb").read() + b"\0")
+    return h.hexdigest()[:16]
+
+
+def flags_hash(flags, sources):
+    return hashlib.sha256("\0".join(list(flags) + ["|"] + list(sources)).encode()).hexdigest()[:16]
+
+
+def build_id(flags, sources):
+    """What ``pp_build_id()`` of a library compiled now from these sources with these flags returns."""
+    return f"{source_hash()}-{flags_hash(flags, sources)}"
+
+
+def embedded_build_id(path):
+    """The stamp inside a built library, read from the file (no dlopen: a stale library must not get loaded by the check)."""
+    if not os.path.exists(path):
+        return None
+    m = re.search(rb"PP_BUILD_ID=([0-9a-f]{16}-[0-9a-f]{16})", open(path, "rb").read())
+    return m.group(1).decode() if m else None
+
+
+def needs_build(lib_path=LIB, flags=None, sources=None):
+    """True unless the library exists and carries the stamp of the sources on disk and of these flags (content hashes, not
+    mtimes: a prebuilt library that no longer matches csrc/ is rebuilt)."""
+    return embedded_build_id(lib_path) != build_id(FLAGS if flags is None else flags, SOURCES if sources is None else sources)
+
+
+def _compile_and_link(lib_path, sources, flags, tag, verbose, only=()):
     hipcc = _hipcc()
+    stamp = build_id(flags, sources)
     objs = []
-    only = os.environ.get("PACKPPI_VARIANT_SOURCES", "").split()      # tagged build: recompile only these, reuse the base objects
-    for src in SOURCES:
+    for src in sources:
         obj = os.path.join(CSRC, src.replace(".hip", f".{tag}.o" if tag else ".o"))
         if tag and only and src not in only:
             objs.append(os.path.join(CSRC, src.replace(".hip", ".o")))
             continue
-        cmd = [hipcc, *FLAGS, *extra_flags, "-c", os.path.join(CSRC, src), "-o", obj]
+        extra = [f'-DPP_BUILD_ID="{stamp}"'] if src == "pp_api.hip" else []
+        cmd = [hipcc, *flags, *extra, "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
@@ -53,6 +81,16 @@ def build_library(force=False, verbose=True, extra_flags=(), tag=""):
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
     return lib_path
+
+
+def build_library(force=False, verbose=True, extra_flags=(), tag=""):
+    """Build the library; with ``tag`` a variant ``libpackppi_hip.<tag>.so`` (selected at run time by PACKPPI_LIB)."""
+    lib_path = LIB if not tag else LIB.replace(".so", f".{tag}.so")
+    flags = [*FLAGS, *extra_flags]
+    if not force and not needs_build(lib_path, flags, SOURCES):
+        return lib_path
+    only = os.environ.get("PACKPPI_VARIANT_SOURCES", "").split()      # tagged build: recompile only these, reuse the base objects
+    return _compile_and_link(lib_path, SOURCES, flags, tag, verbose, only)
 
 
 def other_variant_path():
@@ -67,23 +105,9 @@ def build_other_variant(verbose=True):
     tag = "f32" if EDGE_F16 else "f16"
     sources = ["pp_api.hip", "pp_prepare.hip", "pp_node.hip", "pp_edge.hip" if EDGE_F16 else "pp_edge_f16.hip", "pp_clash.hip"]
     flags = [f for f in FLAGS if f != "-DPP_EDGE_F16"] + ([] if EDGE_F16 else ["-DPP_EDGE_F16"])
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h", ".inc"))]
-    if os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps):
+    if not needs_build(out, flags, sources):
         return out
-    hipcc = _hipcc()
-    objs = []
-    for src in sources:
-        obj = os.path.join(CSRC, src.replace(".hip", f".{tag}.o"))
-        cmd = [hipcc, *flags, "-c", os.path.join(CSRC, src), "-o", obj]
-        if verbose:
-            print(" ".join(cmd), flush=True)
-        subprocess.run(cmd, check=True)
-        objs.append(obj)
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, *objs]
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.run(cmd, check=True)
-    return out
+    return _compile_and_link(out, sources, flags, tag, verbose)
 
 
 def check_variant_path():
@@ -93,12 +117,8 @@ def check_variant_path():
 def build_check_variant(verbose=True):
     """``libpackppi_hip.chk.so``: the default kernels with -DPP_CHECK_RANGE (every value about to be split into f16 operands is
     compared with the f16 limit and counted; packppi_amd/rangecheck.py runs a checkpoint through it)."""
-    out = check_variant_path()
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h", ".inc"))]
-    if os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps):
-        return out
     os.environ.pop("PACKPPI_VARIANT_SOURCES", None)
-    return build_library(force=True, verbose=verbose, extra_flags=["-DPP_CHECK_RANGE"], tag="chk")
+    return build_library(verbose=verbose, extra_flags=["-DPP_CHECK_RANGE"], tag="chk")
 
 
 if __name__ == "__main__":

@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "pp_internal.h"
+#include "pp_topk_aten.h"
 #include <cstring>
 #include <cmath>
 #include <chrono>
@@ -17,7 +18,14 @@ static thread_local std::string g_err;
 void pp_set_error(const std::string &msg) { g_err = msg; }
 
 extern "C" const char *pp_last_error(void) { return g_err.c_str(); }
-extern "C" int pp_version(void) { return 100; }
+extern "C" int pp_version(void) { return 101; }
+// build stamp (packppi_amd/build.py passes -DPP_BUILD_ID="<sources>-<flags>"); the marker prefix lets build.py read it from
+// the file without loading the library
+#ifndef PP_BUILD_ID
+#define PP_BUILD_ID "unstamped-unstamped"
+#endif
+static const char g_build_id[] = "PP_BUILD_ID=" PP_BUILD_ID;
+extern "C" const char *pp_build_id(void) { return g_build_id + 12; }
 
 #define FAIL(code, msg)      \
     do {                     \
@@ -360,6 +368,7 @@ extern "C" pp_status pp_plan_create(const float *weights, size_t n_weights, cons
     p->device = device;
     p->off = off;
     p->has_network = has_net;
+    p->knn_ties = PP_KNN_TIES_ATEN_CPU;
     pp_status st;
     if (has_net) {
     if ((st = upload(&p->w, weights, off.total)) != PP_OK) return st;
@@ -448,6 +457,24 @@ extern "C" void pp_plan_destroy(pp_plan *p) {
         (void)hipFree(sl.p);
     }
     delete p;
+}
+
+extern "C" pp_status pp_plan_set_knn_ties(pp_plan *p, int mode) {
+    if (!p) FAIL(PP_ERR_INVALID, "pp_plan_set_knn_ties: null plan");
+    if (mode != PP_KNN_TIES_LOWER_INDEX && mode != PP_KNN_TIES_ATEN_CPU && mode != PP_KNN_TIES_ATEN_MEMBER)
+        FAIL(PP_ERR_INVALID, "pp_plan_set_knn_ties: unknown mode " + std::to_string(mode));
+    p->knn_ties = mode;
+    return PP_OK;
+}
+
+// torch.topk(values, k, largest=False) indices of ATen's CPU kernel (pp_topk_aten.h), on the host
+extern "C" pp_status pp_topk_aten_host(const float *values, int n, int k, int32_t *idx_out) {
+    if (!values || !idx_out || n < 1 || k < 1 || k > n) FAIL(PP_ERR_INVALID, "pp_topk_aten_host: bad argument");
+    std::vector<pp_tk_pair> q((size_t)n);
+    for (int j = 0; j < n; j++) { q[j].v = values[j]; q[j].i = j; }
+    pp_tk_topk_smallest(q.data(), n, k);
+    for (int j = 0; j < k; j++) idx_out[j] = q[j].i;
+    return PP_OK;
 }
 
 extern "C" pp_status pp_plan_set_clash_params(pp_plan *p, float tol, const float *lower, const float *upper, void *stream) {

@@ -76,6 +76,7 @@ struct pp_plan {
     std::vector<ArenaSlot> arena_pool;   // workspaces of destroyed contexts, reused by the next pp_complex_prepare
     std::mutex pool_mutex;
     bool has_network;         // false: geometry-only plan (atom14 / clash / proximal)
+    int knn_ties;             // PP_KNN_TIES_*: what the neighbour search does on exactly equal distances
     float *w;                 // device copy of all weights, original layouts
     WeightOff off;
     float *wT;                // device arena of transposed copies

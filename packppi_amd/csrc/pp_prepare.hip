@@ -3,6 +3,7 @@
 // :34-47 (relpos), :120-153 (RBF), :164-196 (inter-residue dihedrals), :243-244 (embedding),
 // rigid_utils.py:1127-1179 (frames).
 #include "pp_internal.h"
+#include "pp_topk_aten.h"
 
 #define KNN_THREADS 256
 
@@ -53,17 +54,24 @@ __global__ void k_frames(const float *__restrict__ X, int N, float *__restrict__
 }
 
 // ---------------------------------------------------------------------------------------------
-// kNN: one block per residue row; K rounds of (value, index)-lexicographic arg-min.
+// kNN: one block per residue row; K rounds of (value, index)-lexicographic arg-min over the row's adjusted distances
+// (encoder.py:105-118), then -- `ties` != PP_KNN_TIES_LOWER_INDEX -- the reference CPU path's own choice where values are
+// exactly equal: torch.topk's selection depends on libstdc++'s nth_element / sort running over the whole row
+// (pp_topk_aten.h), so a row that has two equal values among its K + 1 smallest (PP_KNN_TIES_ATEN_CPU; only rank K = rank
+// K + 1, a MEMBERSHIP tie, in PP_KNN_TIES_ATEN_MEMBER) is redone by one lane running exactly that code on the row in LDS.
+// Rows without such a tie have one possible answer and never pay for it.
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(KNN_THREADS)
-k_knn(const float *__restrict__ X, const float *__restrict__ rmask, const int2 *__restrict__ seg, int K,
+k_knn(const float *__restrict__ X, const float *__restrict__ rmask, const int2 *__restrict__ seg, int K, int ties,
       int32_t *__restrict__ eidx, float *__restrict__ mask_att) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float *d = reinterpret_cast<float *>(smem_raw);            // [L]
+    pp_tk_pair *q = reinterpret_cast<pp_tk_pair *>(smem_raw);   // [L] (adjusted distance, index in the complex)
     __shared__ float red_v[KNN_THREADS / 64];
     __shared__ int red_i[KNN_THREADS / 64];
     __shared__ float s_max;
-    __shared__ int s_pick;
+    __shared__ float pick_v[33];
+    __shared__ int pick_i[33];
+    __shared__ int s_tie;
     const int n = blockIdx.x;
     const int row0 = seg[n].x, L = seg[n].y;          // this row's complex: rows row0 .. row0 + L - 1
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -75,11 +83,13 @@ k_knn(const float *__restrict__ X, const float *__restrict__ rmask, const int2 *
         const float *ca_j = X + (size_t)(row0 + j) * 42 + 3;
         float m2 = mi * rmask[row0 + j];
         float v = m2 * dist_eps(ca_j, ci, 1e-6f);
-        d[j] = v;
+        q[j].v = v;
+        q[j].i = j;
         lmax = fmaxf(lmax, v);
     }
     for (int o = 32; o > 0; o >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, o));
     if (lane == 0) red_v[wid] = lmax;
+    if (tid == 0) s_tie = 0;
     __syncthreads();
     if (tid == 0) {
         float m = red_v[0];
@@ -90,14 +100,16 @@ k_knn(const float *__restrict__ X, const float *__restrict__ rmask, const int2 *
     const float dmax = s_max;
     for (int j = tid; j < L; j += KNN_THREADS) {
         float m2 = mi * rmask[row0 + j];
-        d[j] = d[j] + (2.f * (1.f - m2)) * dmax;
+        q[j].v = q[j].v + (2.f * (1.f - m2)) * dmax;
     }
     __syncthreads();
-    for (int k = 0; k < K; k++) {
+    // round K (when the complex has more than K residues) only looks at the next value: is rank K + 1 equal to rank K?
+    const int rounds = K + ((ties != PP_KNN_TIES_LOWER_INDEX && L > K) ? 1 : 0);
+    for (int k = 0; k < rounds; k++) {
         float bv = INFINITY;
         int bi = 0x7fffffff;
         for (int j = tid; j < L; j += KNN_THREADS) {
-            float v = d[j];
+            float v = q[j].v;
             if (v < bv) { bv = v; bi = j; }      // strided scan keeps the lowest j among equal values
         }
         for (int o = 32; o > 0; o >>= 1) {
@@ -112,14 +124,36 @@ k_knn(const float *__restrict__ X, const float *__restrict__ rmask, const int2 *
             int ix = red_i[0];
             for (int w = 1; w < KNN_THREADS / 64; w++)
                 if (red_v[w] < v || (red_v[w] == v && red_i[w] < ix)) { v = red_v[w]; ix = red_i[w]; }
-            s_pick = ix;
-            d[ix] = INFINITY;
-            eidx[(size_t)n * K + k] = row0 + ix;
-            mask_att[(size_t)n * 32 + k] = mi * rmask[row0 + ix];
+            pick_v[k] = v;
+            pick_i[k] = ix;
+            if (k > 0 && v == pick_v[k - 1]) s_tie |= (k == K) ? 2 : 1;
+            if (k < K) {
+                if (ix < L) {
+                    q[ix].v = INFINITY;
+                    eidx[(size_t)n * K + k] = row0 + ix;
+                    mask_att[(size_t)n * 32 + k] = mi * rmask[row0 + ix];
+                } else {
+                    // nothing finite left (a segment shorter than K, or NaN coordinates): the row itself, masked out
+                    eidx[(size_t)n * K + k] = n;
+                    mask_att[(size_t)n * 32 + k] = 0.f;
+                }
+            }
         }
         __syncthreads();
     }
     if (tid < 32 && tid >= K) mask_att[(size_t)n * 32 + tid] = 0.f;
+    const int want = ties == PP_KNN_TIES_ATEN_CPU ? 3 : (ties == PP_KNN_TIES_ATEN_MEMBER ? 2 : 0);
+    if (!(s_tie & want) || mi == 0.f) return;       // (a masked row's list is never used: mask_att is 0 throughout)
+    if (tid == 0) {
+        for (int k = 0; k < K; k++)
+            if (pick_i[k] < L) q[pick_i[k]].v = pick_v[k];      // the row as it was before the rounds
+        pp_tk_topk_smallest(q, L, K);
+        for (int k = 0; k < K; k++) {
+            const int ix = q[k].i;
+            eidx[(size_t)n * K + k] = row0 + ix;
+            mask_att[(size_t)n * 32 + k] = mi * rmask[row0 + ix];
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -248,13 +282,13 @@ pp_status pp_launch_prepare(pp_ctx *c, hipStream_t s, const int64_t *E_idx) {
                            c->eidx, c->mask_att, reinterpret_cast<int *>(c->scal));
     } else {
     hipLaunchKernelGGL(k_frames, dim3((N + 127) / 128), dim3(128), 0, s, c->b.X, N, c->frames, c->bbpos);
-    size_t smem = (size_t)c->L * sizeof(float);       // L = the longest complex of the context
+    size_t smem = (size_t)c->L * sizeof(pp_tk_pair);  // L = the longest complex of the context
     if (smem > 64 * 1024) {
         PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_knn),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     }
     hipLaunchKernelGGL(k_knn, dim3(N), dim3(KNN_THREADS), smem, s, c->b.X, c->b.residue_mask, c->seg, c->K,
-                       c->eidx, c->mask_att);
+                       c->plan->knn_ties, c->eidx, c->mask_att);
     }
 #ifdef PP_EDGE_F16
     return pp_launch_edge_embed_f16(c, s);      // MFMA form (pp_edge_f16.hip); k_edge_embed below is the fp32 build's

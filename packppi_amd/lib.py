@@ -15,9 +15,12 @@ from .weights import check_state_dict
 _LIB_PATH = os.environ.get("PACKPPI_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libpackppi_hip.so")     # PACKPPI_LIB: A/B runs of build variants
 _lib = None
 
-SYMBOLS = ("pp_version", "pp_last_error", "pp_plan_create", "pp_plan_destroy", "pp_plan_set_clash_params",
+SYMBOLS = ("pp_version", "pp_last_error", "pp_build_id", "pp_plan_set_knn_ties", "pp_topk_aten_host", "pp_plan_create", "pp_plan_destroy", "pp_plan_set_clash_params",
            "pp_complex_prepare", "pp_complex_prepare_packed", "pp_ctx_destroy", "pp_ctx_get_graph", "pp_ctx_set_graph", "pp_score", "pp_sample", "pp_atom14",
            "pp_clash", "pp_proximal", "pp_time_kernel", "pp_profile_kernel", "pp_profile_read", "pp_edge_variant", "pp_has_range_check", "pp_range_check")
+
+
+KNN_TIES = {"lower_index": 0, "aten_cpu": 1, "aten_member": 2}
 
 
 class PPTables(C.Structure):
@@ -43,6 +46,17 @@ def load():
                            "(hipcc --offload-arch=gfx950); there is no CPU fallback")
     lib = C.CDLL(_LIB_PATH)
     vp, f, i = C.c_void_p, C.c_float, C.c_int
+    lib.pp_build_id.restype = C.c_char_p
+    # a prebuilt library must come from the sources on disk (content hash, packppi_amd/build.py); PACKPPI_LIB variants differ
+    # in flags only, so the <sources> half of the stamp is what is compared
+    if not os.environ.get("PACKPPI_SKIP_BUILD_CHECK"):
+        from .build import source_hash
+        have, want = lib.pp_build_id().decode().split("-")[0], source_hash()
+        if have != want:
+            raise RuntimeError(f"{_LIB_PATH} is stale: built from sources {have}, csrc/ is now {want}; rebuild with "
+                               "`python -m packppi_amd.build` (or `python __graft_entry__.py`)")
+    lib.pp_plan_set_knn_ties.argtypes = [vp, i]
+    lib.pp_topk_aten_host.argtypes = [vp, i, i, vp]
     lib.pp_version.restype = C.c_int
     lib.pp_last_error.restype = C.c_char_p
     lib.pp_plan_create.argtypes = [vp, C.c_size_t, C.POINTER(PPTables), i, C.POINTER(vp)]
@@ -113,6 +127,17 @@ class Plan:
         _check(lib.pp_plan_create(wptr, wn, C.byref(tab), self.device.index, C.byref(h)), "pp_plan_create")
         self.handle = h
         self._clash_params = None
+        self.knn_ties = "aten_cpu"
+        if os.environ.get("PACKPPI_KNN_TIES"):
+            self.set_knn_ties(os.environ["PACKPPI_KNN_TIES"])
+
+    def set_knn_ties(self, mode):
+        """What the neighbour search does on exactly equal CA distances: "aten_cpu" (default: the reference CPU path's
+        torch.topk choice and order), "aten_member" (that choice only where membership depends on it) or "lower_index"."""
+        if mode not in KNN_TIES:
+            raise ValueError(f"knn ties mode must be one of {sorted(KNN_TIES)}")
+        _check(load().pp_plan_set_knn_ties(self.handle, KNN_TIES[mode]), "pp_plan_set_knn_ties")
+        self.knn_ties = mode
 
     def set_clash_params(self, vtf, tol):
         key = (float(vtf), float(tol))
@@ -165,9 +190,12 @@ class Context:
         if seg is None:
             _check(lib.pp_complex_prepare(plan.handle, C.byref(pb), _stream(dev), C.byref(h)), "pp_complex_prepare")
         else:
-            # ragged batch without padding rows (batch.pack): [1, sum of lengths, ...] + the complexes' first rows
-            lens = (seg[1:] - seg[:-1]).tolist()
-            if self.B != 1 or int(seg[-1]) != self.L or int(seg[0]) != 0 or min(lens) < 1:
+            # ragged batch without padding rows (batch.pack): [1, sum of lengths, ...] + the complexes' first rows; the host
+            # copy of the table that pack() carries along saves the read-back
+            host = batch.get("seg_offsets_host") if hasattr(batch, "get") else getattr(batch, "seg_offsets_host", None)
+            offs = [int(x) for x in (host if host is not None else seg.tolist())]
+            lens = [b - a for a, b in zip(offs[:-1], offs[1:])]
+            if self.B != 1 or len(offs) < 2 or offs[-1] != self.L or offs[0] != 0 or min(lens) < 1:
                 raise RuntimeError("seg_offsets does not describe this batch")
             self._t["seg_offsets"] = seg.to(device=dev, dtype=torch.int32).contiguous()
             self.K = min(32, min(lens))

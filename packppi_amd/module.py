@@ -85,7 +85,7 @@ class TDiffusionModule:
     eps = 1e-6
 
     def __init__(self, state_dict: Dict[str, torch.Tensor], sample_cfg: Any = None, encoder_cfg: Any = None,
-                 model_cfg: Any = None, device="cuda", **kwargs):
+                 model_cfg: Any = None, device="cuda", knn_ties: Optional[str] = None, **kwargs):
         self._state_dict = {k: v.detach().float().cpu() for k, v in state_dict.items()}
         self.hparams = SimpleNamespace(sample_cfg=_cfg(sample_cfg, SAMPLE_DEFAULTS), encoder_cfg=encoder_cfg,
                                        model_cfg=model_cfg)
@@ -95,6 +95,7 @@ class TDiffusionModule:
         self.device = torch.device("cpu")
         self._plan: Optional[Plan] = None
         self._ctx_key, self._ctx = None, None
+        self._knn_ties = knn_ties         # None: the library default (the reference CPU path's torch.topk choice)
         self.to(device)
 
     # ---- construction ----------------------------------------------------------------------
@@ -112,6 +113,8 @@ class TDiffusionModule:
             device = torch.device("cuda", torch.cuda.current_device())
         if self._plan is None or self._plan.device != device:
             self._plan = Plan(self._state_dict, device)
+            if self._knn_ties is not None:
+                self._plan.set_knn_ties(self._knn_ties)
             self._ctx_key, self._ctx = None, None
         self.device = device
         return self

@@ -74,8 +74,11 @@ def sample_sharded(model, complexes, use_proximal=False, group=None, init_chi=No
     cfg = model.hparams.sample_cfg
     groups, cur, rows_in = [], [], 0
     for i in mine:
-        n = int(complexes[i]["residue_mask"].sum())
-        if n < 32:
+        rm = complexes[i]["residue_mask"].reshape(-1) > 0
+        n = int(complexes[i]["max_size"])
+        # K = min(32, L) is a property of the batch (encoder.py:115): a complex that is shorter than 32 rows once its trailing
+        # padding is dropped goes through the plain B = 1 path with its own tensors, as the reference would run it
+        if int(rm.sum()) < 32 or n < 32:
             groups.append([i])
             continue
         if cur and rows_in + n > max_rows:
@@ -87,9 +90,16 @@ def sample_sharded(model, complexes, use_proximal=False, group=None, init_chi=No
         groups.append(cur)
     chis = {}
     for grp in groups:
+        if len(grp) == 1:
+            i = grp[0]
+            if init_chi is not None:
+                chis[i] = model.sample_from(complexes[i], init_chi[i].to(model.device))
+            else:
+                chis[i] = model.sampling(complexes[i])
+            continue
         pb = pack([complexes[i] for i in grp])
         if init_chi is not None:
-            offs = pb["seg_offsets"].tolist()
+            offs = pb["seg_offsets_host"]
             x0 = torch.cat([init_chi[i][:, :b - a] for i, a, b in zip(grp, offs[:-1], offs[1:])], 1).to(model.device)
             out = model.sample_from(pb, x0)
         else:

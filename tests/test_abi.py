@@ -33,6 +33,29 @@ def test_library_exports_every_declared_symbol(lib_path):
     assert lib.pp_version() >= 100
 
 
+def test_build_stamp_matches_the_sources_on_disk(lib_path, monkeypatch):
+    """pp_build_id() = hash of csrc/*.hip|*.h + the public header, and of the flags, taken when the library was compiled:
+    build() rebuilds on a mismatch (content, not mtime) and the binding refuses a stale prebuilt library."""
+    from packppi_amd import build, lib as L
+    lib = ctypes.CDLL(lib_path)
+    lib.pp_build_id.restype = ctypes.c_char_p
+    stamp = lib.pp_build_id().decode()
+    assert re.fullmatch(r"[0-9a-f]{16}-[0-9a-f]{16}", stamp)
+    assert stamp == build.build_id(build.FLAGS, build.SOURCES) == build.embedded_build_id(lib_path)
+    assert not build.needs_build()
+    for other in (build.other_variant_path(), build.check_variant_path()):      # variants: same sources, other flags
+        if os.path.exists(other):
+            assert build.embedded_build_id(other).split("-")[0] == build.source_hash()
+            assert build.embedded_build_id(other) != stamp
+    monkeypatch.setattr(build, "source_hash", lambda: "0" * 16)                  # "the sources changed"
+    assert build.needs_build()
+    monkeypatch.setattr(L, "_lib", None)
+    with pytest.raises(RuntimeError, match="stale"):
+        L.load()
+    monkeypatch.setenv("PACKPPI_SKIP_BUILD_CHECK", "1")
+    assert L.load() is not None
+
+
 def test_plan_create_without_gpu_reports_error(lib_path):
     import torch
     if torch.cuda.is_available():

@@ -186,6 +186,17 @@ def test_pack_unpack_roundtrip():
     assert torch.equal(pack(split(collate(ds))).X, pb.X)
     with pytest.raises(ValueError):
         pack([collate(ds)])
+    assert pb.seg_offsets_host == [0, 40, 73, 130]
+    # a residue masked out in the middle of a chain (missing backbone atom: featurize.py) keeps its row and its mask;
+    # only trailing padding is dropped
+    holes = [protein_to_batch(synth.make_complex(n, 3 + n)) for n in (40, 33)]
+    holes[0].residue_mask[0, 11] = 0.0
+    padded = split(collate([protein_to_data(synth.make_complex(n, 3 + n)) for n in (40, 33)]))
+    padded[0].residue_mask[0, 11] = 0.0
+    for src in (holes, padded):
+        ph = pack(src)
+        assert ph.seg_offsets_host == [0, 40, 73] and ph.residue_mask[0, 11] == 0 and ph.residue_mask.sum() == 72
+        assert torch.equal(ph.X, pack(ds[:2]).X)
 
 
 def test_add_sc_noise_matches_reference_draw():

@@ -70,7 +70,7 @@ class _FakeModel:
 
     def sample_from(self, batch, x0, sde_noise=None):
         assert batch.num_proteins == 1 and x0.shape == (1, batch.max_size, 4)
-        self.packed_shapes.append((int(batch.max_size), batch.seg_offsets.tolist()))
+        self.packed_shapes.append((int(batch.max_size), batch.get("seg_offsets_host") or [0, int(batch.max_size)]))
         return 0.5 * x0 + batch.residue_type[..., None].float() * 0.01
 
     def analyze_samples(self, batch, chi):
@@ -89,6 +89,7 @@ def _sharded_worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     lens = [40, 20, 57, 33, 64]                      # the 20-residue complex (K = 20) must go alone
     cs = [protein_to_batch(synth.make_complex(n, 50 + n)) for n in lens]
+    cs[2].residue_mask[0, 17] = 0.0                  # a residue masked out mid-chain (missing backbone atom) stays in place
     g = torch.Generator().manual_seed(1)
     init = {i: torch.rand(1, n, 4, generator=g) for i, n in enumerate(lens)}
     model = _FakeModel()

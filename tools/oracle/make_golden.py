@@ -88,13 +88,15 @@ def save(name, **arrs):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
+    ap.add_argument("--g7-blocks", default="0,1,2,3,4,5,6,7")
+    ap.add_argument("--threads", type=int, default=8)
     args = ap.parse_args()
     only = set(args.only.split(",")) if args.only else None
 
     def want(tag):
         return only is None or tag in only
 
-    torch.set_num_threads(8)
+    torch.set_num_threads(args.threads)
     model = refshim.build_reference_module(0)
     sd = make_random_state_dict(WEIGHT_SEED)
     model.load_state_dict(sd, strict=True)
@@ -229,19 +231,38 @@ def main():
         print(f"  S1500 ode 100 steps {time.time() - t0:.1f}s", flush=True)
         save("g5_S1500", **out)
 
-    # ---- g7: the first GPU's share of BASELINE config 4 (32 of the 256 synthetic ~300-residue complexes), 100 steps each ------
+    # ---- g7: BASELINE config 4 (256 synthetic ~300-residue complexes), 100 steps each, in blocks of 32 complexes
+    # (g7_c5_rank{r} = complexes 32r .. 32r+31; keys carry the GLOBAL complex id).  --g7-blocks picks the blocks.
+    # For every complex whose CA-distance rows hold an exact tie among the K+1 smallest values, the reference's own neighbour
+    # lists (torch.topk on CPU, encoder.py:105-118) are stored too: E_idx_{i} int16 [L][K], tie_rows_{i}. --------------------
     if want("g7"):
         lens = synth.c5_lengths(256)
-        out = {"lengths": np.array(lens[:32], np.int64)}
-        t0 = time.time()
-        for i in range(32):
-            b = synth_batch(lens[i], 10000 + i)
-            rb = ref_batch(b)
-            init = seeded_init(model, rb, 20000 + i)
-            out[f"init_{i}"] = init
-            out[f"chi_ode_100_{i}"] = run_sampling(model, rb, init, 100)
-            print(f"  c5[{i}] L={lens[i]} {time.time() - t0:.0f}s", flush=True)
-        save("g7_c5_rank0", **out)
+        for blk in [int(x) for x in args.g7_blocks.split(",")]:
+            ids = list(range(32 * blk, 32 * blk + 32))
+            out = {"lengths": np.array([lens[i] for i in ids], np.int64), "ids": np.array(ids, np.int64)}
+            t0 = time.time()
+            for i in ids:
+                b = synth_batch(lens[i], 10000 + i)
+                rb = ref_batch(b)
+                init = seeded_init(model, rb, 20000 + i)
+                out[f"init_{i}"] = init
+                out[f"chi_ode_100_{i}"] = run_sampling(model, rb, init, 100)
+                with torch.no_grad():
+                    Dn, E_idx, _ = model.encoder._dist(rb.X[:, :, 1, :], rb.residue_mask)
+                    # the K+1 smallest values of every row: any two equal -> order or membership is the topk's choice
+                    X = rb.X[:, :, 1, :]
+                    m2 = rb.residue_mask[:, None, :] * rb.residue_mask[:, :, None]
+                    D = m2 * torch.sqrt(((X[:, None] - X[:, :, None]) ** 2).sum(3) + 1e-6)
+                    Dadj = D + 2 * (1. - m2) * D.max(-1, keepdim=True)[0]
+                    srt = torch.sort(Dadj, -1)[0][0, :, :33]
+                    rows = torch.nonzero((srt[:, 1:] == srt[:, :-1]).any(-1)).flatten()
+                if len(rows):
+                    out[f"E_idx_{i}"] = E_idx[0].to(torch.int16)
+                    out[f"tie_rows_{i}"] = rows.to(torch.int16)
+                    member = [int(r) for r in rows if srt[r, 31] == srt[r, 32]]
+                    print(f"  c5[{i}] tie rows {rows.tolist()} (membership: {member})", flush=True)
+                print(f"  c5[{i}] L={lens[i]} {time.time() - t0:.0f}s", flush=True)
+            save(f"g7_c5_rank{blk}", **out)
 
     # ---- g3p: proximal optimiser ------------------------------------------------------------------
     if want("g3p"):
