@@ -64,13 +64,34 @@ def load_s1500():
     return _load_fixture("g5_S1500", "init_chi_seed1500")
 
 
-def c5_complexes(rank, dev):
-    """This rank's 32 of BASELINE config 4's 256 synthetic complexes (L ~ U{270..330}, default_rng(256), seeds 10000 + i)."""
+def c5_share(rank, world, dev):
+    """BASELINE config 4: the 256 synthetic complexes (L ~ U{270..330}, default_rng(256), seeds 10000 + i) dealt to `world`
+    ranks by parallel.shard_complexes (longest first); returns (lengths of all 256, {complex id: batch} of THIS rank's share)."""
     from packppi_amd import synth
     from packppi_amd.featurize import protein_to_batch
+    from packppi_amd.parallel import shard_complexes
     lens = synth.c5_lengths(256)
-    ids = [(rank * 32 + k) % 256 for k in range(32)]
-    return [protein_to_batch(synth.make_complex(lens[i], 10000 + i)).to(dev) for i in ids]
+    mine = shard_complexes(lens, world)[rank]
+    return lens, {i: protein_to_batch(synth.make_complex(lens[i], 10000 + i)).to(dev) for i in mine}
+
+
+def c5_complexes(rank, dev):
+    """One GPU's share of config 4 when it runs on 8 GPUs (32 complexes), as a list (tools/, tests)."""
+    return list(c5_share(rank % 8, 8, dev)[1].values())
+
+
+def c5_inits(share, seed):
+    g = torch.Generator().manual_seed(seed)
+    return {i: (torch.rand(1, int(c["max_size"]), 4, generator=g) * 2 - 1) * np.pi * c.SC_D_mask.cpu() for i, c in share.items()}
+
+
+def reference_container_rates():
+    """The UNMODIFIED reference timed in the build container (tools/oracle/time_reference.py; the reference cannot travel to the
+    GPU box): its rate under torch.no_grad and as eval_diffusion.py:62 calls it, with host, cores and date.  None if absent."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "reference_cpu_rates.json")))
+    except (OSError, ValueError):
+        return None
 
 
 def cpu_baseline(batch, init, weights, n_sample_steps, n_grad_steps):
@@ -101,9 +122,14 @@ def cpu_baseline(batch, init, weights, n_sample_steps, n_grad_steps):
         for j in range(n_grad_steps):
             x = O.sampling(wg, batch, x, sched[j: j + 2], hoist=False).detach()   # the reference's step() is @no_grad
         dtg = time.perf_counter() - t0
-        out["as_shipped"] = {"value": res / (dtg / n_grad_steps * N_DIFFUSION_STEPS), "unit": "residues/s",
+        out["as_shipped"] = {"value": res / (dtg / n_grad_steps * N_DIFFUSION_STEPS), "unit": "residues/s", "kind": "port",
                              "sample": f"{n_grad_steps} steps with autograd recording (eval_diffusion.py:62 calls sampling() "
-                                       f"without torch.no_grad); {dtg:.1f} s measured, scaled x{N_DIFFUSION_STEPS / n_grad_steps:g}"}
+                                       f"without torch.no_grad); {dtg:.1f} s measured, scaled x{N_DIFFUSION_STEPS / n_grad_steps:g}",
+                             "note": "the PORT loses nothing to autograd; the reference itself does (its per-step graph rebuild "
+                                     "keeps every L x L intermediate alive): see reference_in_build_container"}
+    ref = reference_container_rates()
+    if ref is not None:
+        out["reference_in_build_container"] = ref      # kind "reference", measured where the reference can run
     return out
 
 
@@ -176,20 +202,24 @@ def main():
     model.schedule = torch.linspace(1, 0, N_DIFFUSION_STEPS + 1)
     ref_chi, complexes = None, None
     if args.workload == "c5":
-        complexes = c5_complexes(rank, dev)
-        residues = sum(c.true_residues() for c in complexes)
-        name = "32 synthetic complexes L~U{270..330} per GPU (default_rng(256)), one packed ragged batch"
-        g = torch.Generator().manual_seed(1000 + rank)
-        inits = {i: (torch.rand(1, int(c["max_size"]), 4, generator=g) * 2 - 1) * np.pi * c.SC_D_mask.cpu()
-                 for i, c in enumerate(complexes)}
-
-        # the initial noised angles of the packed rows: resident on the device before the timed region, like the batch
-        x0_packed = torch.cat([inits[i][:, : c.true_residues()] for i, c in enumerate(complexes)], 1).to(dev)
+        # BASELINE configs[4] as stated: ALL 256 complexes, dealt to the N ranks by parallel.shard_complexes, every rank runs
+        # parallel.sample_sharded end to end on its share (packing, preparation, 100 evaluations, per-complex metrics) and the
+        # metric rows of all 256 complexes are all-gathered (RCCL): total work is fixed -> "strong" scaling
+        from packppi_amd.parallel import sample_sharded
+        c5_lens, complexes = c5_share(rank, world, dev)
+        residues = sum(c.true_residues() for c in complexes.values())
+        name = ("256 synthetic complexes L~U{270..330} (default_rng(256)) sharded over the GPUs by parallel.shard_complexes, "
+                "packed ragged batches, per-complex metrics + all-gather of the metric rows inside the timed pass")
+        inits = c5_inits(complexes, 1000 + rank)
+        inits = {i: v.to(dev) for i, v in inits.items()}        # resident before the timed region, like the batch
+        if args.proximal:
+            raise SystemExit("--proximal with --workload c5: use the per-complex workloads")
+        c5_last = {}
 
         def one_pass():
-            if args.proximal:
-                raise SystemExit("--proximal with --workload c5: use the per-complex workloads")
-            return sample_sharded_local(model, complexes, x0_packed)
+            chis, ids_all, rows_all = sample_sharded(model, complexes, init_chi=inits, lengths=c5_lens)
+            c5_last["ids"], c5_last["rows"] = ids_all, rows_all
+            return chis
     else:
         batch, init, ref_chi = load_t1124() if args.workload == "t1124" else load_s1500()
         name = {"t1124": "data/T1124_lig.pdb (L=739, 738 true residues), 1 complex per GPU",
@@ -245,17 +275,21 @@ def main():
         m = model.analyze_samples(gb, chi)
         row = torch.stack([torch.as_tensor(float(v), device=dev) for v in m.values()]).float()
         atom_rmsd = float(m["atom_rmsd"])
+        rows = [row]
+        if dist is not None:
+            rows = [torch.empty_like(row) for _ in range(world)]
+            dist.all_gather(rows, row)
+        ranks_seen, rows_gathered = len(rows), len(rows)
     else:
-        from packppi_amd.batch import pack, unpack
-        from packppi_amd.parallel import metrics_to_row
-        first = unpack(pack(complexes), chi)[0]
-        m = model.analyze_samples(complexes[0], first)
-        row, atom_rmsd = metrics_to_row(m).to(dev), float(m["atom_rmsd"])
-    rows = [row]
-    if dist is not None:
-        rows = [torch.empty_like(row) for _ in range(world)]
-        dist.all_gather(rows, row)
-    ranks_seen = len(rows)
+        from packppi_amd.parallel import METRIC_KEYS
+        # the gather happened inside every timed pass (parallel.gather_metric_rows): all 256 rows are on every rank
+        rows_gathered = int(c5_last["ids"].numel())
+        assert c5_last["ids"].tolist() == list(range(256)) and bool(torch.isfinite(c5_last["rows"]).all())
+        atom_rmsd = float(c5_last["rows"][:, METRIC_KEYS.index("atom_rmsd")].mean())
+        cnt = torch.tensor([1.0], device=dev)
+        if dist is not None:
+            dist.all_reduce(cnt)
+        ranks_seen = int(cnt.item())
     max_dchi = None
     if ref_chi is not None and not args.proximal:
         d = (chi.cpu().double() - ref_chi.double()).abs()
@@ -265,17 +299,19 @@ def main():
     # secondary figure: BASELINE configs[4]'s per-GPU share through the packed multi-complex path
     secondary = None
     if complexes is None and not args.no_secondary and not args.proximal:
-        c5 = c5_complexes(rank, dev)
-        g = torch.Generator().manual_seed(1000 + rank)
-        c5_init = {i: (torch.rand(1, int(c["max_size"]), 4, generator=g) * 2 - 1) * np.pi * c.SC_D_mask.cpu()
-                   for i, c in enumerate(c5)}
-        c5_x0 = torch.cat([c5_init[i][:, : c.true_residues()] for i, c in enumerate(c5)], 1).to(dev)
+        # one GPU's share of configs[4] when it runs on 8 GPUs: rank r takes shard (r mod 8) of parallel.shard_complexes(256
+        # lengths, 8) and runs the sampling part of parallel.sample_sharded on it (one packed ragged batch)
+        _, share = c5_share(rank % 8, 8, dev)
+        c5 = list(share.values())
+        c5_init = c5_inits(share, 1000 + rank)
+        c5_x0 = torch.cat([c5_init[i][:, : c.true_residues()] for i, c in share.items()], 1).to(dev)
         el5, _ = timed(lambda: sample_sharded_local(model, c5, c5_x0), 3, 1)
         res5 = allsum(sum(c.true_residues() for c in c5))
-        secondary = {"workload": "BASELINE configs[4] share: 32 synthetic complexes L~U{270..330} per GPU as one packed ragged "
-                                 "batch (no padding rows), 100 steps, no proximal",
+        secondary = {"workload": "BASELINE configs[4], one GPU's share at 8 GPUs (parallel.shard_complexes(256 lengths, 8)[rank mod 8]: "
+                                 "32 synthetic complexes L~U{270..330}) as one packed ragged batch (no padding rows), 100 steps, no "
+                                 "proximal; the whole 256-complex job incl. metrics and gather: --workload c5",
                      "value": res5 * 3 / el5, "unit": "residues/s", "ms_per_step": el5 / 3 * 1e3, "residues": res5,
-                     "complexes": 32 * world}
+                     "complexes": len(c5) * world}
 
     # kernel roofline, measured live: one more pass of the same workload in which every launch of the kernel carries a
     # start / stop HIP event pair on the launch stream (pp_profile_kernel -> hipExtLaunchKernelGGL: the dispatch's own
@@ -353,15 +389,18 @@ def main():
             "unit": "residues/s",
             "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if args.workload == "c5" else "weak", "vs_baseline": None,
             "dtype": "f32 (dense layers as split-f16: two f16 per operand, three f16 MFMAs per product, fp32 accumulate)",
             "data": "synthetic (seeded random weights; T1124 backbone fixture, seeded initial noise)"
             if args.workload == "t1124" else "synthetic",
             "config": {"workload": name, "diffusion_steps": N_DIFFUSION_STEPS, "proximal": bool(args.proximal),
-                       "residues_per_gpu": residues, "mode": "ode"},
+                       "residues_per_gpu": residues, "residues_rank0": residues, "mode": "ode"},
             "parity": {"max_abs_dchi_vs_reference_rad": max_dchi, "atom_rmsd": atom_rmsd},
-            "ranks_seen": ranks_seen, "metrics_rows_gathered": ranks_seen,
+            "ranks_seen": ranks_seen, "metrics_rows_gathered": rows_gathered,
         }
+        if complexes is not None:
+            out["config"]["complexes_total"] = 256
+            out["config"]["complexes_this_rank"] = len(complexes)
         if roof is not None:
             out["dtype"] = dtype
             out["roofline"] = roof

@@ -195,6 +195,15 @@ int pp_edge_variant(void);
  * PP_ERR_UNSUPPORTED.  (pp_plan_create rejects weights that are not finite or outside the f16 range in every build.) */
 int pp_has_range_check(void);
 pp_status pp_range_check(unsigned long long *events, int reset);
+/* The same count by kernel family: the edge-level kernels (which the PACKPPI_EDGE=f32 build replaces by exact-fp32 ones)
+ * and the node-level kernels (split f16 in every build: there is no fp32 variant of them). */
+pp_status pp_range_check_parts(unsigned long long *edge_events, unsigned long long *node_events, int reset);
+
+/* Sticky saturation flag, every build (no reference counterpart).  The default kernels clamp hidden activations at the f16
+ * maximum before splitting them; a context remembers that it happened: *flags bit 0 = in an edge-level kernel, bit 1 = in a
+ * node-level kernel, 0 = never since pp_complex_prepare.  The call waits for `stream`.  A set bit means results of this
+ * context are not fp32-equivalent for this checkpoint (run python -m packppi_amd.rangecheck for the details). */
+pp_status pp_ctx_saturated(pp_ctx *ctx, int *flags, void *stream);
 
 /* The library also exports a few undocumented pp_debug_* entry points (single-kernel launches and internal-buffer
  * copies) used only by tools/debug/ to test kernels for run-to-run reproducibility.  They are not part of the

@@ -97,16 +97,22 @@ def pack(complexes: Iterable[Batch]) -> Batch:
     tensors [L, ...]) or B = 1 batches ([1, L, ...]).  Only TRAILING padding is dropped: a complex keeps its rows up to the
     last true residue, so a residue masked out in the middle of a chain (a missing backbone atom: featurize.py) stays in
     place with its ``residue_mask`` 0, exactly as the reference carries it."""
+    complexes = list(complexes)
     rows = {k: [] for k in TENSOR_KEYS}
     offs = [0]
+    ends = []
     for c in complexes:
         lead = c["residue_type"].dim() == 2
         if lead and c["residue_type"].shape[0] != 1:
             raise ValueError("pack() takes single complexes (use split() on a padded batch first)")
-        keep = ((c["residue_mask"][0] if lead else c["residue_mask"]) > 0).cpu()
-        if not bool(keep.any()):
+        keep = (c["residue_mask"][0] if lead else c["residue_mask"]) > 0
+        # index of the last true residue + 1 (0 for an empty complex), computed where the mask lives
+        ends.append((keep * torch.arange(1, keep.numel() + 1, device=keep.device)).max())
+    ends = [int(x) for x in torch.stack(ends).tolist()]            # ONE read-back for the whole batch
+    for c, n in zip(complexes, ends):
+        if n == 0:
             raise ValueError("empty complex")
-        n = int(torch.nonzero(keep).max()) + 1
+        lead = c["residue_type"].dim() == 2
         for k in TENSOR_KEYS:
             t = c[k][0] if lead else c[k]
             rows[k].append(t[:n])

@@ -39,6 +39,10 @@ def evaluate_model(model, args):
     if args.seed is not None:
         torch.manual_seed(args.seed)
     SC_D_sample = model.sampling(batch, use_proximal=args.use_proximal)
+    if model.saturated():
+        # a hidden activation reached the f16 maximum in the split-f16 dense layers: not the reference's arithmetic any more
+        print("----- WARNING: f16 saturation in the score network (flag %d); run `python -m packppi_amd.rangecheck` on this "
+              "checkpoint -----" % model.saturated())
     xyz = get_atom14_coords(batch.X, batch.residue_type, batch.BB_D, SC_D_sample)
     protein["atom_positions"] = xyz.cpu().squeeze(0).numpy()
     with open(analysis.tmp_pdb, "w") as fh:

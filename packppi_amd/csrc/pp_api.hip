@@ -328,6 +328,29 @@ extern "C" int pp_has_range_check(void) {
     return 0;
 #endif
 }
+extern "C" pp_status pp_range_check_parts(unsigned long long *edge_events, unsigned long long *node_events, int reset) {
+    if (!edge_events || !node_events) FAIL(PP_ERR_INVALID, "pp_range_check_parts: null argument");
+#ifdef PP_CHECK_RANGE
+    PP_HIP_CHECK(hipDeviceSynchronize());
+    *edge_events = (unsigned long long)pp_edge_range_hits(reset);
+    *node_events = (unsigned long long)pp_node_range_hits(reset);
+    return PP_OK;
+#else
+    *edge_events = *node_events = 0;
+    FAIL(PP_ERR_UNSUPPORTED, "pp_range_check_parts: this library was built without -DPP_CHECK_RANGE (use libpackppi_hip.chk.so: "
+                             "python -m packppi_amd.rangecheck)");
+#endif
+}
+// sticky saturation word of the context (every build): waits for `stream`
+extern "C" pp_status pp_ctx_saturated(pp_ctx *c, int *flags, void *stream) {
+    if (!c || !flags) FAIL(PP_ERR_INVALID, "pp_ctx_saturated: null argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    unsigned v = 0;
+    PP_HIP_CHECK(hipMemcpyAsync(&v, c->sat, sizeof(v), hipMemcpyDeviceToHost, s));
+    PP_HIP_CHECK(hipStreamSynchronize(s));
+    *flags = (int)v;
+    return PP_OK;
+}
 extern "C" pp_status pp_range_check(unsigned long long *events, int reset) {
     if (!events) FAIL(PP_ERR_INVALID, "pp_range_check: null argument");
 #ifdef PP_CHECK_RANGE
@@ -583,6 +606,7 @@ static pp_status prepare_impl(pp_plan *plan, const pp_batch *b, const int32_t *s
     ALLOC(xyz, N * 42); ALLOC(rec, N * 64); ALLOC(axes, N * 24); ALLOC(brad, N); ALLOC(per_res, N); ALLOC(dchi, N * 4);
     ALLOC(px, N * 4); ALLOC(pm, N * 4); ALLOC(pv, N * 4); ALLOC(pz, N * 4); ALLOC(pxeff, N * 4); ALLOC(pmask, N);
     ALLOC(scal, 64);
+    ALLOC(sat, 4);
     ALLOC(seg, N);
     ALLOC(prox_part, (size_t)PP_PROX_CHUNK * ((N + 15) / 16));
     c->max_steps = 1 << 20;
@@ -615,6 +639,10 @@ static pp_status prepare_impl(pp_plan *plan, const pp_batch *b, const int32_t *s
         if (packed) hipLaunchKernelGGL(k_fill_seg_packed, dim3((c->N + 255) / 256), dim3(256), 0, s_, c->seg, c->N, seg_offsets, n_seg, c->L);
         else hipLaunchKernelGGL(k_fill_seg, dim3((c->N + 255) / 256), dim3(256), 0, s_, c->seg, c->N, c->L);
         if (hipGetLastError() != hipSuccess) { pp_set_error("segment table launch failed"); st = PP_ERR_HIP; }
+    }
+    if (st == PP_OK && hipMemsetAsync(c->sat, 0, 4 * sizeof(unsigned), static_cast<hipStream_t>(stream)) != hipSuccess) {
+        pp_set_error("clearing the saturation word failed");
+        st = PP_ERR_HIP;
     }
     if (net && st == PP_OK) st = pp_launch_prepare(c, static_cast<hipStream_t>(stream));
     if (net && st == PP_OK) st = pp_launch_edge_static(c, static_cast<hipStream_t>(stream));

@@ -77,8 +77,9 @@ __device__ __forceinline__ f32x2v split_residual(h2v hh, f32x2v x) {
     asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d1) : "v"(hp), "v"(x[1]));
     return f32x2v{d0, d1};
 }
+typedef unsigned short us2v __attribute__((ext_vector_type(2)));
 template <bool RELU>
-__device__ __forceinline__ void split_tile(const f32x16 &v, HT &o) {
+__device__ __forceinline__ void split_tile(const f32x16 &v, HT &o, unsigned &sat) {
 #pragma unroll
     for (int s = 0; s < 2; s++)
 #pragma unroll
@@ -90,6 +91,8 @@ __device__ __forceinline__ void split_tile(const f32x16 &v, HT &o) {
                 x[1] = __builtin_amdgcn_fmed3f(x[1], 0.f, 65504.f);
             }
             const h2v hh = cvt2(x);
+            if (RELU)      // sticky saturation flag: running maximum of the clamped halves (v_pk_max_u16), see pp_internal.h
+                sat = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(us2v, sat), __builtin_bit_cast(us2v, hh)));
             const f32x2v d = split_residual(hh, x);
             const h2v ll = cvt2(d);
             o.hi[s][i] = hh[0]; o.hi[s][i + 1] = hh[1];
@@ -130,6 +133,7 @@ struct EdgeArgs {
     const float *Z;            // layer 0: precomputed W_B h_E0 of this message function [N][K][128]
     const float *pts2, *PA2, *PC2, *b_mid2;   // fused edge update: node-level inputs / bias of the NEXT node message
     float *Znm, *Zem;          // k_edge_static outputs
+    unsigned *sat;             // the context's sticky saturation word (bit 0: edge kernels)
     float *dbg;                // diagnostics: [N][4 waves][64 lanes][8] or null
     int n_pairs;               // k_edge_update_mix: workgroups with two residues (the rest have one)
     int mix_mode;
@@ -449,7 +453,7 @@ __device__ __forceinline__ void geometry_share(const float *__restrict__ pts_i, 
     PRE_PUBLISH()                                                                 \
     _Pragma("unroll") for (int r = 0; r < R; r++) {                               \
         HT ht;                                                                    \
-        split_tile<true>(acc[r], ht);                                             \
+        split_tile<true>(acc[r], ht, sat);                                             \
         xbuf_put_h(xbuf + r * XBUF_FLOATS, wave, lane, ht);                       \
     }                                                                             \
     __syncthreads();
@@ -536,6 +540,7 @@ __device__ __forceinline__ void node_message_body(const EdgeArgs &A, const int r
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, h = lane >> 5;
     const int K = A.K;
+    unsigned sat = 0;
     GROUP_SETUP()
 #pragma unroll
     for (int r = 0; r < R; r++)
@@ -565,7 +570,7 @@ __device__ __forceinline__ void node_message_body(const EdgeArgs &A, const int r
         if constexpr (!ST0) {             // this wave's tile of h_E -> split -> exchange buffer
             HT ht;
             load_tile(hrow + 32 * wave, h, acc[r]);
-            split_tile<false>(acc[r], ht);
+            split_tile<false>(acc[r], ht, sat);
             xbuf_put_h(xbuf + r * XBUF_FLOATS, wave, lane, ht);
         }
         load_tile(A.PA + (size_t)n[r] * 128 + 32 * wave, h, acc[r]);
@@ -601,6 +606,7 @@ __device__ __forceinline__ void node_message_body(const EdgeArgs &A, const int r
             if (tid == 0) A.msum[n[r]] = ms * A.inv_K;
         }
     }
+    if (pp_sat_hit(sat)) atomicOr(A.sat, 1u);
 }
 
 template <int R, bool ST0>
@@ -642,6 +648,7 @@ __device__ __forceinline__ void edge_update_body(const EdgeArgs &A, const int re
     const int j = lane & 31, h = lane >> 5;
     const int K = A.K;
     const int jj = j < K ? j : K - 1;
+    unsigned sat = 0;
     GROUP_SETUP()
 #pragma unroll
     for (int r = 0; r < R; r++)
@@ -693,7 +700,7 @@ __device__ __forceinline__ void edge_update_body(const EdgeArgs &A, const int re
         load_tile(A.hE_in + ((size_t)n[r] * K + jj) * 128 + 32 * wave, h, out[r]);
         if constexpr (!ST0) {
             HT ht;
-            split_tile<false>(out[r], ht);
+            split_tile<false>(out[r], ht, sat);
             xbuf_put_h(xbuf + r * XBUF_FLOATS, wave, lane, ht);
         }
         load_tile(A.PA + (size_t)n[r] * 128 + 32 * wave, h, acc[r]);
@@ -734,7 +741,7 @@ __device__ __forceinline__ void edge_update_body(const EdgeArgs &A, const int re
         for (int q = 0; q < 16; q++) out[r][q] -= mean;
         ln_affine_tile(out[r], rstd, prm + P_G2 + 32 * wave, prm + P_BE2 + 32 * wave, h);
         HT ht;
-        split_tile<false>(out[r], ht);
+        split_tile<false>(out[r], ht, sat);
         xbuf_put_h(x1buf + r * XBUF_FLOATS, wave, lane, ht);
         // `out` keeps x1 (this wave's tile, fp32) as the residual of the second LayerNorm and collects the FFN output
         // on top of it: out = x1 + b + W2 relu(W1 x1 + b1)
@@ -778,7 +785,7 @@ __device__ __forceinline__ void edge_update_body(const EdgeArgs &A, const int re
 #pragma unroll
         for (int r = 0; r < R; r++) {
             HT ht;
-            split_tile<false>(out[r], ht);
+            split_tile<false>(out[r], ht, sat);
             xbuf_put_h(xbuf + r * XBUF_FLOATS, wave, lane, ht);
             geometry_share(A.pts2 + (size_t)n[r] * 48, A.frames + (size_t)n[r] * 12, A.pts2 + (size_t)nbr[r] * 48, h, wave,
                            lane, gbuf + r * GBUF_FLOATS);
@@ -824,6 +831,7 @@ __device__ __forceinline__ void edge_update_body(const EdgeArgs &A, const int re
             }
         }
     }
+    if (pp_sat_hit(sat)) atomicOr(A.sat, 1u);
 #ifdef PP_X_TS
     TS(17)
     if (A.dbg && tid == 0)
@@ -888,7 +896,7 @@ k_edge_static(EdgeArgs A) {
     const int jj = j < K ? j : K - 1;
     const float *hrow = A.hE_in + ((size_t)n * K + jj) * 128;
 #pragma unroll
-    for (int t = 0; t < 4; t++) { load_tile(hrow + 32 * t, h, acc[0]); split_tile<false>(acc[0], x[0][t]); }
+    for (int t = 0; t < 4; t++) { load_tile(hrow + 32 * t, h, acc[0]); { unsigned nosat = 0; split_tile<false>(acc[0], x[0][t], nosat); } }
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[0][r] = 0.f;
     WSTAGE(0, NCH, acc, (mfma_x<1, 0, false>(AK, x, acc)))
@@ -1081,6 +1089,7 @@ static EdgeArgs edge_args(pp_ctx *c, int layer, bool edge) {
     A.pts2 = c->ptsN; A.PA2 = c->PAn; A.PC2 = c->PCn;
     A.b_mid2 = p->w + p->off.layer[layer < 2 ? layer + 1 : 2].nm_mid_b;
     A.dbg = g_dbg;
+    A.sat = c->sat;
     return A;
 }
 

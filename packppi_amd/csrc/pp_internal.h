@@ -144,6 +144,7 @@ struct pp_ctx {
     uint8_t *pmask;           // [N]
     float *prox_part;         // [PP_PROX_CHUNK][ceil(N / 16)] per-block loss terms of the proximal steps
     float *scal;              // small scalar scratch
+    unsigned *sat;            // sticky word: bit 0 = an edge kernel, bit 1 = a node kernel clamped a hidden activation at 65504
     // in-situ kernel timing (pp_profile_kernel): every launch of one hot kernel carries a start / stop event pair
     // (hipExtLaunchKernelGGL: the dispatch's own begin / end timestamps, what rocprofv3's kernel trace reports)
     int prof_which = -1;       // -1 off, 0 node message, 1 edge update, 2 node update
@@ -187,6 +188,14 @@ void pp_set_error(const std::string &msg);
 #define PP_RANGE_READER(name) \
     unsigned int name(int) { return 0; }
 #endif
+// ---- sticky f16 saturation flag of the DEFAULT kernels ------------------------------------------------------------------
+// Hidden activations are clamped at the f16 maximum before they are split (one v_med3).  Every build remembers when that
+// happened: the clamped halves are folded into a per-lane running maximum (v_pk_max_u16 on the packed pair: non-negative
+// f16 bit patterns order like integers), and a lane that saw 0x7BFF (or a NaN pattern above it) ORs a bit into the
+// context's sticky word when the kernel ends.  pp_ctx_saturated reads it.
+__device__ __forceinline__ bool pp_sat_hit(unsigned packed_max) {
+    return (packed_max & 0xffffu) >= 0x7bffu || (packed_max >> 16) >= 0x7bffu;
+}
 unsigned int pp_edge_range_hits(int reset);
 unsigned int pp_node_range_hits(int reset);
 

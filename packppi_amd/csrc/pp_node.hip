@@ -349,6 +349,7 @@ struct NUpdArgs {
     float *hV;
     const float *S, *msum;
     float *ptsN, *PAn, *PCn, *ptsE, *PAe, *PCe, *score;
+    unsigned *sat;               // the context's sticky saturation word (bit 1: node kernels)
 };
 
 template <bool LAST>
@@ -410,7 +411,10 @@ __device__ __forceinline__ void publish4(_Float16 *hi, _Float16 *lo, int off, co
     *reinterpret_cast<nu2 *>(lo + off) = l;
 }
 // hidden activations: ReLU, saturated at the f16 maximum (one v_med3)
-__device__ __forceinline__ nf4 relu_sat(const nf4 &v) {
+// `satm` keeps the largest pre-clamp value this lane has seen (sticky saturation flag, pp_internal.h); NaN inputs are caught
+// by the !(x < limit) form of the final test
+__device__ __forceinline__ nf4 relu_sat(const nf4 &v, float &satm) {
+    satm = __builtin_fmaxf(__builtin_fmaxf(satm, __builtin_fmaxf(v[0], v[1])), __builtin_fmaxf(v[2], v[3]));
     return nf4{__builtin_amdgcn_fmed3f(v[0], 0.f, 65504.f), __builtin_amdgcn_fmed3f(v[1], 0.f, 65504.f),
                __builtin_amdgcn_fmed3f(v[2], 0.f, 65504.f), __builtin_amdgcn_fmed3f(v[3], 0.f, 65504.f)};
 }
@@ -594,6 +598,7 @@ k_node_update(NUpdArgs A, float *chi, int step, int sde, const float *noise, int
 #endif
     nh8 bh[4], bl[4];
     nf4 cH, cL;
+    float satm = 0.f;
     const nf4 zero4 = zero4i;
     // ---- W_out on the masked mean S: mean_j mask_j (W_out y_j + b) = W_out mean_j(mask_j y_j) + b mean_j(mask_j) -----
     LDB4(sm.a_hi, sm.a_lo)
@@ -613,8 +618,9 @@ k_node_update(NUpdArgs A, float *chi, int step, int sde, const float *noise, int
     cH = zero4; cL = zero4;                                                                                \
     NTILE4(4 + 4 * (c), cH, cL)                                                                            \
     publish4(sm.c_hi, sm.c_lo, r * NU_S512 + 16 * (4 * wv + (c)) + 4 * g,                                  \
-             relu_sat(fold(cH, cL) + *reinterpret_cast<const nf4 *>(par + NU_P_FIB + 16 * (4 * wv + (c)) + 4 * g)));
+             relu_sat(fold(cH, cL) + *reinterpret_cast<const nf4 *>(par + NU_P_FIB + 16 * (4 * wv + (c)) + 4 * g), satm));
     FFN_IN_TILE(0) FFN_IN_TILE(1) FFN_IN_TILE(2) FFN_IN_TILE(3)
+    if (!(satm < 65504.f)) atomicOr(A.sat, 2u);
     __syncthreads();
 #if defined(PP_X_NU_STOP) && PP_X_NU_STOP == 3     /* timing experiment: stop here */
     return;
@@ -678,7 +684,7 @@ k_node_update(NUpdArgs A, float *chi, int step, int sde, const float *noise, int
         cH = zero4; cL = zero4;
         NTILE4_IF(36, wv < 4, cH, cL)
         if (wv < 4) {
-            publish4(sm.c_hi, sm.c_lo, r * NU_S512 + fc, relu_sat(fold(cH, cL) + *reinterpret_cast<const nf4 *>(par + NU_P_DB0 + fc)));
+            publish4(sm.c_hi, sm.c_lo, r * NU_S512 + fc, relu_sat(fold(cH, cL) + *reinterpret_cast<const nf4 *>(par + NU_P_DB0 + fc), satm));
         }
         __syncthreads();
 #if defined(PP_X_NU_STOP) && PP_X_NU_STOP == 5     /* timing experiment: stop here */
@@ -701,15 +707,15 @@ k_node_update(NUpdArgs A, float *chi, int step, int sde, const float *noise, int
             NSTAGE_IF(42, w0, eH, mm3(AK, dh[0], dl[0], eH, eL))
             NSTAGE_IF(43, w0, eH, mm3(AK, dh[1], dl[1], eH, eL))
             if (w0) {
-                publish4(sm.c_hi, sm.c_lo, r * NU_S512 + 64 + 4 * g, relu_sat(fold(cH, cL) + *reinterpret_cast<const nf4 *>(par + NU_P_DB1 + 4 * g)));
-                publish4(sm.c_hi, sm.c_lo, r * NU_S512 + 80 + 4 * g, relu_sat(fold(eH, eL) + *reinterpret_cast<const nf4 *>(par + NU_P_DB1 + 16 + 4 * g)));
+                publish4(sm.c_hi, sm.c_lo, r * NU_S512 + 64 + 4 * g, relu_sat(fold(cH, cL) + *reinterpret_cast<const nf4 *>(par + NU_P_DB1 + 4 * g), satm));
+                publish4(sm.c_hi, sm.c_lo, r * NU_S512 + 80 + 4 * g, relu_sat(fold(eH, eL) + *reinterpret_cast<const nf4 *>(par + NU_P_DB1 + 16 + 4 * g), satm));
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 ldB(sm.c_hi, sm.c_lo, r * NU_S512 + 8 * g, 2, dh[0], dl[0]);
             }
             cH = zero4; cL = zero4;
             NSTAGE_IF(44, w0, cH, mm3(AK, dh[0], dl[0], cH, cL))
             if (w0) {
-                publish4(sm.c_hi, sm.c_lo, r * NU_S512 + 96 + 4 * g, relu_sat(fold(cH, cL) + *reinterpret_cast<const nf4 *>(par + NU_P_DB2 + 4 * g)));
+                publish4(sm.c_hi, sm.c_lo, r * NU_S512 + 96 + 4 * g, relu_sat(fold(cH, cL) + *reinterpret_cast<const nf4 *>(par + NU_P_DB2 + 4 * g), satm));
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 ldB(sm.c_hi, sm.c_lo, r * NU_S512 + 8 * g, 3, dh[0], dl[0]);      // columns 112..127: stale but finite, zero weights
             }
@@ -718,6 +724,7 @@ k_node_update(NUpdArgs A, float *chi, int step, int sde, const float *noise, int
         }
         if (w0) {
             // registers 0..3 of lane group 0 = the four scores of residue r
+            if (!(satm < 65504.f)) atomicOr(A.sat, 2u);          // decoder hidden layers (the FFN's were reported above)
             const nf4 sc = fold(cH, cL) + *reinterpret_cast<const nf4 *>(par + NU_P_DB3);
             if (g == 0 && live) *reinterpret_cast<nf4 *>(A.score + (size_t)n * 4) = sc;
             if constexpr (MODE == PP_NU_STEP) {
@@ -895,6 +902,7 @@ pp_status pp_launch_node_update(pp_ctx *c, int layer, int last_mode, float *chi,
     A.ptsN = c->ptsN; A.PAn = c->PAn; A.PCn = c->PCn;
     A.ptsE = c->ptsE; A.PAe = c->PAe; A.PCe = c->PCe;
     A.score = c->score;
+    A.sat = c->sat;
     int embed_next = (last_mode == PP_NU_STEP && embed_next_step) ? 1 : 0;    // node embedding for step + 1 afterwards
 #ifdef PP_X_NU_EMBED_LAUNCH      /* experiment: the next step's embedding as its own launch (k_node_embed) */
     const bool embed_after = embed_next != 0;

@@ -6,6 +6,7 @@
 #include "pp_topk_aten.h"
 
 #define KNN_THREADS 256
+#define KNN_PAR_MAX 2047      // rows up to this length take ATen's nth_element branch (K * 64 > L for K = 32): done by the whole block
 
 // The distance arithmetic that decides neighbour membership must round like the reference's
 // separate mul/add/sqrt ops, so no FMA contraction in this file's geometric helpers.
@@ -144,10 +145,80 @@ k_knn(const float *__restrict__ X, const float *__restrict__ rmask, const int2 *
     if (tid < 32 && tid >= K) mask_att[(size_t)n * 32 + tid] = 0.f;
     const int want = ties == PP_KNN_TIES_ATEN_CPU ? 3 : (ties == PP_KNN_TIES_ATEN_MEMBER ? 2 : 0);
     if (!(s_tie & want) || mi == 0.f) return;       // (a masked row's list is never used: mask_att is 0 throughout)
-    if (tid == 0) {
+    if (tid == 0)
         for (int k = 0; k < K; k++)
             if (pick_i[k] < L) q[pick_i[k]].v = pick_v[k];      // the row as it was before the rounds
-        pp_tk_topk_smallest(q, L, K);
+    __syncthreads();
+    if ((long)K * 64 <= (long)L || L > KNN_PAR_MAX) {
+        // ATen's partial_sort branch (rows of 2048 residues and more): one lane, heap code as it stands
+        if (tid == 0) pp_tk_topk_smallest(q, L, K);
+    } else {
+        // std::nth_element(q, q + K - 1, q + L) with the whole block: every partition pass is the closed form of
+        // pp_topk_aten.h (pp_tk_partition_pivot_lists) -- stop positions by prefix sums, the number of exchanges by a
+        // reduction, the exchanges themselves in parallel; then std::sort of the first K - 1 by one lane (31 elements).
+        short *Apos = reinterpret_cast<short *>(q + L), *Bpos = Apos + (KNN_PAR_MAX + 1);
+        __shared__ int wtL[2][KNN_THREADS / 64], wtR[2][KNN_THREADS / 64], wtT[KNN_THREADS / 64];
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        int first = 0, last = L, depth = 2 * pp_tk_lg(L);
+        const int nth = K - 1;
+        bool heap_done = false;
+        while (last - first > 3) {
+            if (depth == 0) {                      // introselect's fallback (never seen outside adversarial inputs)
+                if (tid == 0) {
+                    pp_tk_heap_select(q + first, q + nth + 1, q + last);
+                    pp_tk_swap(q + first, q + nth);
+                }
+                heap_done = true;
+                break;
+            }
+            --depth;
+            if (tid == 0) pp_tk_median_to_first(q + first, q + first + 1, q + first + (last - first) / 2, q + last - 1);
+            __syncthreads();
+            const pp_tk_pair pivot = q[first];
+            const int m = last - first;
+            int baseL = 0, baseR = 0;
+            for (int c0 = 0, it = 0; c0 < m - 1; c0 += KNN_THREADS, it++) {
+                const int o = c0 + tid;
+                const bool in = o < m - 1;
+                const int iA = first + 1 + o, iB = last - 1 - o;           // ascending / descending position of this thread
+                const bool fl = in && !pp_tk_less(q[in ? iA : first], pivot);
+                const bool fr = in && !pp_tk_less(pivot, q[in ? iB : first]);
+                const unsigned long long bl = __ballot(fl), br = __ballot(fr);
+                if (lane == 0) { wtL[it & 1][wid] = __popcll(bl); wtR[it & 1][wid] = __popcll(br); }
+                __syncthreads();
+                int offL = baseL, offR = baseR;
+#pragma unroll
+                for (int w = 0; w < KNN_THREADS / 64; w++) {
+                    const int a = wtL[it & 1][w], b = wtR[it & 1][w];
+                    if (w < wid) { offL += a; offR += b; }
+                    baseL += a; baseR += b;
+                }
+                if (fl) Apos[offL + __popcll(bl & lt)] = (short)iA;
+                if (fr) Bpos[offR + __popcll(br & lt)] = (short)iB;
+            }
+            if (tid == 0) Bpos[baseR] = (short)first;          // the pivot: where the downward scan stops at the latest
+            const int nA = baseL, nB = baseR + 1;
+            __syncthreads();
+            int cnt = 0;
+            for (int t = tid; t < nA && t < nB; t += KNN_THREADS) cnt += Apos[t] < Bpos[t] ? 1 : 0;
+            for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+            if (lane == 0) wtT[wid] = cnt;
+            __syncthreads();
+            int T = 0;
+#pragma unroll
+            for (int w = 0; w < KNN_THREADS / 64; w++) T += wtT[w];
+            const int a_next = T < nA ? (int)Apos[T] : last, b_prev = T > 0 ? (int)Bpos[T - 1] : last;
+            for (int t = tid; t < T; t += KNN_THREADS) pp_tk_swap(q + Apos[t], q + Bpos[t]);
+            const int cut = a_next < b_prev ? a_next : b_prev;
+            __syncthreads();
+            if (cut <= nth) first = cut; else last = cut;
+        }
+        if (tid == 0) {
+            if (!heap_done) pp_tk_insertion_sort(q + first, q + last);
+            pp_tk_sort(q, q + K - 1);
+        }
+    }
+    if (tid == 0) {
         for (int k = 0; k < K; k++) {
             const int ix = q[k].i;
             eidx[(size_t)n * K + k] = row0 + ix;
@@ -283,6 +354,7 @@ pp_status pp_launch_prepare(pp_ctx *c, hipStream_t s, const int64_t *E_idx) {
     } else {
     hipLaunchKernelGGL(k_frames, dim3((N + 127) / 128), dim3(128), 0, s, c->b.X, N, c->frames, c->bbpos);
     size_t smem = (size_t)c->L * sizeof(pp_tk_pair);  // L = the longest complex of the context
+    if (c->L <= KNN_PAR_MAX) smem += 2 * (KNN_PAR_MAX + 1) * sizeof(short);      // stop-position lists of the parallel partition
     if (smem > 64 * 1024) {
         PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_knn),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));

@@ -147,6 +147,50 @@ PP_HD void pp_tk_insertion_sort(pp_tk_pair *first, pp_tk_pair *last) {
     }
 }
 
+// ---- the same partition as a DATA-PARALLEL formula (what the kNN kernel's 256 threads evaluate together) ------------------
+// __unguarded_partition(first + 1, last, pivot = *first) only ever exchanges disjoint pairs, and which pairs is a closed form
+// of the ORIGINAL sequence: let A = the positions i in [first + 1, last), ascending, with !(a[i] < pivot) (where the upward
+// scan can stop) and B = the positions, descending, with !(pivot < a[i]) (where the downward scan can stop), followed by
+// `first` itself (the pivot: the scan's sentinel).  Between two exchanges both scans only cross untouched elements, so the
+// t-th exchange is (A[t], B[t]); it happens while A[t] < B[t]; with T = the number of exchanges the function returns
+// min(A[T], B[T - 1]) (the upward scan stops at the latest on the element the last exchange put at B[T - 1]; B[-1] = last).
+// This sequential statement of the formula is what tests/test_topk_aten.py holds against std::nth_element; the kernel computes
+// A and B by prefix sums, T by a reduction and does the exchanges in parallel (pp_prepare.hip).
+PP_HD pp_tk_pair *pp_tk_partition_pivot_lists(pp_tk_pair *first, pp_tk_pair *last, int *A, int *B) {
+    pp_tk_pair *mid = first + (last - first) / 2;
+    pp_tk_median_to_first(first, first + 1, mid, last - 1);
+    const pp_tk_pair pivot = *first;
+    const int m = (int)(last - first);
+    int nA = 0, nB = 0;
+    for (int i = 1; i < m; i++)
+        if (!pp_tk_less(first[i], pivot)) A[nA++] = i;
+    for (int i = m - 1; i >= 1; i--)
+        if (!pp_tk_less(pivot, first[i])) B[nB++] = i;
+    B[nB++] = 0;                                   // the pivot position: where the downward scan stops at the latest
+    int T = 0;
+    while (T < nA && T < nB && A[T] < B[T]) T++;
+    for (int t = 0; t < T; t++) pp_tk_swap(first + A[t], first + B[t]);
+    const int a_next = T < nA ? A[T] : m, b_prev = T > 0 ? B[T - 1] : m;
+    return first + (a_next < b_prev ? a_next : b_prev);
+}
+// std::nth_element with that partition (scratch: two int arrays of last - first entries)
+PP_HD void pp_tk_nth_element_lists(pp_tk_pair *first, pp_tk_pair *nth, pp_tk_pair *last, int *A, int *B) {
+    if (first == last || nth == last) return;
+    int depth = pp_tk_lg((int)(last - first)) * 2;
+    while (last - first > 3) {
+        if (depth == 0) {
+            pp_tk_heap_select(first, nth + 1, last);
+            pp_tk_swap(first, nth);
+            return;
+        }
+        --depth;
+        pp_tk_pair *cut = pp_tk_partition_pivot_lists(first, last, A, B);
+        if (cut <= nth) first = cut;
+        else last = cut;
+    }
+    pp_tk_insertion_sort(first, last);
+}
+
 // std::nth_element(first, nth, last)
 PP_HD void pp_tk_nth_element(pp_tk_pair *first, pp_tk_pair *nth, pp_tk_pair *last) {
     if (first == last || nth == last) return;

@@ -17,7 +17,7 @@ _lib = None
 
 SYMBOLS = ("pp_version", "pp_last_error", "pp_build_id", "pp_plan_set_knn_ties", "pp_topk_aten_host", "pp_plan_create", "pp_plan_destroy", "pp_plan_set_clash_params",
            "pp_complex_prepare", "pp_complex_prepare_packed", "pp_ctx_destroy", "pp_ctx_get_graph", "pp_ctx_set_graph", "pp_score", "pp_sample", "pp_atom14",
-           "pp_clash", "pp_proximal", "pp_time_kernel", "pp_profile_kernel", "pp_profile_read", "pp_edge_variant", "pp_has_range_check", "pp_range_check")
+           "pp_clash", "pp_proximal", "pp_time_kernel", "pp_profile_kernel", "pp_profile_read", "pp_edge_variant", "pp_has_range_check", "pp_range_check", "pp_range_check_parts", "pp_ctx_saturated")
 
 
 KNN_TIES = {"lower_index": 0, "aten_cpu": 1, "aten_member": 2}
@@ -81,6 +81,8 @@ def load():
     lib.pp_has_range_check.argtypes = []
     lib.pp_has_range_check.restype = C.c_int
     lib.pp_range_check.argtypes = [C.POINTER(C.c_ulonglong), i]
+    lib.pp_range_check_parts.argtypes = [C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong), i]
+    lib.pp_ctx_saturated.argtypes = [vp, C.POINTER(C.c_int), vp]
     lib.pp_edge_variant.restype = C.c_int
     _lib = lib
     return lib
@@ -267,6 +269,13 @@ class Context:
         _check(load().pp_proximal(self.handle, _ptr(chi), float(lamda), int(num_steps), _ptr(traj), _ptr(last),
                                   _ptr(losses), _stream(self.plan.device)), "pp_proximal")
         return traj, last, losses
+
+    def saturated(self) -> int:
+        """Sticky f16 saturation flag of this context: 0 = no hidden activation was ever clamped at 65504; bit 0 = in an
+        edge-level kernel, bit 1 = in a node-level kernel.  Waits for the stream."""
+        v = C.c_int(0)
+        _check(load().pp_ctx_saturated(self.handle, C.byref(v), _stream(self.plan.device)), "pp_ctx_saturated")
+        return int(v.value)
 
     def time_kernel(self, which: int, iters: int = 20) -> float:
         """Average ms per launch of the node-message (0) / edge-update (1) kernel, HIP events on the current stream."""

@@ -200,6 +200,11 @@ class TDiffusionModule:
         own draw; the packed multi-complex path injects per-complex draws)."""
         return self._context(batch).sample(SC_D_init, self.schedule, self.hparams.sample_cfg.mode, sde_noise)
 
+    def saturated(self) -> int:
+        """Sticky f16 saturation flag of the context of the last batch (0 = clean; see lib.Context.saturated).  A non-zero
+        value means a hidden activation reached the f16 maximum: results are not fp32-equivalent for this checkpoint."""
+        return self._ctx.saturated() if self._ctx is not None else 0
+
     def compute_rmsd(self, true_coords, pred_coords, atom_mask, residue_mask):
         w = atom_mask * residue_mask[..., None]
         return (torch.sum((true_coords - pred_coords) ** 2, dim=-1) * w).sum() / (w + self.eps).sum()

@@ -57,9 +57,11 @@ def gather_metric_rows(ids: torch.Tensor, rows: torch.Tensor, group=None) -> Tup
     return all_rows[:, 0].to(torch.int64), all_rows[:, 1:]
 
 
-def sample_sharded(model, complexes, use_proximal=False, group=None, init_chi=None, max_rows=200_000):
+def sample_sharded(model, complexes, use_proximal=False, group=None, init_chi=None, max_rows=200_000, lengths=None):
     """Run the sampling path on this rank's share of ``complexes`` (list of B = 1 batches already on the rank's device)
-    and gather every complex's metric row on every rank.
+    and gather every complex's metric row on every rank.  With ``lengths`` (the residue counts of ALL complexes, known to
+    every rank) ``complexes`` may be a dict {complex id: batch} that holds only this rank's share -- a rank need not build
+    the other ranks' inputs.
 
     The shard is sampled as ragged PACKED batches (``batch.pack``: no padding rows are launched; complexes shorter than 32
     residues go alone because K = min(32, L)), at most ``max_rows`` residues per batch; the proximal stage, which the
@@ -70,15 +72,17 @@ def sample_sharded(model, complexes, use_proximal=False, group=None, init_chi=No
     from .functional import proximal_optimizer
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     world = dist.get_world_size(group) if dist.is_initialized() else 1
-    mine = shard_complexes([int(c["max_size"]) for c in complexes], world)[rank]
+    if lengths is None:
+        lengths = [int(c["max_size"]) for c in complexes]
+    mine = shard_complexes(lengths, world)[rank]
     cfg = model.hparams.sample_cfg
     groups, cur, rows_in = [], [], 0
-    for i in mine:
-        rm = complexes[i]["residue_mask"].reshape(-1) > 0
+    true_counts = (torch.stack([(complexes[i]["residue_mask"] > 0).sum() for i in mine]).tolist() if mine else [])   # one read-back
+    for i, n_true in zip(mine, true_counts):
         n = int(complexes[i]["max_size"])
         # K = min(32, L) is a property of the batch (encoder.py:115): a complex that is shorter than 32 rows once its trailing
         # padding is dropped goes through the plain B = 1 path with its own tensors, as the reference would run it
-        if int(rm.sum()) < 32 or n < 32:
+        if n_true < 32 or n < 32:
             groups.append([i])
             continue
         if cur and rows_in + n > max_rows:

@@ -40,13 +40,17 @@ extern "C" void mine_piece(int which, const float *v, int n, int k, int *out) {
     auto q = fill_mine(v, n);
     if (which == 0) pp_tk_sort(q.data(), q.data() + n);
     else if (which == 1) pp_tk_nth_element(q.data(), q.data() + k - 1, q.data() + n);
+    else if (which == 3) {      // nth_element through the data-parallel partition formula (the kernel's form)
+        std::vector<int> A(n + 1), B(n + 1);
+        pp_tk_nth_element_lists(q.data(), q.data() + k - 1, q.data() + n, A.data(), B.data());
+    }
     else pp_tk_partial_sort(q.data(), q.data() + k, q.data() + n);
     for (int j = 0; j < n; j++) out[j] = q[j].i;
 }
 extern "C" void std_piece(int which, const float *v, int n, int k, int *out) {
     auto q = fill(v, n);
     if (which == 0) std::sort(q.begin(), q.end(), less_nan_last);
-    else if (which == 1) std::nth_element(q.begin(), q.begin() + k - 1, q.end(), less_nan_last);
+    else if (which == 1 || which == 3) std::nth_element(q.begin(), q.begin() + k - 1, q.end(), less_nan_last);
     else std::partial_sort(q.begin(), q.begin() + k, q.end(), less_nan_last);
     for (int j = 0; j < n; j++) out[j] = (int)q[j].second;
 }

@@ -169,6 +169,28 @@ def test_cli_flags_match_reference():
         eval_diffusion.main(["--outdir", "x"])
 
 
+def test_T1124_pdb_parses_to_the_golden_batch():
+    """data/T1124_lig.pdb itself (11 208 ATOM records, 5 527 hydrogens, 1 313 alternate-location flags, 132 HETATM) through
+    pdb_io + featurize == the batch the reference's prot_to_data produced from it (tests/golden/g4_T1124.npz, asserted
+    equal at generation time by tools/oracle/make_golden.py).  The file lives in the reference checkout: skipped where that
+    is absent (the GPU box)."""
+    path = "/root/reference/data/T1124_lig.pdb"
+    if not os.path.exists(path):
+        pytest.skip("reference checkout not present")
+    from packppi_amd.batch import TENSOR_KEYS
+    from packppi_amd.featurize import protein_to_batch
+    from packppi_amd.pdb_io import from_pdb_file
+    prot = from_pdb_file(path)
+    z = np.load(os.path.join(GOLD, "g4_T1124.npz"))
+    assert prot["atom_positions"].shape == (739, 14, 3)
+    assert "".join(sorted(set(prot["chain_id"].tolist()))) == "AB"
+    assert np.array_equal(prot["chain_id"], z["prot.chain_id"]) and np.array_equal(prot["residue_index"], z["prot.residue_index"])
+    b = protein_to_batch(prot)
+    for k in TENSOR_KEYS:
+        assert np.array_equal(b[k].numpy(), z["batch." + k]), k
+    assert int(b.max_size) == 739 and int(b.residue_mask.sum()) == 738 and int(b.SC_D_mask.sum()) == 1210     # (1 226 by composition; 16 chi lack an atom)
+
+
 def test_pack_unpack_roundtrip():
     """batch.pack: complexes back to back without padding rows; unpack splits per-row results again."""
     from packppi_amd import synth

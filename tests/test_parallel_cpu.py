@@ -124,6 +124,54 @@ def test_sample_sharded_packs_and_gathers_gloo_world2():
     assert sorted(owned) == list(range(5))
 
 
+def test_gather_arguments_are_what_a_device_backend_needs(monkeypatch):
+    """The "nccl" (RCCL) branch cannot run here; what it is handed can be checked: every all_gather gets a list of `world`
+    buffers with the shape, dtype and device of the contiguous input tensor -- same size on every rank, padded to the longest
+    shard -- and the result is assembled from the true counts."""
+    from packppi_amd import parallel
+    calls = []
+
+    class FakeDist:
+        """two ranks; the other rank holds one complex more, with ids shifted by 100"""
+        @staticmethod
+        def is_available():
+            return True
+
+        @staticmethod
+        def is_initialized():
+            return True
+
+        @staticmethod
+        def get_world_size(group=None):
+            return 2
+
+        @staticmethod
+        def all_gather(outs, t, group=None):
+            assert len(outs) == 2 and t.is_contiguous()
+            for o in outs:
+                assert o.shape == t.shape and o.dtype == t.dtype and o.device == t.device and o.is_contiguous()
+            calls.append((tuple(t.shape), t.dtype))
+            outs[0].copy_(t)
+            if t.dtype == torch.int64:               # the counts
+                outs[1].copy_(t + 1)
+            else:                                    # [cap, 1 + W] blocks: rank 1 = rank 0's rows with ids + 100, and one more
+                other = torch.zeros_like(t)
+                n0 = int((t[:, 1:].abs().sum(1) > 0).sum())
+                other[:n0] = t[:n0]
+                other[:n0, 0] += 100
+                other[n0, 0], other[n0, 1:] = 999.0, 7.0
+                outs[1].copy_(other)
+
+    monkeypatch.setattr(parallel, "dist", FakeDist)
+    W = len(METRIC_KEYS)
+    ids = torch.tensor([4, 2, 9])
+    rows = torch.arange(3 * W, dtype=torch.float32).reshape(3, W) + 1
+    ids_all, rows_all = gather_metric_rows(ids, rows)
+    assert calls == [((1,), torch.int64), ((4, W + 1), torch.float32)]          # padded to the longest shard (3 + 1)
+    assert ids_all.tolist() == [2, 4, 9, 102, 104, 109, 999] and rows_all.shape == (7, W)
+    assert torch.equal(rows_all[0], rows[1]) and torch.equal(rows_all[3], rows[1]) and bool((rows_all[6] == 7).all())
+
+
 def test_bench_refuses_a_rank_count_mismatch():
     """bench.py --gpus N under a launcher with a different WORLD_SIZE exits non-zero before touching any GPU."""
     import subprocess

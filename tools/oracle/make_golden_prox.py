@@ -52,6 +52,154 @@ def ref_batch(b, double=False):
     return refshim.Data(**d)
 
 
+def wrapped(a, b):
+    d = (a.double() - b.double()).abs()
+    return torch.minimum(d, (2 * np.pi - d).abs())
+
+
+def chunked_fp64_proximal(b, chi0, vtf=12., tol=0.5, lamda=1., num_steps=50, rows=96):
+    """fp64 ARBITER for complexes whose (L, L, 14, 14) pair tensors do not fit host memory in double precision (S1500: 35 GB
+    each, ten of them in the reference): optimize.py:21-73 with the clash loss of clash.py:102-254 evaluated over row blocks of
+    the residue-pair matrix and the gradient accumulated block by block (the loss is a sum over atom pairs, so this is the same
+    function).  Built from the pinned oracle's pieces; validated against the REFERENCE's own fp64 run on T1124 by
+    append_trajectory before it is used."""
+    from oracle import ref_cpu as O
+    from packppi_amd import constants as rc
+    dt = torch.float64
+    bd = {k: (v.double() if isinstance(v, torch.Tensor) and v.dtype == torch.float32 else v) for k, v in b.items()}
+    S, exists, ridx = bd["residue_type"], bd["atom_mask"], bd["residue_index"]
+    L = S.shape[1]
+    n_sc = exists[..., 4:].sum(-1)
+    radius = exists * torch.as_tensor(rc.between_radius, dtype=dt)[S]
+    lo, up = rc.make_atom14_dists_bounds(overlap_tolerance=tol, bond_length_tolerance_factor=vtf)
+    lo, up = torch.as_tensor(lo, dtype=dt)[S], torch.as_tensor(up, dtype=dt)[S]
+    w_atom = torch.zeros(1, L, 14, dtype=dt)
+    w_atom[..., 4:] = (1.0 / (1e-10 + n_sc))[..., None]              # per-residue score = sum_{a >= 4} per_atom / n_sc
+    bb = torch.zeros(14, 14, dtype=dt); bb[:4, :4] = 1
+    cn = torch.zeros(14, 14, dtype=dt); cn[2, 0] = 1
+    ss = torch.zeros(14, 14, dtype=dt); ss[5, 5] = 1
+
+    def per_res(chi, need_grad):
+        """per-residue clash [1, L] and, if asked, d(sum_i c_i per_res_i)/dchi for given c (closure)."""
+        x = chi.clone().requires_grad_(need_grad)
+        xyz = O.atom14_coords(bd["X"], S, bd["BB_D"], x)
+        return x, xyz
+
+    def between_blocks(xyz, coef):
+        """sum over atom pairs of err * (coef[i, a] + coef[j, b]) block by block; returns (per_atom [1,L,14] detached,
+        d(that sum)/dxyz)."""
+        per_atom = torch.zeros(1, L, 14, dtype=dt)
+        gxyz = torch.zeros_like(xyz)
+        xd = xyz.detach()
+        for i0 in range(0, L, rows):
+            i1 = min(L, i0 + rows)
+            xi = xd[:, i0:i1].clone().requires_grad_(True)
+            xj = xd.clone().requires_grad_(True)
+            d = torch.sqrt(1e-10 + ((xi[:, :, None, :, None, :] - xj[:, None, :, None, :, :]) ** 2).sum(-1))
+            m = exists[:, i0:i1, None, :, None] * exists[:, None, :, None, :]
+            m = m * (1 - bb)
+            m = m * (ridx[:, i0:i1, None, None, None] < ridx[:, None, :, None, None])
+            nb = ((ridx[:, i0:i1, None] + 1) == ridx[:, None, :])[..., None, None]
+            m = m * (1 - nb * cn) * (1 - ss)
+            lower = m * (radius[:, i0:i1, None, :, None] + radius[:, None, :, None, :])
+            err = m * torch.relu(lower - tol - d)
+            per_atom[:, i0:i1] += err.detach().sum(dim=(2, 4))
+            per_atom += err.detach().sum(dim=(1, 3))
+            if coef is not None:
+                tot = (err * (coef[:, i0:i1, None, :, None] + coef[:, None, :, None, :])).sum()
+                gi, gj = torch.autograd.grad(tot, (xi, xj))
+                gxyz[:, i0:i1] += gi
+                gxyz += gj
+        return per_atom, gxyz
+
+    def clash(chi, need_grad):
+        x, xyz = per_res(chi, need_grad)
+        coef = (w_atom / L) if need_grad else None                    # loss term: lamda * mean_i per_res_i
+        pa_b, gxyz = between_blocks(xyz, coef)
+        within = O.within_residue_violation(xyz, exists, lo, up)
+        pr = ((pa_b + within.detach())[..., 4:].sum(-1)) / (1e-10 + n_sc)
+        if not need_grad:
+            return pr, None
+        tail = (within * w_atom / L).sum()
+        xyz.backward(gxyz, retain_graph=True)
+        tail.backward()
+        return pr, x.grad
+
+    chi0 = chi0.double()
+    pr0, _ = clash(chi0, False)
+    mask = (pr0 > pr0.mean())[..., None].expand(-1, -1, 4)
+    z = chi0 * mask
+    x = z.clone().requires_grad_(True)
+    opt = torch.optim.Adam([x], lr=1e-2)
+    chis, losses = [], []
+    for it in range(num_steps):
+        opt.zero_grad()
+        xe = torch.where(mask, x * mask, chi0)
+        pr, g = clash(xe.detach(), True)
+        prox = (torch.abs(xe - z) ** 2).sum(-1).mean()
+        prox.backward()
+        x.grad += lamda * torch.where(mask, g, torch.zeros_like(g))
+        losses.append(float(prox.detach() + lamda * pr.mean()))
+        opt.step()
+        chis.append(torch.where(mask, x.detach().clone(), chi0))
+    return chis, losses
+
+
+def append_trajectory(args, cases, proximal_optimizer):
+    for tag in args.only.split(","):
+        path = os.path.join(GOLD, f"g6_prox_{tag}.npz")
+        old = dict(np.load(path))
+        fx, key = cases[tag]
+        z, b = load_fixture(fx)
+        chi0 = torch.from_numpy(z[key]).float()
+        t0 = time.time()
+        chis32, losses32 = proximal_optimizer(ref_batch(b), chi0.clone(), 12., 0.5, 1., 50)
+        chis32 = [c.detach() for c in chis32]
+        print(f"  {tag} fp32 reference: {time.time() - t0:.0f}s", flush=True)
+        for n in KEEP:       # the same run as the one stored (same thread count -> same reduction order)
+            assert np.array_equal(chis32[n - 1].numpy(), old[f"chi32_step{n}"]), (tag, n)
+        t0 = time.time()
+        if tag in args.no64.split(","):
+            # validate the chunked arbiter where the reference's fp64 run exists, then use it here.  The pinned oracle in
+            # fp64 is not bit-for-bit the reference in fp64 (its loss differs by 1.5e-8 relative at the same point), and 50 Adam
+            # steps amplify that: on L64 2.6e-8 rad at step 5, 2.8e-7 at step 10, 3e-4 at step 50 -- an order of magnitude
+            # below the |ref32 - ref64| distances the arbiter is used to judge.
+            zt, bt = load_fixture(cases["L120"][0])
+            ct, _ = chunked_fp64_proximal(bt, torch.from_numpy(zt[cases["L120"][1]]).float(), rows=32)
+            ref64 = np.load(os.path.join(GOLD, "g6_prox_L120.npz"))
+            dv = {n: float(wrapped(ct[n - 1], torch.from_numpy(ref64[f"chi64_step{n}"])).max()) for n in KEEP}
+            print(f"  chunked fp64 arbiter vs the reference's fp64 run on L120: {dv}", flush=True)
+            assert dv[10] < 2e-6 and dv[50] < 1e-3, dv
+            old["arbiter64_vs_reference_on_L120"] = np.array([dv[n] for n in KEEP])
+            chis64, losses64 = chunked_fp64_proximal(b, chi0)
+            old["arbiter64"] = np.array("oracle fp64, pair matrix in row blocks (tools/oracle/make_golden_prox.py)")
+            for n in KEEP:
+                old[f"chi64_step{n}"] = chis64[n - 1].numpy()
+            old["losses64"] = np.array(losses64, np.float64)
+        else:
+            chis64, losses64 = proximal_optimizer(ref_batch(b, True), chi0.double(), 12., 0.5, 1., 50)
+            chis64 = [c.detach() for c in chis64]
+            for n in KEEP:
+                assert np.array_equal(chis64[n - 1].numpy(), old[f"chi64_step{n}"]), (tag, n)
+            old["arbiter64"] = np.array("reference fp64")
+        print(f"  {tag} fp64: {time.time() - t0:.0f}s", flush=True)
+        moved = torch.zeros(chi0.shape[1], dtype=torch.bool)
+        for c in chis32:
+            moved |= (c != chi0).any(-1)[0]
+        idx = torch.nonzero(moved).flatten()
+        old["traj32_residues"] = idx.to(torch.int32).numpy()
+        old["traj32"] = torch.stack([c[0, idx] for c in chis32]).numpy()                 # [50, n_moved, 4]
+        div = np.array([float(wrapped(a, c).max()) for a, c in zip(chis32, chis64)])
+        old["div_32_64"] = div
+        flips = np.nonzero(div > 1e-5)[0]
+        old["first_flip_ref"] = np.int64(flips[0] + 1 if len(flips) else 51)              # 1-based step; 51 = never
+        print(f"  {tag}: {len(idx)} residues move; |ref32 - ref64| by step: "
+              + " ".join(f"{d:.1e}" for d in div[[0, 4, 9, 14, 19, 29, 39, 49]]) + f"; first > 1e-5 at step {int(old['first_flip_ref'])}",
+              flush=True)
+        np.savez_compressed(path, **old)
+        print(f"  rewrote {os.path.basename(path)} {os.path.getsize(path) / 1e6:.2f} MB", flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="L64,L120,T1124,S1500")
@@ -60,6 +208,10 @@ def main():
     ap.add_argument("--append-grads", action="store_true",
                     help="load the existing g6 files and add the reference's clash value and autograd gradient at its own fp32 "
                          "iterates (per_res32_stepN, grad32_stepN): the trajectory-independent check of the analytic gradient")
+    ap.add_argument("--append-trajectory", action="store_true",
+                    help="re-run the reference (fp32: every case; fp64: every case but --no64, which get the chunked fp64 "
+                         "arbiter below) and add every step of the fp32 run (traj32 on the residues that move), the per-step "
+                         "distance between the two precisions (div_32_64) and the first step at which they part (first_flip_ref)")
     args = ap.parse_args()
     torch.set_num_threads(args.threads)
     from src.models.components.optimize import proximal_optimizer
@@ -67,6 +219,9 @@ def main():
 
     cases = {"L64": ("g3_proximal_L64", "init_chi_seed11"), "L120": ("g3_proximal_L120", "init_chi_seed11"),
              "T1124": ("g4_T1124", "chi_ode_100"), "S1500": ("g5_S1500", "chi_ode_100")}
+    if args.append_trajectory:
+        append_trajectory(args, cases, proximal_optimizer)
+        return
     if args.append_grads:
         from src.models.components.clash import compute_residue_clash
         for tag in args.only.split(","):
