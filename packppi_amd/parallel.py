@@ -29,6 +29,40 @@ def metrics_to_row(metric: Dict[str, torch.Tensor]) -> torch.Tensor:
     return torch.stack([torch.as_tensor(metric[k], dtype=torch.float32).reshape(()) for k in METRIC_KEYS])
 
 
+def packed_metric_rows(model, pb, chi, sizes) -> torch.Tensor:
+    """``analyze_samples`` (TorsionalDiffusion.py:311-341) for every complex of a packed batch at once: one atom14 launch
+    and segment sums instead of one context, one launch and a dozen small reductions per complex.  ``sizes`` = the complexes'
+    own ``max_size`` (the reference's atom_rmsd denominator adds eps for every atom slot of the complex, padding included).
+    Returns [n_complexes, len(METRIC_KEYS)] on the batch's device, rows in packing order."""
+    import numpy as np
+    offs = pb["seg_offsets_host"]
+    n = len(offs) - 1
+    dev = chi.device
+    lens = torch.tensor([b - a for a, b in zip(offs[:-1], offs[1:])], device=dev)
+    seg = torch.repeat_interleave(torch.arange(n, device=dev), lens)              # complex of every packed row
+
+    def seg_sum(x):                                                                  # [1, N, ...] -> [n] sums per complex
+        x = x.reshape(x.shape[1], -1).sum(-1)
+        return torch.zeros(n, device=dev, dtype=x.dtype).index_add_(0, seg, x)
+
+    true, m, pi1 = pb["SC_D"], pb["SC_D_mask"], pb["chi_1pi_periodic_mask"]
+    cols = []
+    for i in range(4):
+        cnt = seg_sum(m[..., i])
+        cnt = torch.where(cnt != 0, cnt, torch.ones_like(cnt))
+        diff = (chi[..., i] - true[..., i]).abs()
+        acc = torch.logical_and(diff * 180 / np.pi < 20, diff > 0).float()
+        ae = torch.minimum(diff, 2 * np.pi - diff)
+        ae = torch.where(pi1[..., i], torch.minimum(ae, np.pi - ae), ae)
+        cols += [seg_sum(ae) / cnt, seg_sum(ae * 180 / np.pi) / cnt, seg_sum(acc) / cnt]
+    pred = model.get_atom14_coords(pb, chi)
+    w = pb["atom_mask"] * pb["residue_mask"][..., None]
+    num = seg_sum(torch.sum((pb["X"] - pred) ** 2, dim=-1) * w)
+    den = seg_sum(w) + model.eps * 14.0 * torch.tensor([float(sz) for sz in sizes], device=dev)
+    cols.append(num / den)
+    return torch.stack(cols, 1)
+
+
 def gather_metric_rows(ids: torch.Tensor, rows: torch.Tensor, group=None) -> Tuple[torch.Tensor, torch.Tensor]:
     """All-gather ragged (ids [n_r], rows [n_r, W]) from every rank; returns them sorted by complex id.
 
@@ -92,7 +126,7 @@ def sample_sharded(model, complexes, use_proximal=False, group=None, init_chi=No
         rows_in += n
     if cur:
         groups.append(cur)
-    chis = {}
+    chis, row_of = {}, {}
     for grp in groups:
         if len(grp) == 1:
             i = grp[0]
@@ -108,11 +142,17 @@ def sample_sharded(model, complexes, use_proximal=False, group=None, init_chi=No
             out = model.sample_from(pb, x0)
         else:
             out = model.sampling(pb)
+        if not use_proximal:          # the metrics of the whole group in one go (the proximal stage changes the angles first)
+            for i, row in zip(grp, packed_metric_rows(model, pb, out, [int(complexes[i]["max_size"]) for i in grp])):
+                row_of[i] = row
         for i, chi in zip(grp, unpack(pb, out)):
             L = int(complexes[i]["max_size"])
-            full = torch.zeros(1, L, 4, device=chi.device, dtype=chi.dtype)
-            full[:, :chi.shape[1]] = chi
-            chis[i] = full
+            if chi.shape[1] == L:
+                chis[i] = chi
+            else:
+                full = torch.zeros(1, L, 4, device=chi.device, dtype=chi.dtype)
+                full[:, :chi.shape[1]] = chi
+                chis[i] = full
     rows = []
     for i in mine:
         if use_proximal:
@@ -120,7 +160,7 @@ def sample_sharded(model, complexes, use_proximal=False, group=None, init_chi=No
                                              cfg.clash_overlap_tolerance, cfg.lamda, cfg.num_steps)
             if losses[-1] < losses[0]:
                 chis[i] = lst[-1]
-        rows.append(metrics_to_row(model.analyze_samples(complexes[i], chis[i])))
+        rows.append(row_of[i] if i in row_of else metrics_to_row(model.analyze_samples(complexes[i], chis[i])))
     dev = model.device
     ids = torch.tensor(mine, device=dev, dtype=torch.int64)
     rows_t = torch.stack(rows).to(dev) if rows else torch.zeros(0, len(METRIC_KEYS), device=dev)

@@ -645,9 +645,14 @@ def test_c5_shard_through_sample_sharded(weights):
     init = {i: torch.from_numpy(gold[i][f"init_{i}"]) for i in range(32)}
     chis, ids, rows = sample_sharded(m, cs, init_chi=init)
     assert ids.tolist() == list(range(32)) and rows.shape == (32, len(METRIC_KEYS)) and torch.isfinite(rows).all()
+    from packppi_amd.parallel import metrics_to_row
     for i in range(32):
         d = wrapped_absdiff(chis[i].cpu(), torch.from_numpy(gold[i][f"chi_ode_100_{i}"]))[cs[i].SC_D_mask.cpu().bool()]
         assert float(d.max()) < 1e-4, (i, float(d.max()))
+        # the gathered row (computed for the whole packed group at once) is the complex's own analyze_samples
+        if i % 8 == 0:
+            want = metrics_to_row(m.analyze_samples(cs[i], chis[i])).cpu()
+            assert torch.allclose(rows[i].cpu(), want, rtol=2e-5, atol=1e-7), (i, rows[i], want)
     low = TDiffusionModule(weights, device=DEV, knn_ties="lower_index")
     low.schedule = m.schedule
     ref = torch.from_numpy(gold[12]["chi_ode_100_12"])

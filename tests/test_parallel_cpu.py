@@ -58,9 +58,11 @@ def test_gather_metric_rows_gloo_world2(lens):
 
 
 class _FakeModel:
-    """CPU stand-in for TDiffusionModule on the sharded path: 'sampling' is a fixed function of the packed rows, so the
-    packing, unpacking, shard assignment and gather can be checked without a GPU."""
+    """CPU stand-in for TDiffusionModule on the sharded path: 'sampling' and 'atom14' are fixed functions of the rows, the
+    metric code is the product's own (TDiffusionModule.analyze_samples / compute_rmsd, unbound), so the packing, unpacking,
+    shard assignment, the packed metric rows and the gather can be checked without a GPU."""
     device = torch.device("cpu")
+    NUM_CHI_ANGLES, eps = 4, 1e-6
 
     def __init__(self):
         from types import SimpleNamespace
@@ -71,13 +73,22 @@ class _FakeModel:
     def sample_from(self, batch, x0, sde_noise=None):
         assert batch.num_proteins == 1 and x0.shape == (1, batch.max_size, 4)
         self.packed_shapes.append((int(batch.max_size), batch.get("seg_offsets_host") or [0, int(batch.max_size)]))
-        return 0.5 * x0 + batch.residue_type[..., None].float() * 0.01
+        return (0.5 * x0 + batch.residue_type[..., None].float() * 0.01) * batch.SC_D_mask
+
+    def get_atom14_coords(self, batch, chi):
+        return batch.X + 0.05 * chi.sum(-1)[..., None, None] * batch.atom_mask[..., None]
+
+    def _geometry_context(self, batch):
+        from types import SimpleNamespace
+        return SimpleNamespace(atom14=lambda chi: self.get_atom14_coords(batch, chi))
+
+    def compute_rmsd(self, *a):
+        from packppi_amd.module import TDiffusionModule
+        return TDiffusionModule.compute_rmsd(self, *a)
 
     def analyze_samples(self, batch, chi):
-        d = {k: torch.tensor(0.0) for k in METRIC_KEYS}
-        d["atom_rmsd"] = chi.sum()
-        d["chi_0_acc"] = torch.tensor(float(batch.max_size))
-        return d
+        from packppi_amd.module import TDiffusionModule
+        return TDiffusionModule.analyze_samples(self, batch, chi)
 
 
 def _sharded_worker(rank, world, port, q):
@@ -94,9 +105,14 @@ def _sharded_worker(rank, world, port, q):
     init = {i: torch.rand(1, n, 4, generator=g) for i, n in enumerate(lens)}
     model = _FakeModel()
     chis, ids, rows = sample_sharded(model, cs, init_chi=init, max_rows=100)
-    expect = {i: 0.5 * init[i] + cs[i].residue_type[..., None].float() * 0.01 for i in chis}
+    expect = {i: (0.5 * init[i] + cs[i].residue_type[..., None].float() * 0.01) * cs[i].SC_D_mask for i in chis}
     ok = all(torch.equal(chis[i], expect[i]) for i in chis)
-    q.put((rank, sorted(chis), model.packed_shapes, ids.tolist(), rows[:, METRIC_KEYS.index("chi_0_acc")].tolist(), ok))
+    # every gathered row (packed groups: parallel.packed_metric_rows) equals the per-complex analyze_samples of that complex
+    from packppi_amd.parallel import metrics_to_row
+    full = {i: (0.5 * init[i] + cs[i].residue_type[..., None].float() * 0.01) * cs[i].SC_D_mask for i in range(len(lens))}
+    want = torch.stack([metrics_to_row(model.analyze_samples(cs[i], full[i])) for i in range(len(lens))])
+    ok = ok and bool(torch.allclose(rows, want, rtol=1e-5, atol=1e-7)) and bool((want[:, -1] > 0).all())
+    q.put((rank, sorted(chis), model.packed_shapes, ids.tolist(), ok))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -114,10 +130,10 @@ def test_sample_sharded_packs_and_gathers_gloo_world2():
         assert p.exitcode == 0
     lens = [40, 20, 57, 33, 64]
     owned = []
-    for rank, mine, shapes, ids, sizes, ok in got:
+    for rank, mine, shapes, ids, ok in got:
         assert ok and mine == shard_complexes(lens, world)[rank]
         owned += mine
-        assert ids == list(range(5)) and sizes == [float(n) for n in lens]          # every rank sees every row
+        assert ids == list(range(5))                                                # every rank sees every row
         for total, offs in shapes:                                                  # packed groups: no padding rows
             seg = [b - a for a, b in zip(offs[:-1], offs[1:])]
             assert total == sum(seg) and (min(seg) >= 32 or len(seg) == 1) and (total <= 100 or len(seg) == 1)
