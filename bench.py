@@ -39,8 +39,9 @@ NODE_UPDATE_STREAM_BYTES = 56 * 8 * 2048       # one workgroup's weight stream (
 FP32_MFMA_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 F16_MFMA_PEAK_TFLOPS = 2500.0       # MI355X_MICROARCH.md, "Peak BF16/FP16 MFMA ~2.5 PF dense"
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md, "HBM3E peak BW 8.0 TB/s spec"
+L2_PEAK_TBS = 34.5                  # MI355X_MICROARCH.md, "L2 (per XCD)": 4 MiB per XCD, ~34.5 TB/s aggregate
 CU_VMEM_PEAK_GBS = 64 * 2.4         # one CU's vector-memory path: 64 B/clk at 2.4 GHz
-PROFILE_TAG = "r02_v17"             # the committed rocprofv3 summaries of THIS command (profiles/<tag>_*.{csv,json})
+PROFILE_TAG = "r03_v1"             # the committed rocprofv3 summaries of THIS command (profiles/<tag>_*.{csv,json})
 
 
 def _load_fixture(name, init_key):
@@ -125,8 +126,8 @@ def cpu_baseline(batch, init, weights, n_sample_steps, n_grad_steps):
         out["as_shipped"] = {"value": res / (dtg / n_grad_steps * N_DIFFUSION_STEPS), "unit": "residues/s", "kind": "port",
                              "sample": f"{n_grad_steps} steps with autograd recording (eval_diffusion.py:62 calls sampling() "
                                        f"without torch.no_grad); {dtg:.1f} s measured, scaled x{N_DIFFUSION_STEPS / n_grad_steps:g}",
-                             "note": "the PORT loses nothing to autograd; the reference itself does (its per-step graph rebuild "
-                                     "keeps every L x L intermediate alive): see reference_in_build_container"}
+                             "note": "autograd recording costs this loop nothing measurable, in the port and in the reference itself "
+                                     "(reference_in_build_container: measured, not quoted)"}
     ref = reference_container_rates()
     if ref is not None:
         out["reference_in_build_container"] = ref      # kind "reference", measured where the reference can run
@@ -144,6 +145,17 @@ def pmc_traffic(kernel):
     # the launch of this kernel the timed passes use (k_edge_update_mix at T1124): the entry with the most launches
     hits = [v for k, v in ks.items() if k.startswith(kernel)]
     return max(hits, key=lambda v: v["launches"])["hbm_bytes"] if hits else None
+
+
+def l2_requests(kernel):
+    """128-byte L2 requests per launch of `kernel` from the committed TCC counter pass of this command
+    (tools/profile/run_tcc.sh -> profiles/<PROFILE_TAG>_tcc_t1124.json).  None when it is absent."""
+    try:
+        ks = json.load(open(os.path.join(ROOT, "profiles", PROFILE_TAG + "_tcc_t1124.json")))["kernels"]
+    except (OSError, KeyError, ValueError):
+        return None
+    hits = [v for k, v in ks.items() if k.startswith(kernel)]
+    return max(hits, key=lambda v: v["launches"]) if hits else None
 
 
 def spawn_ranks(n):
@@ -343,12 +355,24 @@ def main():
             executed_mfma = (2960 + 656 - 128) * 4096.0 * residues    # average of the layer-0 and layer-1 launches
             peak, dtype = FP32_MFMA_PEAK_TFLOPS, "f32"
         whole = 46792576.0 * total_res * N_DIFFUSION_STEPS * args.steps / elapsed / 1e12 / max(args.gpus, 1)
+        # what the kernel is closest to: the L2 -> CU operand stream (every workgroup pulls the layer's packed weight set)
+        l2 = l2_requests("k_edge_update") if args.workload == "t1124" else None
+        l2_stream = None
+        if l2 is not None:
+            l2_stream = {"achieved": l2["l2_request_bytes"] / t_edge / 1e12, "unit": "TB/s", "peak": L2_PEAK_TBS,
+                         "frac": l2["l2_request_bytes"] / t_edge / 1e12 / L2_PEAK_TBS,
+                         "practical": "16.8-18.8 TB/s is what a kernel that only pulls L2-resident rows reaches (MI355X_MICROARCH.md, indexed rows)",
+                         "l2_hit_rate": l2["l2_hit_rate"], "requests_per_launch": l2["l2_requests"],
+                         "of_which_weight_stream_bytes": 917504.0 * 1.0 * ((residues + 2) // 3 + max(residues - 2 * ((residues + 2) // 3), 0)),
+                         "source": f"profiles/{PROFILE_TAG}_tcc_t1124.json (rocprofv3 --pmc TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum, own pass) / live kernel time"}
         roof = {"bound": "mfma", "kernel": "k_edge_update", "achieved": achieved,
                 "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                 "peak_is": "dense F16 MFMA (the pipe the kernel runs on)" if split_f16 else "FP32 matrix",
-                "limiter": "not the pipe: SQ counters put the MFMA pipe at ~30 % busy; the kernel is bound by instruction issue "
-                           "and latency around the MFMAs (the per-workgroup weight stream, LDS exchanges, LayerNorms); `bound` "
-                           "names the roofline that would bind at the limit",
+                "limiter": "not the matrix pipe (SQ counters: ~33 % busy here, 45-49 % on multi-round batches): the L2 -> CU operand "
+                           "stream (every workgroup pulls the layer's 0.93 MB packed weight set; `l2_stream`: ~3/4 of what a pure "
+                           "L2-row-pulling kernel reaches on this chip) together with the LDS reads of the B operands and the VALU "
+                           "work of the f16 splits, about equally loaded (DESIGN.md 4.5); `bound` names the roofline that would bind "
+                           "at the limit",
                 "achieved_is": "the reference's fp32 dense-layer arithmetic (2 FLOP per MAC) per second; the kernel "
                                "issues 3 f16 MFMAs per product, see executed_mfma_tflops",
                 "achieved_over_fp32_matrix_peak": achieved / FP32_MFMA_PEAK_TFLOPS,
@@ -356,6 +380,7 @@ def main():
                 "traffic": pmc_traffic("k_edge_update") if args.workload == "t1124" else None,
                 "traffic_unit": f"HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes of this "
                                 f"command; profiles/{PROFILE_TAG}_pmc_traffic.json)",
+                "l2_stream": l2_stream,
                 "kernel_ms": t_edge * 1e3,
                 "kernel_ms_is": "mean begin-to-end interval of the dispatches inside the sampling loop (start/stop HIP events attached to each launch)",
                 "kernel_does": "edge update of layer l + node message of layer l+1, one launch",

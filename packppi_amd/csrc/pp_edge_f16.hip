@@ -1204,7 +1204,8 @@ pp_status pp_launch_edge_static(pp_ctx *c, hipStream_t s) {
 pp_status pp_launch_node_message(pp_ctx *c, int layer, hipStream_t s) {
     EDGE_ATTR_CHECK()
     EdgeArgs A = edge_args(c, layer, false);
-    const int R = pick_R(c->N);
+    static const int nm_R = getenv("PP_NM_R") ? atoi(getenv("PP_NM_R")) : 0;       // measurement aid: residues per workgroup of this kernel only
+    const int R = (nm_R >= 1 && nm_R <= PP_RMAX) ? nm_R : pick_R(c->N);
     PP_LAUNCH(c, nm_kernel_r(R, layer == 0), dim3((c->N + R - 1) / R), dim3(ET), nm_smem(R), s, A);
     PP_HIP_CHECK(hipGetLastError());
     return PP_OK;

@@ -1,0 +1,32 @@
+#!/bin/bash
+# Runs on the GPU box: L2 hit / miss counters of the hot kernels for one workload (is the per-workgroup weight stream served
+# from the XCD's L2, or does the h_E stream evict it?).   bash tools/profile/run_tcc.sh <workload> [extra bench flags]
+set -e
+ROOT=$(pwd)
+WL=${1:-t1124}; shift || true
+OUT=$ROOT/gpurun_out/tcc_$WL
+mkdir -p $OUT
+export TMPDIR=/tmp
+cd /tmp
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum --output-format csv -d $OUT/p1 -o run -- python3 $ROOT/bench.py --workload $WL --steps 1 --warmup 1 --cpu-steps 0 --no-secondary "$@" > $OUT/p1.json 2> $OUT/p1.err || echo "pass failed: $(tail -2 $OUT/p1.err)"
+cd $ROOT; find $OUT -type f ! -name "*counter_collection.csv" ! -name "*.err" -delete
+python3 - $OUT $WL <<'PY'
+import csv, glob, collections, json, os, sys
+out = {}
+for f in sorted(glob.glob(sys.argv[1] + "/p*/**/*counter_collection.csv", recursive=True)):
+    agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0][:40]
+        agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[(k, r["Counter_Name"])] += 1
+    for k in agg:
+        if "edge_update" in k or "node_message" in k or "node_update" in k:
+            d = {c: v / cnt[(k, c)] for c, v in agg[k].items()}
+            hit = d.get("TCC_HIT_sum", 0) / max(d.get("TCC_HIT_sum", 0) + d.get("TCC_MISS_sum", 0), 1)
+            print(k, {c: round(v) for c, v in d.items()}, "L2 hit rate %.3f" % hit)
+            out[k.replace("void ", "")] = {"launches": cnt[(k, "TCC_REQ_sum")], "l2_requests": d.get("TCC_REQ_sum", 0), "l2_hits": d.get("TCC_HIT_sum", 0),
+                                           "l2_misses": d.get("TCC_MISS_sum", 0), "l2_hit_rate": hit,
+                                           "l2_request_bytes": 128.0 * d.get("TCC_REQ_sum", 0)}
+tag = os.environ.get("PROFILE_TAG", "r03_v1")
+json.dump({"command": "rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum -- python3 bench.py --workload %s --steps 1 --warmup 1 --cpu-steps 0 --no-secondary" % sys.argv[2],
+           "request_size_bytes": 128, "kernels": out}, open(os.path.join("profiles", "%s_tcc_%s.json" % (tag, sys.argv[2])), "w"), indent=1)
+PY
