@@ -75,7 +75,7 @@ typedef struct pp_batch {
 int pp_version(void);
 const char *pp_last_error(void);
 
-/* Build stamp: "<sources>-<flags>", two 16-digit hex prefixes of the SHA-256 of (a) every file of packppi_amd/csrc/*.hip|*.h
+/* Build stamp: "<sources>-<flags>", two 16-digit hex prefixes of the SHA-256 of (a) every .hip / .h file of packppi_amd/csrc
  * plus this header, (b) the compiler flags, as computed by packppi_amd/build.py when the library was compiled.  The Python
  * binding refuses a library whose <sources> part differs from the sources on disk (a stale prebuilt .so). */
 const char *pp_build_id(void);

@@ -91,7 +91,11 @@ __device__ __forceinline__ void split_tile(const f32x16 &v, HT &o, unsigned &sat
                 x[1] = __builtin_amdgcn_fmed3f(x[1], 0.f, 65504.f);
             }
             const h2v hh = cvt2(x);
+#ifndef PP_X_NOSAT     /* A/B aid: build without the sticky-flag bookkeeping */
             if (RELU)      // sticky saturation flag: running maximum of the clamped halves (v_pk_max_u16), see pp_internal.h
+#else
+            if (false)
+#endif
                 sat = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(us2v, sat), __builtin_bit_cast(us2v, hh)));
             const f32x2v d = split_residual(hh, x);
             const h2v ll = cvt2(d);

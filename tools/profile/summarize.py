@@ -12,7 +12,7 @@ import os
 import sys
 from collections import defaultdict
 
-ROUND = os.environ.get("GRAFT_ROUND", "r02")
+ROUND = os.environ.get("GRAFT_ROUND", "r03")
 
 
 def short(name):
