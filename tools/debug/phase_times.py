@@ -26,9 +26,16 @@ for layer in (0, 1):
         dbg.zero_()
         assert l.pp_debug_edge(ctx.handle, layer, None) == 0
         torch.cuda.synchronize()
-    t = dbg.cpu()[:, :18]
-    t = t[t[:, 17] > 0]
-    d = torch.diff(torch.cat([torch.zeros(t.shape[0], 1), t], 1), dim=1)
-    print("layer %d: %d workgroups, mean total %.0f cycles" % (layer, t.shape[0], t[:, 17].mean()))
-    for i, nm in enumerate(names):
-        print("   %-40s %7.0f cycles  (%4.1f %%)" % (nm, d[:, i].mean(), 100 * d[:, i].mean() / t[:, 17].mean()))
+    t_all = dbg.cpu()[:, :18]
+    npairs = (L + 2) // 3
+    rows = torch.arange(L)
+    groups = {"two-residue workgroups / team 0": (rows < 2 * npairs) & (t_all[:, 17] > 0),
+              "one-residue workgroups / team 1": (rows >= 2 * npairs) & (t_all[:, 17] > 0)}
+    for gname, sel in groups.items():
+        t = t_all[sel]
+        if not len(t):
+            continue
+        d = torch.diff(torch.cat([torch.zeros(t.shape[0], 1), t], 1), dim=1)
+        print("layer %d, %s: %d, mean total %.0f cycles" % (layer, gname, t.shape[0], t[:, 17].mean()))
+        for i, nm in enumerate(names):
+            print("   %-40s %7.0f cycles  (%4.1f %%)" % (nm, d[:, i].mean(), 100 * d[:, i].mean() / t[:, 17].mean()))
