@@ -641,16 +641,13 @@ k_node_message(EdgeArgs A) {
 // FUSE: the workgroup goes straight on to the NEXT layer's node message of its residues (same edges, whose new h_E it
 // holds; the node-level inputs PA2 / PC2 / pts2 were written by the node update that ran before this kernel): one
 // launch, one prologue and one read of h_E less per layer.
-// DUO: the body runs as one of the two four-wave TEAMS of a 512-thread workgroup (k_edge_update_duo below): thread ids are
-// team-local, every __syncthreads() is the workgroup's (both teams meet at every phase boundary), and a team whose residues
-// are all masked or out of range must not leave early -- it computes on a valid row and stores nothing.
-template <int R, bool ST0, bool FUSE, int NXB_ = (R == 1 ? PP_NXB_R1 : 1), bool DUO = false>
+template <int R, bool ST0, bool FUSE>
 __device__ __forceinline__ void edge_update_body(const EdgeArgs &A, const int res0, float *smem) {
-    constexpr int NXB = NXB_;
+    constexpr int NXB = R == 1 ? PP_NXB_R1 : 1;
     float *const xb0 = smem;
     float *xbuf = xb0, *x1buf = smem + NXB * R * XBUF_FLOATS, *stat = x1buf + R * XBUF_FLOATS,
           *prm = stat + R * STAT_FLOATS;
-    const int tid = DUO ? (threadIdx.x & (ET - 1)) : threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, h = lane >> 5;
     const int K = A.K;
@@ -671,10 +668,7 @@ __device__ __forceinline__ void edge_update_body(const EdgeArgs &A, const int re
                 if (tid == 0) A.msum[n[r]] = 0.f;
             }
         }
-    if (first < 0) {
-        if constexpr (DUO) first = n[0];       // keep the team in step with the other one: compute on a valid row, store nothing
-        else return;
-    }
+    if (first < 0) return;
 #pragma unroll
     for (int r = 0; r < R; r++)
         if (!live[r]) n[r] = first;
@@ -883,33 +877,6 @@ k_edge_update_mix(EdgeArgs A) {
 #endif
     if (pair >= 0) edge_update_body<2, ST0, FUSE>(A, 2 * pair, smem);
     else edge_update_body<1, ST0, FUSE>(A, 2 * A.n_pairs + single, smem);
-}
-
-// EXPERIMENT (PP_EDGE_DUO=1; measured slower): PING-PONG launch -- one 512-thread workgroup per CU made of
-// two four-wave TEAMS, each running the edge update of its own residues with its own LDS block, offset by ONE phase.  The chain of
-// a team alternates between a matrix phase (the 4 .. 8 weight stages of a layer: only MFMAs, weight fetches and B-operand reads)
-// and an exchange phase (ReLU / split / publish or a LayerNorm: VALU and LDS work, no MFMA), with a workgroup barrier at every
-// phase boundary.  Team 1 enters the chain one barrier late, and because every barrier is the whole workgroup's, the two teams stay
-// exactly one phase apart: whenever one team exchanges, the other one feeds the matrix pipe.  Same arithmetic per residue as
-// k_edge_update<R> (the bodies are the same code): results are bit-identical to the other launch shapes.
-//   A.n_pairs > 0 : team 0 = residues (2 b, 2 b + 1), team 1 = residue 2 n_pairs + b   (three residues per CU: one complex)
-//   A.n_pairs == 0: team t = residues (4 b + 2 t, 4 b + 2 t + 1)                        (four residues per workgroup)
-#define DUO_TEAM_FLOATS ((2 * 2 * XBUF_FLOATS) + 2 * STAT_FLOATS + PARAM_LDS)
-template <bool ST0, bool FUSE>
-__global__ void __launch_bounds__(2 * ET, 1)
-k_edge_update_duo(EdgeArgs A) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int team = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));
-    float *tsm = smem + team * DUO_TEAM_FLOATS;
-    const int b = blockIdx.x;
-    if (team == 1) __syncthreads();                   // one phase behind team 0
-    if (A.n_pairs > 0) {
-        if (team == 0) edge_update_body<2, ST0, FUSE, 1, true>(A, 2 * b, tsm);
-        else edge_update_body<1, ST0, FUSE, 1, true>(A, 2 * A.n_pairs + b, tsm);
-    } else {
-        edge_update_body<2, ST0, FUSE, 1, true>(A, 4 * b + 2 * team, tsm);
-    }
-    if (team == 0) __syncthreads();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1179,9 +1146,7 @@ static bool edge_attrs() {
                 ok = set(reinterpret_cast<const void *>(nm_kernel_r(R, st0)), MAX_SMEM) &&
                      set(reinterpret_cast<const void *>(eu_kernel_r(R, st0)), MAX_SMEM);
         ok = ok && set(reinterpret_cast<const void *>(k_edge_update_mix<true, PP_FUSED>), MAX_SMEM) &&
-             set(reinterpret_cast<const void *>(k_edge_update_mix<false, PP_FUSED>), MAX_SMEM) &&
-             set(reinterpret_cast<const void *>(k_edge_update_duo<true, PP_FUSED>), MAX_SMEM) &&
-             set(reinterpret_cast<const void *>(k_edge_update_duo<false, PP_FUSED>), MAX_SMEM);
+             set(reinterpret_cast<const void *>(k_edge_update_mix<false, PP_FUSED>), MAX_SMEM);
         int dev = 0;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
@@ -1260,16 +1225,6 @@ pp_status pp_launch_edge_update(pp_ctx *c, int layer, hipStream_t s) {
     if (layer < 0 || layer > 1) { pp_set_error("pp_launch_edge_update: layer must be 0 or 1"); return PP_ERR_INVALID; }
     EdgeArgs A = edge_args(c, layer, true);
     const int R = pick_R(c->N);
-    static const int duo = getenv("PP_EDGE_DUO") ? atoi(getenv("PP_EDGE_DUO")) : 0;      // experiment: ping-pong teams (k_edge_update_duo)
-    if (duo && g_forced_R < 1 && c->N > 2 * g_num_cu) {
-        const bool three = c->N <= 3 * g_num_cu;           // one complex that fills the chip once: pair + single per workgroup
-        A.n_pairs = three ? (c->N + 2) / 3 : 0;
-        const int wgs = three ? A.n_pairs : (c->N + 3) / 4;
-        PP_LAUNCH(c, (layer == 0 ? k_edge_update_duo<true, PP_FUSED> : k_edge_update_duo<false, PP_FUSED>), dim3(wgs), dim3(2 * ET),
-                  2 * DUO_TEAM_FLOATS * sizeof(float), s, A);
-        PP_HIP_CHECK(hipGetLastError());
-        return PP_OK;
-    }
     if (use_mix(c->N)) {
         // three residues per CU as one two-residue and one one-residue workgroup
         A.n_pairs = (c->N + 2) / 3;
