@@ -1,6 +1,6 @@
 #!/bin/bash
 # GPU box: the default library against the variant built without the sticky-flag bookkeeping (-DPP_X_NOSAT), interleaved, three
-# workloads:  bash tools/debug/ab_sat.sh
+# workloads.  Build the variant first: PACKPPI_VARIANT_SOURCES="pp_edge_f16.hip pp_api.hip" python -m packppi_amd.build --tag nosat -DPP_X_NOSAT ;  bash tools/debug/ab_sat.sh
 for rep in 1 2; do
   for so in libpackppi_hip.so libpackppi_hip.nosat.so; do
     for wl in t1124 s1500; do
