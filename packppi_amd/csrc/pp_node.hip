@@ -803,366 +803,6 @@ k_node_update(NUpdArgs A, float *chi, int step, int sde, const float *noise, int
     }
 }
 
-// ==================================================================================================================
-// The same node update for a workgroup of NW = 4 waves (256 threads): every wave plays TWO of the eight roles of
-// k_node_update -- role q of wave w is "wave" wv = w + 4 q of the kernel above (same weight slots, same feature tiles, same
-// LayerNorm partials), the two roles of a wave take turns inside every phase and meet the other waves at the same barriers.
-// Arithmetic and summation order per output are those of the 8-wave kernel: results are bit-identical.  (Experiment of round
-// 3: the shape a node update would have to take to run as the tail of an edge-update workgroup; PP_NU_WAVES=4 launches it
-// on its own.)
-// ==================================================================================================================
-__device__ __forceinline__ void ln128_partial(float (*st)[16][2], int wv, int r, int g, const nf4 &x) {
-    const float mw = xsum_g((x[0] + x[1]) + (x[2] + x[3])) * (1.f / 16.f);
-    const nf4 d = x - mw;
-    const float qw = xsum_g(fmaf(d[0], d[0], d[1] * d[1]) + fmaf(d[2], d[2], d[3] * d[3]));
-    if (g == 0) *reinterpret_cast<nf2 *>(st[wv][r]) = nf2{mw, qw};
-}
-__device__ __forceinline__ nf4 ln128_finish(float (*st)[16][2], int r, const nf4 &x, const nf4 &gain, const nf4 &beta) {
-    float m8[8], msum = 0.f, qsum = 0.f;
-#pragma unroll
-    for (int v = 0; v < 8; v++) {
-        const nf2 t = *reinterpret_cast<const nf2 *>(st[v][r]);
-        m8[v] = t[0];
-        msum += t[0];
-        qsum += t[1];
-    }
-    const float mean = msum * 0.125f;
-    float dm = 0.f;
-#pragma unroll
-    for (int v = 0; v < 8; v++) dm = fmaf(m8[v] - mean, m8[v] - mean, dm);
-    const float var = fmaf(16.f, dm, qsum) * (1.f / 128.f);
-    const float rstd = 1.f / sqrtf(var + 1e-5f);
-    return (x - mean) * rstd * gain + beta;
-}
-
-#define ROLES 2
-#define ROLE_LOOP _Pragma("unroll") for (int role = 0; role < ROLES; role++)
-#define ROLE_VARS                                                \
-    const int wv = wave + 4 * role;                              \
-    const int fc = 16 * wv + 4 * g;                              \
-    const nh8 *wq = wqr[role];                                   \
-    AOpN(&AR)[NU_NRING] = ARr[role];                             \
-    (void)fc; (void)wq; (void)AR;
-
-template <int MODE, int NU_ND>
-__global__ void __launch_bounds__(256)
-k_node_update4(NUpdArgs A, float *chi, int step, int sde, const float *noise, int embed_next, StepScalars sp, TimeEmb te_next) {
-    constexpr int NU_NRING = NU_ND + 1;
-    constexpr bool LAST = MODE != PP_NU_MID;
-    constexpr int NSLOT = LAST ? PP_NU_SLOTS_LAST : PP_NU_SLOTS_MID;
-    constexpr int NLOAD = MODE == PP_NU_SCORE ? 46 : NSLOT;
-    constexpr int NPAR = LAST ? NU_P_LAST_TOTAL : NU_P_MID_TOTAL;
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    SmemU &sm = *reinterpret_cast<SmemU *>(smem_raw);
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r = lane & 15, g = lane >> 4, N = A.N, n0 = blockIdx.x * 16;
-    const int n = n0 + r, nc = n < N ? n : N - 1;
-    const bool live = n < N;
-    const float *par = sm.par;
-    const nf4 zero4 = {0.f, 0.f, 0.f, 0.f};
-
-    // ---- inputs ------------------------------------------------------------------------------------------------------
-    nf4 s4[2], hv4[ROLES];
-#pragma unroll
-    for (int it = 0; it < 2; it++) {
-        const int srow = (tid >> 5) + 8 * it, scol = (tid & 31) * 4, sn = n0 + srow < N ? n0 + srow : N - 1;
-        s4[it] = *reinterpret_cast<const nf4 *>(A.S + (size_t)sn * 128 + scol);
-    }
-    ROLE_LOOP hv4[role] = *reinterpret_cast<const nf4 *>(A.hV + (size_t)nc * 128 + 16 * (wave + 4 * role) + 4 * g);
-    const float ms = A.msum[nc], rm = A.rmask[nc];
-    float chi1 = 0.f, scm1 = 0.f, nz1 = 0.f, nz2 = 0.f;
-    bool p1 = false, p2 = false;
-    int rt = 0;
-    nf4 spv = zero4;
-    if constexpr (MODE == PP_NU_STEP) {
-        if (wave == 0) {
-            spv = nf4{sp.c_ode, sp.w, sp.c_drift, sp.c_diff};
-            chi1 = chi[(size_t)nc * 4 + g];
-            scm1 = A.sc_mask[(size_t)nc * 4 + g];
-            p1 = A.m1pi[(size_t)nc * 4 + g] != 0;
-            p2 = A.m2pi[(size_t)nc * 4 + g] != 0;
-            if (sde) {
-                const size_t NN = (size_t)N * 4;
-                const float *nz = noise + (size_t)step * 2 * NN + (size_t)nc * 4 + g;
-                nz1 = nz[0];
-                nz2 = nz[NN];
-            }
-        }
-        if (embed_next) rt = (int)A.rtype[nc];
-    }
-    nf4 tailv = zero4;
-    nf4 ev[4] = {zero4, zero4, zero4, zero4};
-    const int erow = tid & 15, ern = n0 + erow < N ? n0 + erow : N - 1;
-    const bool e_bb = MODE == PP_NU_STEP && tid >= 128 && tid < 144, e_te = MODE == PP_NU_STEP && tid >= 192 && tid < 208;
-    if (tid < 48) {
-        const int row = tid / 3, rn = n0 + row < N ? n0 + row : N - 1;
-        tailv = *reinterpret_cast<const nf4 *>(A.frames + (size_t)rn * 12 + 4 * (tid - 3 * row));
-    } else if (e_bb) {
-        if (embed_next) {
-            const nf2 *bp = reinterpret_cast<const nf2 *>(A.bb_sincos + (size_t)ern * 6);
-            const nf2 b0 = bp[0], b1 = bp[1], b2 = bp[2];
-            ev[0] = nf4{b0[0], b0[1], b1[0], b1[1]};
-            ev[1] = nf4{b2[0], b2[1], 0.f, 0.f};
-        }
-    } else if (e_te) {
-        if (embed_next) {
-#pragma unroll
-            for (int k = 0; k < 16; k++) ev[k >> 2][k & 3] = te_next.v[k];
-        }
-    }
-    constexpr int NPV = (NPAR / 4 + 255) / 256;
-    nf4 pv[NPV];
-#pragma unroll
-    for (int i = 0; i < NPV; i++) {
-        const int q = tid + 256 * i;
-        pv[i] = reinterpret_cast<const nf4 *>(A.params)[q < NPAR / 4 ? q : 0];
-    }
-    // ---- both roles' weight streams -----------------------------------------------------------------------------------
-    const nh8 *wqr[ROLES];
-    AOpN ARr[ROLES][NU_NRING];
-    ROLE_LOOP {
-        wqr[role] = reinterpret_cast<const nh8 *>(A.wstream) + (size_t)(wave + 4 * role) * NSLOT * 128 + lane;
-#pragma unroll
-        for (int k = 0; k < NU_ND; k++) gload_N(wqr[role], k, ARr[role][k]);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = 0; i < NPV; i++) {
-        const int q = tid + 256 * i;
-        if (q < NPAR / 4) reinterpret_cast<nf4 *>(sm.par)[q] = pv[i];
-    }
-    nf4 oh4[ROLES] = {zero4, zero4};
-    if constexpr (MODE == PP_NU_STEP) {
-        if (embed_next) ROLE_LOOP oh4[role] = *reinterpret_cast<const nf4 *>(A.embT + (size_t)rt * 128 + 16 * (wave + 4 * role) + 4 * g);
-    }
-    if (tid < 48) reinterpret_cast<nf4 *>(&sm.fr[0][0])[tid] = tailv;
-    else if (e_bb) {
-        publish4(sm.e_hi, sm.e_lo, erow * NU_S32, ev[0]);
-        publish4(sm.e_hi, sm.e_lo, erow * NU_S32 + 4, ev[1]);
-    } else if (e_te) {
-        publish4(sm.e_hi, sm.e_lo, erow * NU_S32 + 12, nf4{0.f, 0.f, ev[0][0], ev[0][1]});
-        publish4(sm.e_hi, sm.e_lo, erow * NU_S32 + 16, nf4{ev[0][2], ev[0][3], ev[1][0], ev[1][1]});
-        publish4(sm.e_hi, sm.e_lo, erow * NU_S32 + 20, nf4{ev[1][2], ev[1][3], ev[2][0], ev[2][1]});
-        publish4(sm.e_hi, sm.e_lo, erow * NU_S32 + 24, nf4{ev[2][2], ev[2][3], ev[3][0], ev[3][1]});
-        publish4(sm.e_hi, sm.e_lo, erow * NU_S32 + 28, nf4{ev[3][2], ev[3][3], 0.f, 0.f});
-    }
-#pragma unroll
-    for (int it = 0; it < 2; it++) publish4(sm.a_hi, sm.a_lo, ((tid >> 5) + 8 * it) * NU_S128 + (tid & 31) * 4, s4[it]);
-    __syncthreads();
-
-    nh8 bh[4], bl[4];
-    nf4 cH, cL;
-    float satm = 0.f;
-    nf4 x[ROLES], h1[ROLES], h2[ROLES];
-    // ---- W_out on the masked mean S, LayerNorm ----------------------------------------------------------------------------
-    LDB4(sm.a_hi, sm.a_lo)
-    ROLE_LOOP {
-        ROLE_VARS
-        cH = zero4; cL = zero4;
-        NTILE4(0, cH, cL)
-        x[role] = fold(cH, cL) + *reinterpret_cast<const nf4 *>(par + NU_P_OUTB + fc) * ms + hv4[role];
-        ln128_partial(sm.stats[0], wv, r, g, x[role]);
-    }
-    __syncthreads();
-    ROLE_LOOP {
-        ROLE_VARS
-        h1[role] = ln128_finish(sm.stats[0], r, x[role], *reinterpret_cast<const nf4 *>(par + NU_P_G0 + fc),
-                                *reinterpret_cast<const nf4 *>(par + NU_P_B0 + fc));
-        publish4(sm.b_hi, sm.b_lo, r * NU_S128 + fc, h1[role]);
-    }
-    __syncthreads();
-    // ---- FFN 128 -> 512 ------------------------------------------------------------------------------------------------------
-    LDB4(sm.b_hi, sm.b_lo)
-    ROLE_LOOP {
-        ROLE_VARS
-        FFN_IN_TILE(0) FFN_IN_TILE(1) FFN_IN_TILE(2) FFN_IN_TILE(3)
-    }
-    if (!(satm < 65504.f)) atomicOr(A.sat, 2u);
-    __syncthreads();
-    // ---- FFN 512 -> 128, LayerNorm, mask ---------------------------------------------------------------------------------
-    ROLE_LOOP {
-        ROLE_VARS
-        nh8 fh[2], fl[2];
-        ldB(sm.c_hi, sm.c_lo, r * NU_S512 + 8 * g, 0, fh[0], fl[0]);
-        cH = zero4; cL = zero4;
-        FOSTAGE(0) FOSTAGE(1) FOSTAGE(2) FOSTAGE(3) FOSTAGE(4) FOSTAGE(5) FOSTAGE(6) FOSTAGE(7)
-        FOSTAGE(8) FOSTAGE(9) FOSTAGE(10) FOSTAGE(11) FOSTAGE(12) FOSTAGE(13) FOSTAGE(14) FOSTAGE(15)
-        x[role] = fold(cH, cL) + *reinterpret_cast<const nf4 *>(par + NU_P_FOB + fc) + h1[role];
-        ln128_partial(sm.stats[1], wv, r, g, x[role]);
-    }
-    __syncthreads();
-    ROLE_LOOP {
-        ROLE_VARS
-        h2[role] = ln128_finish(sm.stats[1], r, x[role], *reinterpret_cast<const nf4 *>(par + NU_P_G1 + fc),
-                                *reinterpret_cast<const nf4 *>(par + NU_P_B1 + fc)) * rm;
-        if (live && (MODE != PP_NU_STEP || !embed_next)) *reinterpret_cast<nf4 *>(A.hV + (size_t)n * 128 + fc) = h2[role];
-        publish4(sm.a_hi, sm.a_lo, r * NU_S128 + fc, h2[role]);
-    }
-    __syncthreads();
-    LDB4(sm.a_hi, sm.a_lo)
-
-    if constexpr (!LAST) {
-        ROLE_LOOP {
-            ROLE_VARS
-            cH = zero4; cL = zero4;
-            NTILE4(36, cH, cL)
-            if (live) *reinterpret_cast<nf4 *>(A.PAe + (size_t)n * 128 + fc) = fold(cH, cL) + *reinterpret_cast<const nf4 *>(par + NU_P_PAE_B + fc);
-            cH = zero4; cL = zero4;
-            NTILE4(40, cH, cL)
-            if (live) *reinterpret_cast<nf4 *>(A.PCe + (size_t)n * 128 + fc) = fold(cH, cL);
-            cH = zero4; cL = zero4;
-            NTILE4(44, cH, cL)
-            if (live) *reinterpret_cast<nf4 *>(A.PAn + (size_t)n * 128 + fc) = fold(cH, cL) + *reinterpret_cast<const nf4 *>(par + NU_P_PAN_B + fc);
-            cH = zero4; cL = zero4;
-            NTILE4(48, cH, cL)
-            if (live) *reinterpret_cast<nf4 *>(A.PCn + (size_t)n * 128 + fc) = fold(cH, cL);
-            cH = zero4; cL = zero4;
-            NTILE4_IF(52, wv < 3, cH, cL)
-            if (wv < 3) {
-                const nf4 p = fold(cH, cL) + *reinterpret_cast<const nf4 *>(par + NU_P_PTS_B + fc);
-                *reinterpret_cast<nf4 *>(&sm.pts[r][fc]) = p;
-                if (live) {
-                    if (fc < 24) *reinterpret_cast<nf4 *>(A.ptsE + (size_t)n * 48 + fc) = p;
-                    else *reinterpret_cast<nf4 *>(A.ptsN + (size_t)n * 48 + fc - 24) = p;
-                }
-            }
-        }
-        __syncthreads();
-        {
-            const int mm = tid >> 7, q = (tid >> 4) & 7, i = tid & 15, ni = n0 + i;
-            if (ni < N) {
-                float *pts = mm == 0 ? A.ptsE : A.ptsN;
-                const float *fr = sm.fr[i];
-                const float px = sm.pts[i][24 * mm + 3 * q], py = sm.pts[i][24 * mm + 3 * q + 1], pz = sm.pts[i][24 * mm + 3 * q + 2];
-#pragma unroll
-                for (int rr = 0; rr < 3; rr++)
-                    pts[(size_t)ni * 48 + 24 + 3 * q + rr] = (fr[3 * rr] * px + fr[3 * rr + 1] * py + fr[3 * rr + 2] * pz) + fr[9 + rr];
-            }
-        }
-        return;
-    } else {
-        // ---- decoder: the four waves' first role (wv 0..3) own the 64 hidden units; the second role only keeps its stream going
-        nf4 dH = zero4, dL = zero4;
-        ROLE_LOOP {
-            ROLE_VARS
-            cH = zero4; cL = zero4;
-            NTILE4_IF(36, wv < 4, cH, cL)
-            if (wv < 4) publish4(sm.c_hi, sm.c_lo, r * NU_S512 + fc, relu_sat(fold(cH, cL) + *reinterpret_cast<const nf4 *>(par + NU_P_DB0 + fc), satm));
-        }
-        __syncthreads();
-        ROLE_LOOP {
-            ROLE_VARS
-            const bool w0 = wv == 0;
-            nh8 dh[2], dl[2];
-            if (w0) {
-                ldB(sm.c_hi, sm.c_lo, r * NU_S512 + 8 * g, 0, dh[0], dl[0]);
-                ldB(sm.c_hi, sm.c_lo, r * NU_S512 + 8 * g, 1, dh[1], dl[1]);
-            }
-            nf4 eH = zero4, eL = zero4;
-            cH = zero4; cL = zero4;
-            NSTAGE_IF(40, w0, cH, mm3(AK, dh[0], dl[0], cH, cL))
-            NSTAGE_IF(41, w0, cH, mm3(AK, dh[1], dl[1], cH, cL))
-            NSTAGE_IF(42, w0, eH, mm3(AK, dh[0], dl[0], eH, eL))
-            NSTAGE_IF(43, w0, eH, mm3(AK, dh[1], dl[1], eH, eL))
-            if (w0) {
-                publish4(sm.c_hi, sm.c_lo, r * NU_S512 + 64 + 4 * g, relu_sat(fold(cH, cL) + *reinterpret_cast<const nf4 *>(par + NU_P_DB1 + 4 * g), satm));
-                publish4(sm.c_hi, sm.c_lo, r * NU_S512 + 80 + 4 * g, relu_sat(fold(eH, eL) + *reinterpret_cast<const nf4 *>(par + NU_P_DB1 + 16 + 4 * g), satm));
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                ldB(sm.c_hi, sm.c_lo, r * NU_S512 + 8 * g, 2, dh[0], dl[0]);
-            }
-            cH = zero4; cL = zero4;
-            NSTAGE_IF(44, w0, cH, mm3(AK, dh[0], dl[0], cH, cL))
-            if (w0) {
-                publish4(sm.c_hi, sm.c_lo, r * NU_S512 + 96 + 4 * g, relu_sat(fold(cH, cL) + *reinterpret_cast<const nf4 *>(par + NU_P_DB2 + 4 * g), satm));
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                ldB(sm.c_hi, sm.c_lo, r * NU_S512 + 8 * g, 3, dh[0], dl[0]);
-            }
-            cH = zero4; cL = zero4;
-            NSTAGE_IF(45, w0, cH, mm3(AK, dh[0], dl[0], cH, cL))
-            if (w0) { dH = cH; dL = cL; }
-        }
-        if (wave == 0) {
-            if (!(satm < 65504.f)) atomicOr(A.sat, 2u);
-            const nf4 sc = fold(dH, dL) + *reinterpret_cast<const nf4 *>(par + NU_P_DB3);
-            if (g == 0 && live) *reinterpret_cast<nf4 *>(A.score + (size_t)n * 4) = sc;
-            if constexpr (MODE == PP_NU_STEP) {
-                const float s0 = __shfl(sc[0], r), s1 = __shfl(sc[1], r), s2 = __shfl(sc[2], r), s3 = __shfl(sc[3], r);
-                const float sg = g == 0 ? s0 : g == 1 ? s1 : g == 2 ? s2 : s3;
-                const float sp_c_ode = spv[0], sp_w = spv[1], sp_c_drift = spv[2], sp_c_diff = spv[3];
-                const float sw = sg * sp_w;
-                float yk = chi1;
-                if (!sde) {
-                    if (p1 || p2) yk = chi1 + sp_c_ode * sw;
-                } else {
-                    if (p1) yk = chi1 + (sp_c_drift * sw + sp_c_diff * nz1);
-                    if (p2) yk = yk + (sp_c_drift * sw + sp_c_diff * nz2);
-                }
-                const float y = wrap_pi(yk) * scm1;
-                if (live) chi[(size_t)n * 4 + g] = y;
-                if (embed_next) {
-                    unsigned hp, lp;
-                    split2(sinf(y) * scm1, cosf(y) * scm1, hp, lp);
-                    *reinterpret_cast<unsigned *>(sm.e_hi + r * NU_S32 + 6 + 2 * g) = hp;
-                    *reinterpret_cast<unsigned *>(sm.e_lo + r * NU_S32 + 6 + 2 * g) = lp;
-                }
-            }
-        }
-        if constexpr (MODE != PP_NU_STEP) return;
-        if (!embed_next) return;
-        __syncthreads();
-        nh8 eh, el;
-        eh = *reinterpret_cast<const nh8 *>(sm.e_hi + r * NU_S32 + 8 * g);
-        el = *reinterpret_cast<const nh8 *>(sm.e_lo + r * NU_S32 + 8 * g);
-        nf4 e0[ROLES], h0[ROLES];
-        ROLE_LOOP {
-            ROLE_VARS
-            cH = zero4; cL = zero4;
-            NSTAGE(46, cH, mm3(AK, eh, el, cH, cL))
-            e0[role] = fold(cH, cL) + (*reinterpret_cast<const nf4 *>(par + NU_P_EMB_B + fc) + oh4[role]);
-            ln128_partial(sm.stats[2], wv, r, g, e0[role]);
-        }
-        __syncthreads();
-        ROLE_LOOP {
-            ROLE_VARS
-            h0[role] = ln128_finish(sm.stats[2], r, e0[role], *reinterpret_cast<const nf4 *>(par + NU_P_EMB_G + fc),
-                                    *reinterpret_cast<const nf4 *>(par + NU_P_EMB_BETA + fc));
-            if (live) *reinterpret_cast<nf4 *>(A.hV + (size_t)n * 128 + fc) = h0[role];
-            publish4(sm.b_hi, sm.b_lo, r * NU_S128 + fc, h0[role]);
-        }
-        __syncthreads();
-        LDB4(sm.b_hi, sm.b_lo)
-        ROLE_LOOP {
-            ROLE_VARS
-            cH = zero4; cL = zero4;
-            NTILE4(47, cH, cL)
-            if (live) *reinterpret_cast<nf4 *>(A.PAn + (size_t)n * 128 + fc) = fold(cH, cL) + *reinterpret_cast<const nf4 *>(par + NU_P_PAN0_B + fc);
-            cH = zero4; cL = zero4;
-            NTILE4(51, cH, cL)
-            if (live) *reinterpret_cast<nf4 *>(A.PCn + (size_t)n * 128 + fc) = fold(cH, cL);
-            if (wv < 2) {
-                cH = zero4; cL = zero4;
-                NTILE4(55, cH, cL)
-                if (fc < 24) {
-                    const nf4 p = fold(cH, cL) + *reinterpret_cast<const nf4 *>(par + NU_P_PTS0_B + fc);
-                    *reinterpret_cast<nf4 *>(&sm.pts[r][fc]) = p;
-                    if (live) *reinterpret_cast<nf4 *>(A.ptsN + (size_t)n * 48 + fc) = p;
-                }
-            }
-        }
-        __syncthreads();
-        if (tid < 128) {
-            const int q = tid >> 4, i = tid & 15, ni = n0 + i;
-            if (ni < N) {
-                const float *fr = sm.fr[i];
-                const float px = sm.pts[i][3 * q], py = sm.pts[i][3 * q + 1], pz = sm.pts[i][3 * q + 2];
-#pragma unroll
-                for (int rr = 0; rr < 3; rr++)
-                    A.ptsN[(size_t)ni * 48 + 24 + 3 * q + rr] = (fr[3 * rr] * px + fr[3 * rr + 1] * py + fr[3 * rr + 2] * pz) + fr[9 + rr];
-            }
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
 static NodeArgs make_args(pp_ctx *c) {
     const pp_plan *p = c->plan;
@@ -1275,21 +915,6 @@ pp_status pp_launch_node_update(pp_ctx *c, int layer, int last_mode, float *chi,
     if (cur) sp = {cur->c_ode, cur->w, cur->c_drift, cur->c_diff};
     if (next) memcpy(te.v, next->temb, sizeof(te.v));
     const bool multi = (int)grid.x > g_nu_cus;
-    static const int nu_waves = getenv("PP_NU_WAVES") ? atoi(getenv("PP_NU_WAVES")) : 8;      // experiment: the 4-wave form on its own
-    if (nu_waves == 4) {
-        const nu_kernel_t k4 = last_mode == PP_NU_MID ? k_node_update4<PP_NU_MID, PP_NU_DEPTH_MULTI>
-                               : last_mode == PP_NU_STEP ? k_node_update4<PP_NU_STEP, PP_NU_DEPTH_MULTI> : k_node_update4<PP_NU_SCORE, PP_NU_DEPTH_MULTI>;
-        static bool attr4 = false;
-        if (!attr4) {
-            PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_node_update4<PP_NU_MID, PP_NU_DEPTH_MULTI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SmemU)));
-            PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_node_update4<PP_NU_STEP, PP_NU_DEPTH_MULTI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SmemU)));
-            PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_node_update4<PP_NU_SCORE, PP_NU_DEPTH_MULTI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SmemU)));
-            attr4 = true;
-        }
-        PP_LAUNCH(c, k4, grid, dim3(256), sizeof(SmemU), s, A, chi, step, sde, noise, embed_next, sp, te);
-        PP_HIP_CHECK(hipGetLastError());
-        return PP_OK;
-    }
     const nu_kernel_t kern = nu_kernel(last_mode == PP_NU_MID ? 0 : last_mode == PP_NU_STEP ? 1 : 2, multi);
     PP_LAUNCH(c, kern, grid, block, sizeof(SmemU), s, A, chi, step, sde, noise, embed_next, sp, te);
     PP_HIP_CHECK(hipGetLastError());
