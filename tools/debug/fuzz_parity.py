@@ -1,0 +1,108 @@
+"""Randomised parity sweep (GPU box): random sizes, random mid-chain masked residues, padded batches of random composition,
+packed batches, short complexes (K < 32), a few sampling steps each -- the HIP path against the CPU oracle (pinned to the
+reference) at the 1e-4 rad bar, plus atom14 / clash at fp32 rounding.   python tools/debug/fuzz_parity.py [cases] [seed]"""
+import os, sys, time
+ROOT = os.path.abspath(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+from oracle import ref_cpu as O
+from packppi_amd import synth
+from packppi_amd.batch import collate, pack, unpack
+from packppi_amd.featurize import protein_to_batch, protein_to_data
+from packppi_amd.functional import compute_residue_clash, get_atom14_coords
+from packppi_amd.module import TDiffusionModule
+from packppi_amd.weights import make_random_state_dict
+
+DEV = "cuda:0"
+
+
+def wrapped(a, b):
+    d = (a.double() - b.double()).abs()
+    return torch.minimum(d, (2 * np.pi - d).abs())
+
+
+def mask_out(b, rows):
+    """what featurize.py does to a residue with a missing backbone atom, on a B = 1 batch"""
+    for r in rows:
+        b.residue_mask[0, r] = 0.0
+        for k in ("X", "atom_mask", "SC_D", "SC_D_mask", "BB_D", "BB_D_mask", "BB_D_sincos", "SC_D_sincos"):
+            b[k][0, r] = 0
+        for k in ("chi_1pi_periodic_mask", "chi_2pi_periodic_mask"):
+            b[k][0, r] = False
+
+
+def run(cases, seed):
+    rng = np.random.default_rng(seed)
+    sd = make_random_state_dict(20251003)
+    m = TDiffusionModule(sd, device=DEV)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    worst = dict(chi=0.0, xyz=0.0, clash=0.0)
+    t0 = time.time()
+    for case in range(cases):
+        kind = ["single", "single_masked", "padded", "packed", "short"][case % 5]
+        steps = int(rng.integers(3, 8))
+        sched = torch.linspace(1, 0, steps + 1)
+        m.schedule = sched
+        if kind in ("single", "single_masked", "short"):
+            # mostly small; one case in six in the launch regimes of larger complexes (one workgroup per residue up to 512 rows,
+            # the mixed pair + single launch up to 768, two residues per workgroup beyond)
+            big = kind != "short" and case % 6 == 5
+            L = int(rng.integers(8, 31)) if kind == "short" else (int(rng.integers(480, 1000)) if big else int(rng.integers(33, 420)))
+            b = protein_to_batch(synth.make_complex(L, int(rng.integers(1 << 30))))
+            if kind == "single_masked":
+                mask_out(b, rng.choice(np.arange(1, L - 1), size=int(rng.integers(1, 4)), replace=False))
+            g = torch.Generator().manual_seed(case)
+            init = (torch.rand(1, L, 4, generator=g) * 2 - 1) * 3.0 * b.SC_D_mask
+            with torch.no_grad():
+                ref = O.sampling(sd, b, init, sched)
+            gb = b.to(DEV)
+            out = m.sample_from(gb, init.to(DEV)).cpu()
+            d = float(wrapped(out, ref)[b.SC_D_mask.bool()].max()) if b.SC_D_mask.any() else 0.0
+            xyz = get_atom14_coords(gb.X, gb.residue_type, gb.BB_D, out.to(DEV)).cpu()
+            xr = O.atom14_coords(b.X, b.residue_type, b.BB_D, out)
+            dx = float(((xyz - xr) * b.atom_mask[..., None]).abs().max())
+            cl = compute_residue_clash(gb, out.to(DEV), 12.0, 0.5).cpu()
+            with torch.no_grad():
+                cr = O.residue_clash(b, out, 12.0, 0.5)
+            dc = float(((cl - cr) * b.residue_mask).abs().max())
+            desc = f"{kind} L={L}"
+        elif kind == "padded":
+            sizes = [int(x) for x in rng.integers(33, 120, size=int(rng.integers(2, 5)))]
+            b = collate([protein_to_data(synth.make_complex(n, int(rng.integers(1 << 30)))) for n in sizes])
+            B, L = b.residue_type.shape
+            g = torch.Generator().manual_seed(case)
+            init = (torch.rand(B, L, 4, generator=g) * 2 - 1) * 3.0 * b.SC_D_mask
+            with torch.no_grad():
+                ref = O.sampling(sd, b, init, sched)
+            out = m.sample_from(b.to(DEV), init.to(DEV)).cpu()
+            d = float(wrapped(out, ref)[b.SC_D_mask.bool()].max())
+            dx = dc = 0.0
+            desc = f"padded {sizes}"
+        else:
+            sizes = [int(x) for x in rng.integers(33, 200, size=int(rng.integers(2, 6)))]
+            cs = [protein_to_batch(synth.make_complex(n, int(rng.integers(1 << 30)))) for n in sizes]
+            if rng.random() < 0.5:
+                mask_out(cs[0], [int(rng.integers(1, sizes[0] - 1))])
+            g = torch.Generator().manual_seed(case)
+            inits = [(torch.rand(1, n, 4, generator=g) * 2 - 1) * 3.0 * c.SC_D_mask for n, c in zip(sizes, cs)]
+            pb = pack(cs).to(DEV)
+            out = unpack(pb, m.sample_from(pb, torch.cat(inits, 1).to(DEV)).cpu())
+            d = 0.0
+            for c, i0, o in zip(cs, inits, out):
+                with torch.no_grad():
+                    ref = O.sampling(sd, c, i0, sched)
+                d = max(d, float(wrapped(o, ref)[c.SC_D_mask.bool()].max()))
+            dx = dc = 0.0
+            desc = f"packed {sizes}"
+        worst["chi"] = max(worst["chi"], d); worst["xyz"] = max(worst["xyz"], dx); worst["clash"] = max(worst["clash"], dc)
+        flag = "" if (d < 1e-4 and dx < 5e-5 and dc < 1e-4) else "   <-- FAIL"
+        print(f"case {case:3d} {desc:40s} steps {steps}: dchi {d:.2e}  dxyz {dx:.2e}  dclash {dc:.2e}{flag}", flush=True)
+    ok = worst["chi"] < 1e-4 and worst["xyz"] < 5e-5 and worst["clash"] < 1e-4 and m.saturated() == 0
+    print(f"FUZZ {'OK' if ok else 'FAIL'}: {cases} cases in {time.time() - t0:.0f} s, worst dchi {worst['chi']:.2e} rad, dxyz {worst['xyz']:.2e} A, "
+          f"dclash {worst['clash']:.2e}")
+    return ok
+
+
+if __name__ == "__main__":
+    sys.exit(0 if run(int(sys.argv[1]) if len(sys.argv) > 1 else 60, int(sys.argv[2]) if len(sys.argv) > 2 else 0) else 1)
