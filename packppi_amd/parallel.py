@@ -91,11 +91,13 @@ def gather_metric_rows(ids: torch.Tensor, rows: torch.Tensor, group=None) -> Tup
     return all_rows[:, 0].to(torch.int64), all_rows[:, 1:]
 
 
-def sample_sharded(model, complexes, use_proximal=False, group=None, init_chi=None, max_rows=200_000, lengths=None):
+def sample_sharded(model, complexes, use_proximal=False, group=None, init_chi=None, max_rows=200_000, lengths=None,
+                   rank=None, world=None):
     """Run the sampling path on this rank's share of ``complexes`` (list of B = 1 batches already on the rank's device)
     and gather every complex's metric row on every rank.  With ``lengths`` (the residue counts of ALL complexes, known to
     every rank) ``complexes`` may be a dict {complex id: batch} that holds only this rank's share -- a rank need not build
-    the other ranks' inputs.
+    the other ranks' inputs.  ``rank`` / ``world`` override the process group's (a single process rehearsing the shards of
+    an N-rank job one after the other; the gather then only orders the local rows).
 
     The shard is sampled as ragged PACKED batches (``batch.pack``: no padding rows are launched; complexes shorter than 32
     residues go alone because K = min(32, L)), at most ``max_rows`` residues per batch; the proximal stage, which the
@@ -104,8 +106,10 @@ def sample_sharded(model, complexes, use_proximal=False, group=None, init_chi=No
     Returns (chi per local complex id, ids_all, rows_all)."""
     from .batch import pack, unpack
     from .functional import proximal_optimizer
-    rank = dist.get_rank(group) if dist.is_initialized() else 0
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if rank is None:
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+    if world is None:
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
     if lengths is None:
         lengths = [int(c["max_size"]) for c in complexes]
     mine = shard_complexes(lengths, world)[rank]
