@@ -22,11 +22,12 @@ import subprocess
 import sys
 import time
 
-import numpy as np
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+import packppi_amd  # noqa: E402,F401  (sets HIP_FORCE_DEV_KERNARG before the HIP runtime initialises)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 N_DIFFUSION_STEPS = 100
 # algorithmic FLOPs (2/MAC, dense projections only) of ONE launch of the dominant kernel (edge update), per edge:
