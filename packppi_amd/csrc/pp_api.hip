@@ -476,11 +476,6 @@ extern "C" void pp_plan_destroy(pp_plan *p) {
     void *ptrs[] = {p->w, p->wT, p->default_frames, p->atom14_to_group, p->atom14_mask, p->lit_positions,
                     p->between_radius, p->bounds_lower, p->bounds_upper};
     for (void *q : ptrs) if (q) (void)hipFree(q);
-    for (GraphSlot &g : p->graph_cache) {
-        (void)hipGraphExecDestroy(g.exec);
-        (void)hipGraphDestroy(g.graph);
-    }
-    if (p->cap_stream) (void)hipStreamDestroy(p->cap_stream);
     for (const ArenaSlot &sl : p->arena_pool) {
         (void)hipFree(sl.p);
     }
@@ -517,7 +512,6 @@ extern "C" pp_status pp_plan_set_clash_params(pp_plan *p, float tol, const float
     return PP_OK;
 }
 
-static void graph_cache_drop_arena(pp_plan *p, void *arena);
 // ---------------------------------------------------------------------------------------------
 extern "C" void pp_ctx_destroy(pp_ctx *c) {
     if (!c) return;
@@ -530,7 +524,6 @@ extern "C" void pp_ctx_destroy(pp_ctx *c) {
         if (p->arena_pool.size() < 4) {
             p->arena_pool.push_back({c->arena, c->arena_bytes, c->last_stream});
         } else {
-            graph_cache_drop_arena(p, c->arena);       // cached step blocks point into this workspace
             (void)hipFree(c->arena);
         }
     }
@@ -614,7 +607,6 @@ static pp_status prepare_impl(pp_plan *plan, const pp_batch *b, const int32_t *s
     ALLOC(px, N * 4); ALLOC(pm, N * 4); ALLOC(pv, N * 4); ALLOC(pz, N * 4); ALLOC(pxeff, N * 4); ALLOC(pmask, N);
     ALLOC(scal, 64);
     ALLOC(sat, 4);
-    if (net) { ALLOC(step_table, PP_MAX_TABLE_STEPS + 1); ALLOC(step_base, 4); }
     ALLOC(seg, N);
     ALLOC(prox_part, (size_t)PP_PROX_CHUNK * ((N + 15) / 16));
     c->max_steps = 1 << 20;
@@ -790,82 +782,6 @@ extern "C" pp_status pp_score(pp_ctx *c, const float *chi, float t, float *score
     return PP_OK;
 }
 
-// ---- replayable step blocks (hipGraph) ---------------------------------------------------------------------------------------
-// A dependent launch costs 2.8-3.4 us on the stream, 1.8-1.95 us as a node of a replayed graph (tools/debug/ubench/graph_cost.hip):
-// the sampling loop -- 600 launches per 100-step pass -- is captured in blocks of PP_GRAPH_BLOCK steps.  For a block to be
-// replayable its launches must carry the same arguments every time, so the only per-step arguments (the reverse-process
-// scalars and the next time embedding of the last layer's node update) move to a device table filled once per pp_sample by
-// kernels whose ARGUMENTS carry the values (no staging buffer, nothing to wait for), and the step index becomes
-// step_base[0] + position in the block; a one-thread kernel at the end of the block advances step_base[0].
-struct StepBlk {
-    StepParams p[24];        // 3 KB of kernel arguments
-};
-__global__ void k_put_steps(StepBlk blk, StepParams *dst, int n) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;        // one float per thread
-    if (t < n * 32) reinterpret_cast<float *>(dst)[t] = reinterpret_cast<const float *>(blk.p)[t];
-}
-__global__ void k_set_steps(int *base, int first, int nsteps) { base[0] = first; base[1] = nsteps; }
-__global__ void k_advance_steps(int *base, int by) { base[0] += by; }
-
-static void graph_cache_drop_arena(pp_plan *p, void *arena) {      // pool_mutex held
-    for (size_t i = 0; i < p->graph_cache.size();) {
-        if (p->graph_cache[i].key.arena == arena) {
-            (void)hipGraphExecDestroy(p->graph_cache[i].exec);
-            (void)hipGraphDestroy(p->graph_cache[i].graph);
-            p->graph_cache.erase(p->graph_cache.begin() + i);
-        } else i++;
-    }
-}
-
-static pp_status run_network(pp_ctx *c, hipStream_t s, int step, int last_mode, float *chi, int mode, const float *noise,
-                             const StepParams *cur, const StepParams *next);
-
-// the instantiated block for this context (built on first use); null exec on failure (the caller falls back to plain launches)
-static hipGraphExec_t step_block_graph(pp_ctx *c, hipStream_t s, int mode, const float *noise, int block) {
-    pp_plan *p = c->plan;
-    GraphKey key;
-    memset(&key, 0, sizeof(key));
-    key.arena = c->arena; key.arena_bytes = c->arena_bytes;
-    key.N = c->N; key.K = c->K; key.B = c->B; key.L = c->L; key.packed = c->packed ? 1 : 0; key.mode = mode; key.block = block;
-    key.knn_ties = 0;
-    key.b = c->b; key.noise = noise; key.seg_offsets = nullptr;
-    {
-        std::lock_guard<std::mutex> g(p->pool_mutex);
-        for (GraphSlot &sl : p->graph_cache)
-            if (memcmp(&sl.key, &key, sizeof(key)) == 0) { sl.stamp = ++p->graph_clock; return sl.exec; }
-    }
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t exec = nullptr;
-    (void)s;
-    if (!p->cap_stream && hipStreamCreateWithFlags(&p->cap_stream, hipStreamNonBlocking) != hipSuccess) {
-        p->cap_stream = nullptr;
-        (void)hipGetLastError();
-        return nullptr;
-    }
-    hipStream_t cs = p->cap_stream;      // nothing runs on it: capturing only records the launches
-    if (hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-    pp_status st = PP_OK;
-    c->table_mode = true;
-    StepParams dummy;
-    memset(&dummy, 0, sizeof(dummy));
-    for (int l = 0; l < block && st == PP_OK; l++) st = run_network(c, cs, l, PP_NU_STEP, c->chi_tmp, mode, noise, &dummy, &dummy);
-    c->table_mode = false;
-    if (st == PP_OK) hipLaunchKernelGGL(k_advance_steps, dim3(1), dim3(1), 0, cs, c->step_base, block);
-    const hipError_t e_end = hipStreamEndCapture(cs, &graph);
-    if (st != PP_OK || e_end != hipSuccess || !graph) { if (graph) (void)hipGraphDestroy(graph); (void)hipGetLastError(); return nullptr; }
-    if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) { (void)hipGraphDestroy(graph); (void)hipGetLastError(); return nullptr; }
-    std::lock_guard<std::mutex> g(p->pool_mutex);
-    if (p->graph_cache.size() >= 6) {          // drop the least recently used block
-        size_t old = 0;
-        for (size_t i = 1; i < p->graph_cache.size(); i++) if (p->graph_cache[i].stamp < p->graph_cache[old].stamp) old = i;
-        (void)hipGraphExecDestroy(p->graph_cache[old].exec);
-        (void)hipGraphDestroy(p->graph_cache[old].graph);
-        p->graph_cache.erase(p->graph_cache.begin() + old);
-    }
-    p->graph_cache.push_back({key, exec, graph, ++p->graph_clock});
-    return exec;
-}
-
 extern "C" pp_status pp_sample(pp_ctx *c, float *chi, const float *schedule, int n_schedule, int mode,
                                const float *sde_noise, void *stream) {
     if (c) c->last_stream = static_cast<hipStream_t>(stream);
@@ -884,37 +800,6 @@ extern "C" pp_status pp_sample(pp_ctx *c, float *chi, const float *schedule, int
     pp_status st;
     // (A hipGraph replay of the loop was measured and dropped: with no stray event records in the stream the kernel
     // trace shows back-to-back dispatches, and capture + replay was 2 % slower than plain launches.)
-    // blocks of PP_GRAPH_BLOCK steps as replayed graphs (PP_GRAPH=0: plain launches throughout; also while a kernel is being
-    // timed in situ, for short runs and beyond the device table's size)
-    static const int use_graph = getenv("PP_GRAPH") ? atoi(getenv("PP_GRAPH")) : 1;
-    const bool graph_ok = use_graph && c->prof_which < 0 && nsteps >= 2 * PP_GRAPH_BLOCK && nsteps <= PP_MAX_TABLE_STEPS;
-    if (graph_ok) {
-        const size_t chi_bytes = (size_t)c->N * 4 * sizeof(float);
-        // a replayable block cannot name the caller's buffer: the loop runs on the context's own copy of the angles
-        PP_HIP_CHECK(hipMemcpyAsync(c->chi_tmp, chi, chi_bytes, hipMemcpyDeviceToDevice, s));
-        StepBlk blk;
-        for (int j0 = 0; j0 <= nsteps; j0 += 24) {              // one entry beyond the last step (read for its time embedding, never used)
-            const int n = (nsteps + 1 - j0) < 24 ? (nsteps + 1 - j0) : 24;
-            memset(&blk, 0, sizeof(blk));
-            for (int j = 0; j < n && j0 + j < nsteps; j++) blk.p[j] = steps[(size_t)(j0 + j)];
-            hipLaunchKernelGGL(k_put_steps, dim3((n * 32 + 255) / 256), dim3(256), 0, s, blk, c->step_table + j0, n);
-        }
-        hipLaunchKernelGGL(k_set_steps, dim3(1), dim3(1), 0, s, c->step_base, 0, nsteps);
-        // (the embedding launch comes before the capture: the launchers set their kernel attributes on first use, which a
-        //  capturing stream does not allow)
-        if ((st = pp_launch_node_embed(c, c->chi_tmp, steps[0], s)) != PP_OK) return st;
-        hipGraphExec_t exec = step_block_graph(c, s, mode, sde_noise, PP_GRAPH_BLOCK);
-        const int nblocks = exec ? nsteps / PP_GRAPH_BLOCK : 0;
-        for (int bq = 0; bq < nblocks; bq++) PP_HIP_CHECK(hipGraphLaunch(exec, s));
-        c->table_mode = true;                                   // the remainder (everything, if no block could be built): plain launches
-        for (int j = nblocks * PP_GRAPH_BLOCK; j < nsteps && st == PP_OK; j++)
-            st = run_network(c, s, j - nblocks * PP_GRAPH_BLOCK, PP_NU_STEP, c->chi_tmp, mode, sde_noise, &steps[j], &steps[j]);
-        c->table_mode = false;
-        if (st != PP_OK) return st;
-        PP_HIP_CHECK(hipMemcpyAsync(chi, c->chi_tmp, chi_bytes, hipMemcpyDeviceToDevice, s));
-        PP_HIP_CHECK(hipGetLastError());
-        return PP_OK;
-    }
     if ((st = pp_launch_node_embed(c, chi, steps[0], s)) != PP_OK) return st;
     static const bool dbg = getenv("PP_DEBUG") != nullptr;
     const auto h0 = std::chrono::steady_clock::now();

@@ -71,29 +71,8 @@ struct ArenaSlot {
     size_t bytes;
     hipStream_t stream;      // work on this stream may still be using the memory
 };
-// An instantiated block of BL reverse-diffusion steps (6 BL launches + the step counter's increment), replayable for any
-// context whose launches would carry the same arguments: same workspace, same batch tensors, same mode.
-#define PP_MAX_TABLE_STEPS 1024
-#define PP_GRAPH_BLOCK 10
-struct GraphKey {
-    void *arena;
-    size_t arena_bytes;
-    int N, K, B, L, packed, mode, block, knn_ties;
-    pp_batch b;
-    const float *noise;
-    const void *seg_offsets;
-};
-struct GraphSlot {
-    GraphKey key;
-    hipGraphExec_t exec;
-    hipGraph_t graph;
-    unsigned long long stamp;
-};
 struct pp_plan {
     int device;
-    std::vector<GraphSlot> graph_cache;  // guarded by pool_mutex
-    hipStream_t cap_stream = nullptr;    // step blocks are captured on this stream (the caller's may be the legacy default stream, which cannot capture) and replayed on the caller's
-    unsigned long long graph_clock = 0;
     std::vector<ArenaSlot> arena_pool;   // workspaces of destroyed contexts, reused by the next pp_complex_prepare
     std::mutex pool_mutex;
     bool has_network;         // false: geometry-only plan (atom14 / clash / proximal)
@@ -165,9 +144,6 @@ struct pp_ctx {
     uint8_t *pmask;           // [N]
     float *prox_part;         // [PP_PROX_CHUNK][ceil(N / 16)] per-block loss terms of the proximal steps
     float *scal;              // small scalar scratch
-    StepParams *step_table;   // [PP_MAX_TABLE_STEPS + 1] per-step scalars of the running pp_sample (graph blocks read them on the device)
-    int *step_base;           // [4]: [0] first step of the block being replayed, [1] number of steps of the run
-    bool table_mode = false;  // launchers: k_node_update<STEP> takes its scalars from step_table (set while graph blocks are built / run)
     unsigned *sat;            // sticky word: bit 0 = an edge kernel, bit 1 = a node kernel clamped a hidden activation at 65504
     // in-situ kernel timing (pp_profile_kernel): every launch of one hot kernel carries a start / stop event pair
     // (hipExtLaunchKernelGGL: the dispatch's own begin / end timestamps, what rocprofv3's kernel trace reports)

@@ -350,10 +350,6 @@ struct NUpdArgs {
     const float *S, *msum;
     float *ptsN, *PAn, *PCn, *ptsE, *PAe, *PCe, *score;
     unsigned *sat;               // the context's sticky saturation word (bit 1: node kernels)
-    // replayable launches (pp_sample's hipGraph blocks): the per-step scalars come from a device table instead of the kernel
-    // arguments -- entry step_base[0] + `step`, with step_base[1] = number of steps of the run; null = arguments as given
-    const StepParams *step_table;
-    const int *step_base;
 };
 
 template <bool LAST>
@@ -520,34 +516,21 @@ k_node_update(NUpdArgs A, float *chi, int step, int sde, const float *noise, int
     bool p1 = false, p2 = false;
     int rt = 0;
     nf4 spv = zero4i;                          // c_ode, w, c_drift, c_diff of this step
-    // table mode: which step this is and whether an embedding follows is only known on the device; everything that depends on it
-    // is requested here and used late (the prologue itself treats "an embedding follows" as true: a few unused loads on the last step)
-    const bool tab = MODE == PP_NU_STEP && A.step_table != nullptr;
-    int gstep = step, emb_true = embed_next;
-    const int embed_maybe = tab ? 1 : embed_next;
-    const StepParams *cur_tab = nullptr;
-    if constexpr (MODE == PP_NU_STEP) {
-        if (tab) {
-            gstep = A.step_base[0] + step;
-            emb_true = gstep + 1 < A.step_base[1] ? 1 : 0;
-            cur_tab = A.step_table + gstep;
-        }
-    }
     if constexpr (MODE == PP_NU_STEP) {
         if (wv == 0) {
-            spv = tab ? nf4{cur_tab->c_ode, cur_tab->w, cur_tab->c_drift, cur_tab->c_diff} : nf4{sp.c_ode, sp.w, sp.c_drift, sp.c_diff};
+            spv = nf4{sp.c_ode, sp.w, sp.c_drift, sp.c_diff};
             chi1 = chi[(size_t)nc * 4 + g];
             scm1 = A.sc_mask[(size_t)nc * 4 + g];
             p1 = A.m1pi[(size_t)nc * 4 + g] != 0;
             p2 = A.m2pi[(size_t)nc * 4 + g] != 0;
             if (sde) {
                 const size_t NN = (size_t)N * 4;
-                const float *nz = noise + (size_t)gstep * 2 * NN + (size_t)nc * 4 + g;
+                const float *nz = noise + (size_t)step * 2 * NN + (size_t)nc * 4 + g;
                 nz1 = nz[0];
                 nz2 = nz[NN];
             }
         }
-        if (embed_maybe) rt = (int)A.rtype[nc];
+        if (embed_next) rt = (int)A.rtype[nc];
     }
     // small inputs of the kernel's tail, staged in LDS now (a dependent fetch there would sit on the critical path): the
     // tile's backbone frames (threads 0..47) and, in layer 2, the chi-independent dense inputs of the next step's node
@@ -561,21 +544,16 @@ k_node_update(NUpdArgs A, float *chi, int step, int sde, const float *noise, int
         const int row = tid / 3, rn = n0 + row < N ? n0 + row : N - 1;
         tailv = *reinterpret_cast<const nf4 *>(A.frames + (size_t)rn * 12 + 4 * (tid - 3 * row));
     } else if (e_bb) {
-        if (embed_maybe) {
+        if (embed_next) {
             const nf2 *bp = reinterpret_cast<const nf2 *>(A.bb_sincos + (size_t)ern * 6);
             const nf2 b0 = bp[0], b1 = bp[1], b2 = bp[2];
             ev[0] = nf4{b0[0], b0[1], b1[0], b1[1]};
             ev[1] = nf4{b2[0], b2[1], 0.f, 0.f};
         }
     } else if (e_te) {
-        if (embed_maybe) {
-            if (tab) {       // the next step's time embedding (the table has one entry beyond the last step)
-                const nf4 *tp = reinterpret_cast<const nf4 *>(cur_tab[1].temb);
-                ev[0] = tp[0]; ev[1] = tp[1]; ev[2] = tp[2]; ev[3] = tp[3];
-            } else {
+        if (embed_next) {
 #pragma unroll
-                for (int k = 0; k < 16; k++) ev[k >> 2][k & 3] = te_next.v[k];
-            }
+            for (int k = 0; k < 16; k++) ev[k >> 2][k & 3] = te_next.v[k];
         }
     }
     constexpr int NPV = (NPAR / 4 + 511) / 512;
@@ -599,16 +577,19 @@ k_node_update(NUpdArgs A, float *chi, int step, int sde, const float *noise, int
     // next step's embedding: the one-hot column is fetched now, used at the very end
     nf4 oh4 = {0.f, 0.f, 0.f, 0.f};
     if constexpr (MODE == PP_NU_STEP) {
-        if (embed_maybe) oh4 = *reinterpret_cast<const nf4 *>(A.embT + (size_t)rt * 128 + fc);
+        if (embed_next) oh4 = *reinterpret_cast<const nf4 *>(A.embT + (size_t)rt * 128 + fc);
     }
     if (tid < 48) reinterpret_cast<nf4 *>(&sm.fr[0][0])[tid] = tailv;
     else if (e_bb) {                       // features 0..5 (6, 7 are rewritten with chi_0's sin / cos later)
         publish4(sm.e_hi, sm.e_lo, erow * NU_S32, ev[0]);
         publish4(sm.e_hi, sm.e_lo, erow * NU_S32 + 4, ev[1]);
+    } else if (e_te) {                     // features 14..29, zeros in 30, 31; 12..13 are rewritten later
+        publish4(sm.e_hi, sm.e_lo, erow * NU_S32 + 12, nf4{0.f, 0.f, ev[0][0], ev[0][1]});
+        publish4(sm.e_hi, sm.e_lo, erow * NU_S32 + 16, nf4{ev[0][2], ev[0][3], ev[1][0], ev[1][1]});
+        publish4(sm.e_hi, sm.e_lo, erow * NU_S32 + 20, nf4{ev[1][2], ev[1][3], ev[2][0], ev[2][1]});
+        publish4(sm.e_hi, sm.e_lo, erow * NU_S32 + 24, nf4{ev[2][2], ev[2][3], ev[3][0], ev[3][1]});
+        publish4(sm.e_hi, sm.e_lo, erow * NU_S32 + 28, nf4{ev[3][2], ev[3][3], 0.f, 0.f});
     }
-    // (the time-embedding features 14..29 of the operand rows are published after the second LayerNorm: in table mode their
-    //  values are the end of a dependent load chain and must not hold up the first barrier; nobody reads them before the
-    //  embedding stage)
     publish4(sm.a_hi, sm.a_lo, srow * NU_S128 + scol, s4);
     __syncthreads();
 
@@ -653,15 +634,8 @@ k_node_update(NUpdArgs A, float *chi, int step, int sde, const float *noise, int
     x = fold(cH, cL) + *reinterpret_cast<const nf4 *>(par + NU_P_FOB + fc) + h1;
     const nf4 h2 = ln128(sm.stats[1], wv, r, g, x, *reinterpret_cast<const nf4 *>(par + NU_P_G1 + fc),
                          *reinterpret_cast<const nf4 *>(par + NU_P_B1 + fc)) * rm;
-    if (live && (MODE != PP_NU_STEP || !emb_true)) *reinterpret_cast<nf4 *>(A.hV + (size_t)n * 128 + fc) = h2;
+    if (live && (MODE != PP_NU_STEP || !embed_next)) *reinterpret_cast<nf4 *>(A.hV + (size_t)n * 128 + fc) = h2;
     publish4(sm.a_hi, sm.a_lo, r * NU_S128 + fc, h2);
-    if (e_te) {                            // features 14..29, zeros in 30, 31; 12..13 are rewritten after the reverse step
-        publish4(sm.e_hi, sm.e_lo, erow * NU_S32 + 12, nf4{0.f, 0.f, ev[0][0], ev[0][1]});
-        publish4(sm.e_hi, sm.e_lo, erow * NU_S32 + 16, nf4{ev[0][2], ev[0][3], ev[1][0], ev[1][1]});
-        publish4(sm.e_hi, sm.e_lo, erow * NU_S32 + 20, nf4{ev[1][2], ev[1][3], ev[2][0], ev[2][1]});
-        publish4(sm.e_hi, sm.e_lo, erow * NU_S32 + 24, nf4{ev[2][2], ev[2][3], ev[3][0], ev[3][1]});
-        publish4(sm.e_hi, sm.e_lo, erow * NU_S32 + 28, nf4{ev[3][2], ev[3][3], 0.f, 0.f});
-    }
     __syncthreads();
 #if defined(PP_X_NU_STOP) && PP_X_NU_STOP == 4     /* timing experiment: stop here */
     return;
@@ -769,7 +743,7 @@ k_node_update(NUpdArgs A, float *chi, int step, int sde, const float *noise, int
                 }
                 const float y = wrap_pi(yk) * scm1;
                 if (live) chi[(size_t)n * 4 + g] = y;
-                if (emb_true) {            // features 6 + 2 g, 7 + 2 g of the embedding operand
+                if (embed_next) {          // features 6 + 2 g, 7 + 2 g of the embedding operand
                     unsigned hp, lp;
                     split2(sinf(y) * scm1, cosf(y) * scm1, hp, lp);
                     *reinterpret_cast<unsigned *>(sm.e_hi + r * NU_S32 + 6 + 2 * g) = hp;
@@ -778,7 +752,7 @@ k_node_update(NUpdArgs A, float *chi, int step, int sde, const float *noise, int
             }
         }
         if constexpr (MODE != PP_NU_STEP) return;
-        if (!emb_true) return;
+        if (!embed_next) return;
         __syncthreads();
 #if defined(PP_X_NU_STOP) && PP_X_NU_STOP == 6     /* timing experiment: stop here */
         return;
@@ -929,8 +903,6 @@ pp_status pp_launch_node_update(pp_ctx *c, int layer, int last_mode, float *chi,
     A.ptsE = c->ptsE; A.PAe = c->PAe; A.PCe = c->PCe;
     A.score = c->score;
     A.sat = c->sat;
-    A.step_table = (c->table_mode && last_mode == PP_NU_STEP) ? c->step_table : nullptr;
-    A.step_base = c->step_base;
     int embed_next = (last_mode == PP_NU_STEP && embed_next_step) ? 1 : 0;    // node embedding for step + 1 afterwards
 #ifdef PP_X_NU_EMBED_LAUNCH      /* experiment: the next step's embedding as its own launch (k_node_embed) */
     const bool embed_after = embed_next != 0;
