@@ -8,6 +8,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+import packppi_amd  # noqa: E402,F401  (sets HIP_FORCE_DEV_KERNARG before anything initialises the HIP runtime)
 
 GOLD = os.path.join(ROOT, "tests", "golden")
 WEIGHT_SEED = 20251003
