@@ -576,6 +576,30 @@ def test_packed_batch_with_a_residue_masked_mid_chain(model, weights):
     model.schedule = torch.linspace(1, 0, 31)
 
 
+def test_new_abi_calls_reject_bad_arguments(model):
+    """pp_status + pp_last_error instead of faults: the entry points added this round, called wrongly through ctypes."""
+    import ctypes as C
+    from packppi_amd import lib as L
+    l = L.load()
+    plan = model._plan.handle
+    assert l.pp_plan_set_knn_ties(plan, 7) == 1 and b"unknown mode" in l.pp_last_error()
+    assert l.pp_plan_set_knn_ties(None, 1) == 1
+    for mode in (0, 2, 1):
+        assert l.pp_plan_set_knn_ties(plan, mode) == 0                  # ends on the default again
+    flags = C.c_int(5)
+    assert l.pp_ctx_saturated(None, C.byref(flags), None) == 1 and b"null" in l.pp_last_error()
+    e, n = C.c_ulonglong(3), C.c_ulonglong(3)
+    assert l.pp_range_check_parts(C.byref(e), C.byref(n), 0) == 3 and e.value == 0 and n.value == 0      # default build: unsupported
+    assert l.pp_range_check_parts(None, C.byref(n), 0) == 1
+    b, _ = load_golden("g2_ops_L33")
+    ctx = model._context(_gpu(b))
+    assert ctx.saturated() == 0
+    with pytest.raises(RuntimeError, match="schedule needs at least 2"):
+        ctx.sample(torch.zeros(1, 33, 4, device=DEV), torch.tensor([1.0]))
+    with pytest.raises(RuntimeError, match="noise"):
+        ctx.sample(torch.zeros(1, 33, 4, device=DEV), torch.linspace(1, 0, 4), "sde", None)
+
+
 def test_randomised_shapes_match_the_oracle():
     """A short randomised sweep (tools/debug/fuzz_parity.py runs hundreds): random sizes incl. complexes shorter than K = 32 and
     sizes in every launch regime, residues masked out mid-chain, padded and packed batches of random composition, 3-7 steps --
