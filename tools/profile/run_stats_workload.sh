@@ -1,0 +1,14 @@
+#!/bin/bash
+# GPU box: rocprofv3 --kernel-trace --stats summary of bench.py for another workload -> profiles/<ROUND>_<tag>_kernel_stats_<workload>.csv
+# Usage: bash tools/profile/run_stats_workload.sh <tag> <workload>
+set -e
+TAG=${1:-v1}; WL=${2:-s1500}
+ROOT=$(pwd); OUT=$ROOT/gpurun_out/stats_$WL; mkdir -p $OUT
+export TMPDIR=/tmp
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o run -- python3 $ROOT/bench.py --workload $WL --steps 2 --warmup 1 --cpu-steps 0 --no-secondary > $OUT/bench.json 2> $OUT/err.txt
+cd $ROOT
+f=$(find $OUT -name "*kernel_stats.csv" | head -1)
+cp $f gpurun_out/${GRAFT_ROUND:-r03}_${TAG}_kernel_stats_$WL.csv
+find $OUT -type f ! -name "bench.json" -delete
+head -8 gpurun_out/${GRAFT_ROUND:-r03}_${TAG}_kernel_stats_$WL.csv | cut -c1-150
