@@ -62,17 +62,43 @@ __global__ void k_frames(const float *__restrict__ X, int N, float *__restrict__
 // K + 1, a MEMBERSHIP tie, in PP_KNN_TIES_ATEN_MEMBER) is redone by one lane running exactly that code on the row in LDS.
 // Rows without such a tie have one possible answer and never pay for it.
 // ---------------------------------------------------------------------------------------------
+// minimum of a 64-bit key over the wave, in every lane: four DPP butterfly steps inside each row of 16 lanes (VALU speed; the
+// ds_bpermute form of __shfl_xor costs an LDS round trip per step, twelve dependent ones per arg-min), then the four row results
+// through SGPRs.  Keys are (float bits of a non-negative distance) << 32 | index: unsigned order = (value, index) order, +inf and
+// NaN patterns last.
+__device__ __forceinline__ unsigned long long wave_min_key(unsigned hi, unsigned lo) {
+#define KNN_DPP_STEP(ctrl)                                                                                              \
+    {                                                                                                                   \
+        const unsigned oh = (unsigned)__builtin_amdgcn_mov_dpp((int)hi, ctrl, 0xF, 0xF, true);                          \
+        const unsigned ol = (unsigned)__builtin_amdgcn_mov_dpp((int)lo, ctrl, 0xF, 0xF, true);                          \
+        const bool less = oh < hi || (oh == hi && ol < lo);                                                             \
+        hi = less ? oh : hi;                                                                                            \
+        lo = less ? ol : lo;                                                                                            \
+    }
+    KNN_DPP_STEP(0xB1)      // quad_perm [1,0,3,2]
+    KNN_DPP_STEP(0x4E)      // quad_perm [2,3,0,1]
+    KNN_DPP_STEP(0x141)     // row_half_mirror
+    KNN_DPP_STEP(0x140)     // row_mirror
+#undef KNN_DPP_STEP
+    unsigned long long best = ~0ull;
+#pragma unroll
+    for (int row = 0; row < 4; row++) {
+        const unsigned long long k = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)hi, 16 * row) << 32) |
+                                     (unsigned)__builtin_amdgcn_readlane((int)lo, 16 * row);
+        best = k < best ? k : best;
+    }
+    return best;
+}
+
 __global__ void __launch_bounds__(KNN_THREADS)
 k_knn(const float *__restrict__ X, const float *__restrict__ rmask, const int2 *__restrict__ seg, int K, int ties,
       int32_t *__restrict__ eidx, float *__restrict__ mask_att) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     pp_tk_pair *q = reinterpret_cast<pp_tk_pair *>(smem_raw);   // [L] (adjusted distance, index in the complex)
     __shared__ float red_v[KNN_THREADS / 64];
-    __shared__ int red_i[KNN_THREADS / 64];
     __shared__ float s_max;
     __shared__ float pick_v[33];
     __shared__ int pick_i[33];
-    __shared__ int s_tie;
     const int n = blockIdx.x;
     const int row0 = seg[n].x, L = seg[n].y;          // this row's complex: rows row0 .. row0 + L - 1
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -90,7 +116,6 @@ k_knn(const float *__restrict__ X, const float *__restrict__ rmask, const int2 *
     }
     for (int o = 32; o > 0; o >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, o));
     if (lane == 0) red_v[wid] = lmax;
-    if (tid == 0) s_tie = 0;
     __syncthreads();
     if (tid == 0) {
         float m = red_v[0];
@@ -105,49 +130,46 @@ k_knn(const float *__restrict__ X, const float *__restrict__ rmask, const int2 *
     }
     __syncthreads();
     // round K (when the complex has more than K residues) only looks at the next value: is rank K + 1 equal to rank K?
+    // One barrier per round: the four wave candidates go through one of two alternating LDS slots, every thread merges them
+    // (same answer everywhere), the thread that owns the winning element in the strided scan retires it, and the global
+    // stores wait until the rounds are over.
+    __shared__ unsigned long long red_k[2][KNN_THREADS / 64];
     const int rounds = K + ((ties != PP_KNN_TIES_LOWER_INDEX && L > K) ? 1 : 0);
+    int tie = 0;
+    unsigned prev = 0;
     for (int k = 0; k < rounds; k++) {
-        float bv = INFINITY;
-        int bi = 0x7fffffff;
+        unsigned bv = 0xffffffffu, bi = 0x7fffffffu;
         for (int j = tid; j < L; j += KNN_THREADS) {
-            float v = q[j].v;
-            if (v < bv) { bv = v; bi = j; }      // strided scan keeps the lowest j among equal values
+            const unsigned v = __float_as_uint(q[j].v);
+            if (v < bv) { bv = v; bi = (unsigned)j; }      // strided scan keeps the lowest j among equal values
         }
-        for (int o = 32; o > 0; o >>= 1) {
-            float ov = __shfl_xor(bv, o);
-            int oi = __shfl_xor(bi, o);
-            if (ov < bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-        }
-        if (lane == 0) { red_v[wid] = bv; red_i[wid] = bi; }
+        const unsigned long long wk = wave_min_key(bv, bi);
+        if (lane == 0) red_k[k & 1][wid] = wk;
         __syncthreads();
-        if (tid == 0) {
-            float v = red_v[0];
-            int ix = red_i[0];
-            for (int w = 1; w < KNN_THREADS / 64; w++)
-                if (red_v[w] < v || (red_v[w] == v && red_i[w] < ix)) { v = red_v[w]; ix = red_i[w]; }
-            pick_v[k] = v;
-            pick_i[k] = ix;
-            if (k > 0 && v == pick_v[k - 1]) s_tie |= (k == K) ? 2 : 1;
-            if (k < K) {
-                if (ix < L) {
-                    q[ix].v = INFINITY;
-                    eidx[(size_t)n * K + k] = row0 + ix;
-                    mask_att[(size_t)n * 32 + k] = mi * rmask[row0 + ix];
-                } else {
-                    // nothing finite left (a segment shorter than K, or NaN coordinates): the row itself, masked out
-                    eidx[(size_t)n * K + k] = n;
-                    mask_att[(size_t)n * 32 + k] = 0.f;
-                }
-            }
+        unsigned long long best = red_k[k & 1][0];
+#pragma unroll
+        for (int w = 1; w < KNN_THREADS / 64; w++) {
+            const unsigned long long o = red_k[k & 1][w];
+            best = o < best ? o : best;
         }
-        __syncthreads();
+        const unsigned vb = (unsigned)(best >> 32);
+        const int ix = (int)(unsigned)best;
+        if (k > 0 && vb == prev && vb < 0x7f800000u) tie |= (k == K) ? 2 : 1;      // (equal finite values; NaN never equals)
+        prev = vb;
+        if (tid == 0) { pick_v[k] = __uint_as_float(vb); pick_i[k] = ix; }
+        if (k < K && ix < L && (ix % KNN_THREADS) == tid) q[ix].v = INFINITY;      // only this thread ever scans element ix
+    }
+    __syncthreads();
+    if (tid < K) {
+        const int ix = pick_i[tid];
+        // nothing finite left (a segment shorter than K, or NaN coordinates): the row itself, masked out
+        eidx[(size_t)n * K + tid] = ix < L ? row0 + ix : n;
+        mask_att[(size_t)n * 32 + tid] = ix < L ? mi * rmask[row0 + ix] : 0.f;
     }
     if (tid < 32 && tid >= K) mask_att[(size_t)n * 32 + tid] = 0.f;
     const int want = ties == PP_KNN_TIES_ATEN_CPU ? 3 : (ties == PP_KNN_TIES_ATEN_MEMBER ? 2 : 0);
-    if (!(s_tie & want) || mi == 0.f) return;       // (a masked row's list is never used: mask_att is 0 throughout)
-    if (tid == 0)
-        for (int k = 0; k < K; k++)
-            if (pick_i[k] < L) q[pick_i[k]].v = pick_v[k];      // the row as it was before the rounds
+    if (!(tie & want) || mi == 0.f) return;         // (a masked row's list is never used: mask_att is 0 throughout)
+    if (tid < K && pick_i[tid] < L) q[pick_i[tid]].v = pick_v[tid];      // the row as it was before the rounds
     __syncthreads();
     if ((long)K * 64 <= (long)L || L > KNN_PAR_MAX) {
         // ATen's partial_sort branch (rows of 2048 residues and more): one lane, heap code as it stands
