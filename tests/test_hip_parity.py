@@ -784,7 +784,8 @@ def test_fp32_variant_library():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, PACKPPI_LIB=lib, PACKPPI_EXPECT_VARIANT="0" if lib.endswith(".f32.so") else "1")
     sel = ("test_library_variant_is_the_requested_one or test_graph or test_network or test_sampling_ode or test_sampling_sde "
-           "or test_T1124_100_steps or test_S1500_100_steps or test_sampling_is_bit_reproducible or test_packed_batch or test_knn_ties")
+           "or test_T1124_100_steps or test_S1500_100_steps or test_sampling_is_bit_reproducible or test_packed_batch or test_knn_ties "
+           "or test_checkpoint_outside_the_f16_range")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_hip_parity.py"), "-q", "-x", "-m", "gpu",
                         "-k", sel, "-p", "no:cacheprovider"], env=env, cwd=root, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
@@ -848,6 +849,39 @@ def test_weight_range_envelope():
         d32 = float(wrapped_absdiff(out3, ref3)[mask3].max())             # and against the fp32 oracle itself where that is meaningful
         assert d32 < max(1e-4, 3 * cond), (name, d32, cond)
         assert m.saturated() == 0, name
+
+
+def test_checkpoint_outside_the_f16_range(weights):
+    """A checkpoint whose hidden activations pass 65504: the default (split-f16) library flags every such evaluation, and the
+    exact-fp32 library (libpackppi_hip.f32.so: fp32 MFMA edge kernels, VALU node update; test_fp32_variant_library runs this
+    case on it) computes it like the fp32 oracle does."""
+    from oracle import ref_cpu as O
+    from packppi_amd import lib as L
+    from packppi_amd import synth
+    from packppi_amd.featurize import protein_to_batch
+    from packppi_amd.module import TDiffusionModule
+    exact = L.load().pp_edge_variant() == 0
+    b = protein_to_batch(synth.make_complex(96, 5))
+    g = torch.Generator().manual_seed(3)
+    chi = (torch.rand(1, 96, 4, generator=g) * 2 - 1) * 3.0 * b.SC_D_mask
+    t = torch.full((96,), 0.5)
+    for name, bit in (("mpnn.mpnn_layers.1.edge_dense.W_in.weight", 1), ("mpnn.mpnn_layers.0.node_message_fn.W_in.weight", 1),
+                      ("mpnn.mpnn_layers.2.node_dense.W_in.weight", 2), ("mpnn.mpnn_layers.0.node_dense.W_in.weight", 2),
+                      ("decoder_score.0.W_in.weight", 2)):
+        sd = dict(weights)
+        sd[name] = weights[name] * 3e5
+        m = TDiffusionModule(sd, device=DEV)
+        s, h = m.network(_gpu(b), chi.to(DEV), t)
+        if not exact:
+            assert m.saturated() & bit, (name, m.saturated())
+            continue
+        assert m.saturated() == 0, name
+        with torch.no_grad():
+            s_o, h_o = O.network(sd, b, chi, t)
+        dh = float((h.cpu() - h_o).abs().max() / h_o.abs().max())
+        ds = float((s.cpu() - s_o).abs().max() / s_o.abs().max())
+        print(f"out of f16 range [{name}]: h_V {dh:.2e}, score {ds:.2e} (relative to the largest entry)")
+        assert dh < 2e-5 and ds < 2e-5, (name, dh, ds)
 
 
 def test_f16_range_check_build():
