@@ -358,6 +358,20 @@ __device__ constexpr int nu_slot_waves(int s) {       // how many waves (0 .. n-
     return s < 36 ? 8 : s < 40 ? 4 : s < 46 ? 1 : s < 55 ? 8 : 2;
 }
 
+// SPLIT launches of a middle layer (CL = 2 or 4 workgroups per tile, see k_node_update): workgroup q of a tile runs the common
+// part (slots 0..35) and then only ITS 4 / CL of the four 128-wide projections, workgroup 0 the local points as well.  Logical
+// slot s of such a workgroup -> slot of the packed stream, and the waves that own a logical slot.
+template <int CL>
+__device__ __forceinline__ int nu_phys_slot(int s, int q) {
+    if constexpr (CL == 1) return s;
+    constexpr int NPS = 16 / CL;                 // projection slots per workgroup
+    return s < 36 ? s : s < 36 + NPS ? s + NPS * q : s + (16 - NPS);
+}
+template <bool LAST, int CL>
+__device__ constexpr int nu_logical_waves(int s) {
+    if (CL == 1) return nu_slot_waves<LAST>(s);
+    return s < 36 + 16 / CL ? 8 : 3;
+}
 __device__ __forceinline__ void gload_N(const nh8 *__restrict__ wq, int slot, AOpN &a) {
     int off = slot * 128;                     // nh8 units per 2 KB slot
     asm volatile("" : "+s"(off));             // opaque: the fetch is issued where it is written, not hoisted to the top
@@ -457,9 +471,9 @@ __device__ __forceinline__ nf4 ln128(float (*st)[16][2], int wv, int r, int g, c
     {                                                                                                                  \
         __builtin_amdgcn_sched_barrier(0);                                                                             \
         if constexpr ((k) + NU_ND < NLOAD && !NU_X_NOLOAD) {                                                           \
-            constexpr int nw_ = nu_slot_waves<LAST>((k) + NU_ND);                                                      \
+            constexpr int nw_ = nu_logical_waves<LAST, CL>((k) + NU_ND);                                               \
             if (nw_ == 8 || wv < nw_)                                                                                  \
-                gload_N(wq, (k) + NU_ND, AR[((k) + NU_ND) % NU_NRING]);                                                \
+                gload_N(wq, nu_phys_slot<CL>((k) + NU_ND, clq), AR[((k) + NU_ND) % NU_NRING]);                         \
         }                                                                                                              \
         if (OWN) {                                                                                                     \
             const AOpN &AK = AR[(k) % NU_NRING];                                                                       \
@@ -489,18 +503,24 @@ __device__ __forceinline__ nf4 ln128(float (*st)[16][2], int wv, int r, int g, c
 #else
 #define NU_X_NOLOAD false
 #endif
-template <int MODE, int NU_ND>
+// CL > 1 (middle layers, when CL x tiles workgroups still fit the chip in one round): CL workgroups per 16-residue tile.  A
+// launch lasts as long as ONE CU needs for its workgroup's weight stream, and most CUs idle (47 tiles at T1124); so the tile's
+// common part (W_out, FFN, both LayerNorms: 36 slots) is computed redundantly by CL workgroups on CL CUs, and the 20 slots of
+// projections behind it are dealt out among them -- no exchange between workgroups, identical arithmetic per output.
+template <int MODE, int NU_ND, int CL = 1>
 __global__ void __launch_bounds__(512)
 k_node_update(NUpdArgs A, float *chi, int step, int sde, const float *noise, int embed_next, StepScalars sp, TimeEmb te_next) {
+    static_assert(CL == 1 || MODE == PP_NU_MID, "only the middle layers have a split form");
     constexpr int NU_NRING = NU_ND + 1;
     constexpr bool LAST = MODE != PP_NU_MID;
     constexpr int NSLOT = LAST ? PP_NU_SLOTS_LAST : PP_NU_SLOTS_MID;
-    constexpr int NLOAD = MODE == PP_NU_SCORE ? 46 : NSLOT;       // slots this instance ever fetches
+    constexpr int NLOAD = MODE == PP_NU_SCORE ? 46 : CL > 1 ? 36 + 16 / CL + 4 : NSLOT;       // (logical) slots this instance ever fetches
+    const int clq = CL > 1 ? (int)(blockIdx.x % CL) : 0;          // which of the tile's workgroups this is
     constexpr int NPAR = LAST ? NU_P_LAST_TOTAL : NU_P_MID_TOTAL;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     SmemU &sm = *reinterpret_cast<SmemU *>(smem_raw);
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r = lane & 15, g = lane >> 4, N = A.N, n0 = blockIdx.x * 16;
+    const int r = lane & 15, g = lane >> 4, N = A.N, n0 = (int)(blockIdx.x / CL) * 16;
     const int n = n0 + r, nc = n < N ? n : N - 1;
     const bool live = n < N;
     const int fc = 16 * wv + 4 * g;            // first of this lane's four features in a 128-wide vector
@@ -634,7 +654,7 @@ k_node_update(NUpdArgs A, float *chi, int step, int sde, const float *noise, int
     x = fold(cH, cL) + *reinterpret_cast<const nf4 *>(par + NU_P_FOB + fc) + h1;
     const nf4 h2 = ln128(sm.stats[1], wv, r, g, x, *reinterpret_cast<const nf4 *>(par + NU_P_G1 + fc),
                          *reinterpret_cast<const nf4 *>(par + NU_P_B1 + fc)) * rm;
-    if (live && (MODE != PP_NU_STEP || !embed_next)) *reinterpret_cast<nf4 *>(A.hV + (size_t)n * 128 + fc) = h2;
+    if (live && clq == 0 && (MODE != PP_NU_STEP || !embed_next)) *reinterpret_cast<nf4 *>(A.hV + (size_t)n * 128 + fc) = h2;
     publish4(sm.a_hi, sm.a_lo, r * NU_S128 + fc, h2);
     __syncthreads();
 #if defined(PP_X_NU_STOP) && PP_X_NU_STOP == 4     /* timing experiment: stop here */
@@ -644,20 +664,24 @@ k_node_update(NUpdArgs A, float *chi, int step, int sde, const float *noise, int
 
     if constexpr (!LAST) {
         // ---- inputs of this layer's edge message and of the next layer's node message ----------------------------------
+        // projection pj = 0..3: PAe (+ bias), PCe, PAn (+ bias), PCn; this workgroup computes pj = NPJ clq .. NPJ clq + NPJ - 1
+        constexpr int NPJ = 4 / CL;
+#define NU_PROJ(i)                                                                                                     \
+        if constexpr ((i) < NPJ) {                                                                                     \
+            cH = zero4; cL = zero4;                                                                                    \
+            NTILE4(36 + 4 * (i), cH, cL)                                                                               \
+            const int pj = NPJ * clq + (i);                                                                            \
+            float *dst = pj == 0 ? A.PAe : pj == 1 ? A.PCe : pj == 2 ? A.PAn : A.PCn;                                  \
+            nf4 v = fold(cH, cL);                                                                                      \
+            if (pj == 0) v = v + *reinterpret_cast<const nf4 *>(par + NU_P_PAE_B + fc);                                \
+            else if (pj == 2) v = v + *reinterpret_cast<const nf4 *>(par + NU_P_PAN_B + fc);                           \
+            if (live) *reinterpret_cast<nf4 *>(dst + (size_t)n * 128 + fc) = v;                                        \
+        }
+        NU_PROJ(0) NU_PROJ(1) NU_PROJ(2) NU_PROJ(3)
+#undef NU_PROJ
+        if (CL > 1 && clq != 0) return;        // (uniform per workgroup) the local points are workgroup 0's
         cH = zero4; cL = zero4;
-        NTILE4(36, cH, cL)
-        if (live) *reinterpret_cast<nf4 *>(A.PAe + (size_t)n * 128 + fc) = fold(cH, cL) + *reinterpret_cast<const nf4 *>(par + NU_P_PAE_B + fc);
-        cH = zero4; cL = zero4;
-        NTILE4(40, cH, cL)
-        if (live) *reinterpret_cast<nf4 *>(A.PCe + (size_t)n * 128 + fc) = fold(cH, cL);
-        cH = zero4; cL = zero4;
-        NTILE4(44, cH, cL)
-        if (live) *reinterpret_cast<nf4 *>(A.PAn + (size_t)n * 128 + fc) = fold(cH, cL) + *reinterpret_cast<const nf4 *>(par + NU_P_PAN_B + fc);
-        cH = zero4; cL = zero4;
-        NTILE4(48, cH, cL)
-        if (live) *reinterpret_cast<nf4 *>(A.PCn + (size_t)n * 128 + fc) = fold(cH, cL);
-        cH = zero4; cL = zero4;
-        NTILE4_IF(52, wv < 3, cH, cL)
+        NTILE4_IF(36 + 4 * NPJ, wv < 3, cH, cL)
         if (wv < 3) {              // local points: features 0..23 edge message, 24..47 next node message
             const nf4 p = fold(cH, cL) + *reinterpret_cast<const nf4 *>(par + NU_P_PTS_B + fc);
             *reinterpret_cast<nf4 *>(&sm.pts[r][fc]) = p;
@@ -1226,6 +1250,9 @@ static nu_kernel_t nu_kernel(int mode, bool multi) {
     return mode == 0 ? k_node_update<PP_NU_MID, PP_NU_DEPTH> : mode == 1 ? k_node_update<PP_NU_STEP, PP_NU_DEPTH>
                                                                           : k_node_update<PP_NU_SCORE, PP_NU_DEPTH>;
 }
+static nu_kernel_t nu_kernel_split(int cl) {
+    return cl == 4 ? k_node_update<PP_NU_MID, PP_NU_DEPTH, 4> : k_node_update<PP_NU_MID, PP_NU_DEPTH, 2>;
+}
 static int g_nu_cus = 0;
 static pp_status node_attrs() {
     static bool done = false;
@@ -1236,6 +1263,9 @@ static pp_status node_attrs() {
             for (int mode = 0; mode < 3; mode++)
                 PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(nu_kernel(mode, multi != 0)),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SmemU)));
+        for (int cl = 2; cl <= 4; cl += 2)
+            PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(nu_kernel_split(cl)),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SmemU)));
 #ifndef PP_EDGE_F16
         PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_node_update_valu<PP_NU_MID>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Smem)));
         PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_node_update_valu<PP_NU_STEP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Smem)));
@@ -1331,6 +1361,15 @@ pp_status pp_launch_node_update(pp_ctx *c, int layer, int last_mode, float *chi,
     }
 #endif
     const bool multi = (int)grid.x > g_nu_cus;
+    // middle layers of a launch that leaves most CUs idle: 4 (or 2) workgroups per tile share out the projections
+    static const int split_max = getenv("PP_NU_SPLIT") ? atoi(getenv("PP_NU_SPLIT")) : 4;     // measurement aid: 1 = never
+    const int tiles = (int)grid.x;
+    const int cl = last_mode != PP_NU_MID ? 1 : (split_max >= 4 && 4 * tiles <= g_nu_cus) ? 4 : (split_max >= 2 && 2 * tiles <= g_nu_cus) ? 2 : 1;
+    if (cl > 1) {
+        PP_LAUNCH(c, nu_kernel_split(cl), dim3(tiles * cl), block, sizeof(SmemU), s, A, chi, step, sde, noise, embed_next, sp, te);
+        PP_HIP_CHECK(hipGetLastError());
+        return PP_OK;
+    }
     const nu_kernel_t kern = nu_kernel(last_mode == PP_NU_MID ? 0 : last_mode == PP_NU_STEP ? 1 : 2, multi);
     PP_LAUNCH(c, kern, grid, block, sizeof(SmemU), s, A, chi, step, sde, noise, embed_next, sp, te);
     PP_HIP_CHECK(hipGetLastError());

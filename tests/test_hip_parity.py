@@ -771,6 +771,36 @@ def test_library_variant_is_the_requested_one():
     assert got in (0, 1) and (want is None or got == int(want))
 
 
+def test_node_update_split_launch_is_bit_identical():
+    """Middle-layer node updates of a launch that leaves most CUs idle run as 4 (or 2) workgroups per 16-residue tile, each
+    computing the tile's common part and its share of the projections (pp_node.hip, CL): every output keeps its arithmetic, so
+    sampling must give the same bits as with plain launches (PP_NU_SPLIT=1; the switch is read once per process)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import hashlib, sys, torch; sys.path.insert(0, %r)\n"
+            "from packppi_amd import synth\n"
+            "from packppi_amd.featurize import protein_to_batch\n"
+            "from packppi_amd.module import TDiffusionModule\n"
+            "from packppi_amd.weights import make_random_state_dict\n"
+            "m = TDiffusionModule(make_random_state_dict(20251003), device='cuda:0')\n"
+            "m.schedule = torch.linspace(1, 0, 11)\n"
+            "for L in (90, 300, 1100, 1900):\n"       # 6 / 19 tiles: 4 per tile; 69 / 119: 2 per tile
+            "    b = protein_to_batch(synth.make_complex(L, 40 + L)).to('cuda:0')\n"
+            "    g = torch.Generator().manual_seed(L)\n"
+            "    init = ((torch.rand(1, L, 4, generator=g) * 2 - 1) * 3.0).to('cuda:0') * b.SC_D_mask\n"
+            "    out = m.sample_from(b, init)\n"
+            "    s, h = m.network(b, out, torch.full((L,), 0.3))\n"
+            "    print(L, hashlib.sha256(out.cpu().numpy().tobytes() + h.cpu().numpy().tobytes()).hexdigest())\n") % root
+    outs = []
+    for split in ("1", "4"):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PP_NU_SPLIT=split), capture_output=True, text=True,
+                           timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append([ln for ln in r.stdout.splitlines() if ln[:1].isdigit()])
+    assert len(outs[0]) == 4 and outs[0] == outs[1], outs
+
+
 def test_fp32_variant_library():
     """The end-to-end parity cases once more on the exact-fp32 edge kernels (one child test run with PACKPPI_LIB)."""
     import subprocess
