@@ -598,7 +598,7 @@ static pp_status prepare_impl(pp_plan *plan, const pp_batch *b, const int32_t *s
                           slots.push_back({reinterpret_cast<void **>(&c->field), bytes_}); total += bytes_; }
     if (net) {
     ALLOC(eidx, N * K); ALLOC(mask_att, N * 32); ALLOC(frames, N * 12); ALLOC(bbpos, N * 15);
-    ALLOC(hE0, N * K * 128); ALLOC(hE, N * K * 128); ALLOC(Znm, N * K * 128); ALLOC(Zem, N * K * 128); ALLOC(hV, N * 128); ALLOC(S, N * 128); ALLOC(msum, N);
+    ALLOC(hE0, N * K * 128); ALLOC(hE, N * K * 128); ALLOC(Znm, N * K * 128); ALLOC(Zem, N * K * 128); ALLOC(hV, N * 128); ALLOC(hV_alt, N * 128); ALLOC(S, N * 128); ALLOC(msum, N);
     ALLOC(ptsN, N * 48); ALLOC(PAn, N * 128); ALLOC(PCn, N * 128);
     ALLOC(ptsE, N * 48); ALLOC(PAe, N * 128); ALLOC(PCe, N * 128);
     ALLOC(score, N * 4); ALLOC(chi_tmp, N * 4);

@@ -123,6 +123,7 @@ struct pp_ctx {
     // per-evaluation state
     float *hE;                // [N][K][128]
     float *hV;                // [N][128]
+    float *hV_alt;            // [N][128] the split node-update launches write the new h_V here, then the two pointers swap
     float *S;                 // [N][128]  masked mean of the node-message hidden layer
     float *msum;              // [N]
     float *ptsN, *PAn, *PCn;  // node-message inputs [N][48] [N][128] [N][128]

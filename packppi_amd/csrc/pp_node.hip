@@ -17,6 +17,7 @@
 #include <string.h>
 
 #include "pp_internal.h"
+#include <utility>
 
 PP_RANGE_COUNTER
 PP_RANGE_READER(pp_node_range_hits)
@@ -346,7 +347,8 @@ struct NUpdArgs {
     const float *frames;         // [N][12]
     const float *embT;           // [51][128]
     const float *wstream, *params;
-    float *hV;
+    const float *hV;             // h_V of the previous layer (input)
+    float *hV_out;               // where the new h_V goes: the same buffer, or the context's alternate one for split launches
     const float *S, *msum;
     float *ptsN, *PAn, *PCn, *ptsE, *PAe, *PCe, *score;
     unsigned *sat;               // the context's sticky saturation word (bit 1: node kernels)
@@ -654,7 +656,7 @@ k_node_update(NUpdArgs A, float *chi, int step, int sde, const float *noise, int
     x = fold(cH, cL) + *reinterpret_cast<const nf4 *>(par + NU_P_FOB + fc) + h1;
     const nf4 h2 = ln128(sm.stats[1], wv, r, g, x, *reinterpret_cast<const nf4 *>(par + NU_P_G1 + fc),
                          *reinterpret_cast<const nf4 *>(par + NU_P_B1 + fc)) * rm;
-    if (live && clq == 0 && (MODE != PP_NU_STEP || !embed_next)) *reinterpret_cast<nf4 *>(A.hV + (size_t)n * 128 + fc) = h2;
+    if (live && clq == 0 && (MODE != PP_NU_STEP || !embed_next)) *reinterpret_cast<nf4 *>(A.hV_out + (size_t)n * 128 + fc) = h2;
     publish4(sm.a_hi, sm.a_lo, r * NU_S128 + fc, h2);
     __syncthreads();
 #if defined(PP_X_NU_STOP) && PP_X_NU_STOP == 4     /* timing experiment: stop here */
@@ -791,7 +793,7 @@ k_node_update(NUpdArgs A, float *chi, int step, int sde, const float *noise, int
         const nf4 e0 = fold(cH, cL) + (*reinterpret_cast<const nf4 *>(par + NU_P_EMB_B + fc) + oh4);
         const nf4 h0 = ln128(sm.stats[2], wv, r, g, e0, *reinterpret_cast<const nf4 *>(par + NU_P_EMB_G + fc),
                              *reinterpret_cast<const nf4 *>(par + NU_P_EMB_BETA + fc));
-        if (live) *reinterpret_cast<nf4 *>(A.hV + (size_t)n * 128 + fc) = h0;
+        if (live) *reinterpret_cast<nf4 *>(A.hV_out + (size_t)n * 128 + fc) = h0;
         publish4(sm.b_hi, sm.b_lo, r * NU_S128 + fc, h0);
         __syncthreads();
 #if defined(PP_X_NU_STOP) && PP_X_NU_STOP == 7     /* timing experiment: stop here */
@@ -1313,7 +1315,7 @@ pp_status pp_launch_node_update(pp_ctx *c, int layer, int last_mode, float *chi,
     A.embT = p->node_emb_T;
     A.wstream = t.nu_stream;
     A.params = t.nu_params;
-    A.hV = c->hV; A.S = c->S; A.msum = c->msum;
+    A.hV = c->hV; A.hV_out = c->hV; A.S = c->S; A.msum = c->msum;
     A.ptsN = c->ptsN; A.PAn = c->PAn; A.PCn = c->PCn;
     A.ptsE = c->ptsE; A.PAe = c->PAe; A.PCe = c->PCe;
     A.score = c->score;
@@ -1366,6 +1368,10 @@ pp_status pp_launch_node_update(pp_ctx *c, int layer, int last_mode, float *chi,
     const int tiles = (int)grid.x;
     const int cl = last_mode != PP_NU_MID ? 1 : (split_max >= 4 && 4 * tiles <= g_nu_cus) ? 4 : (split_max >= 2 && 2 * tiles <= g_nu_cus) ? 2 : 1;
     if (cl > 1) {
+        // the tile's workgroups all read the old h_V and one of them writes the new one: into the other buffer, so that a
+        // workgroup that starts late (a shared GPU, a busy chip) still reads what it must; the context's pointers swap
+        A.hV_out = c->hV_alt;
+        std::swap(c->hV, c->hV_alt);
         PP_LAUNCH(c, nu_kernel_split(cl), dim3(tiles * cl), block, sizeof(SmemU), s, A, chi, step, sde, noise, embed_next, sp, te);
         PP_HIP_CHECK(hipGetLastError());
         return PP_OK;
