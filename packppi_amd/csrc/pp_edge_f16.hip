@@ -158,6 +158,12 @@ enum { P_BMID = 0, P_BOUT = 128, P_FOB = 256, P_G2 = 384, P_BE2 = 512, P_FIB = 6
 #ifndef PP_WDEPTH
 #define PP_WDEPTH 2
 #endif
+// -DPP_X_TS -DPP_X_TS_FINE=k0: wave 0's clock after each of the 16 stages k0 .. k0 + 15 of the edge update (measurement aid)
+#if defined(PP_X_TS) && defined(PP_X_TS_FINE)
+#define TSF(k) if constexpr ((k) >= PP_X_TS_FINE && (k) < PP_X_TS_FINE + 16) tsf[(k) - PP_X_TS_FINE] = (int)(__builtin_readcyclecounter() - ts0f);
+#else
+#define TSF(k)
+#endif
 #ifndef PP_NXB_R1
 #define PP_NXB_R1 2        // exchange buffers of the one-residue instances (1: 35.5 KB of LDS, four workgroups per CU fit)
 #endif
@@ -172,6 +178,12 @@ enum { P_BMID = 0, P_BOUT = 128, P_FOB = 256, P_G2 = 384, P_BE2 = 512, P_FIB = 6
 #define PP_X_NOWLOAD_ true
 #else
 #define PP_X_NOWLOAD_ false
+#endif
+
+#ifdef PP_X_NOBT         /* timing experiment (results are wrong): only the first tile of a layer's input is read from LDS */
+#define PP_X_NOBT_ true
+#else
+#define PP_X_NOBT_ false
 #endif
 
 #ifdef PP_X_E_NOMFMA     /* timing experiment (results are wrong): the matrix instructions are left out */
@@ -409,6 +421,7 @@ __device__ __forceinline__ void geometry_share(const float *__restrict__ pts_i, 
         const AOp &AK = AR[(k) % NRING];                                                                       \
         BODY;                                                                                                  \
         _Pragma("unroll") for (int r_ = 0; r_ < R; r_++) asm volatile("" ::"v"(ACC[r_][0]));                   \
+        TSF(k)                                                                                                 \
     }
 
 // ---- activations between layers -----------------------------------------------------------------------------------
@@ -434,10 +447,27 @@ __device__ __forceinline__ void geometry_share(const float *__restrict__ pts_i, 
 #define BT_FETCH(BUF, t, set)                                                     \
     _Pragma("unroll") for (int r = 0; r < R; r++) xbuf_get_h((BUF) + r * XBUF_FLOATS, t, lane, bt[set][r]);
 // stage k: B operand = tile T of BUF (tile T+1 is requested first), SWAP as in mfma_h
+// PP_X_PIPE: issue order inside a stage -- the next tile's LDS reads and the weight fetches go out between the first MFMAs (the
+// scheduler otherwise lets them sink to the end of the stage, where the next stage waits for them at once)
+#ifdef PP_X_PIPE
+#define STAGE_ORDER()                                                                                      \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4 * R; i_++) {                                                 \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                 \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                 \
+    }                                                                                                      \
+    _Pragma("unroll") for (int i_ = 0; i_ < 2; i_++) {                                                     \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                 \
+        __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);                                                 \
+    }                                                                                                      \
+    __builtin_amdgcn_sched_group_barrier(0x008, 6 * R, 0);
+#else
+#define STAGE_ORDER()
+#endif
 #define XSTAGE(k, NCH, ACC, BUF, T, SWAP)                                         \
     WSTAGE(k, NCH, ACC, {                                                         \
-        if constexpr ((T) < 3) { BT_FETCH(BUF, (T) + 1, ((T) + 1) & 1) }          \
+        if constexpr ((T) < 3 && !PP_X_NOBT_) { BT_FETCH(BUF, (T) + 1, ((T) + 1) & 1) }          \
         (mfma_h<R, SWAP>(AK, bt[(T) & 1], ACC));                                  \
+        STAGE_ORDER()                                                             \
     })
 #define XLAYER(k0, NCH, ACC, BUF, SWAP)                                           \
     MF_BEGIN()                                                                    \
@@ -558,6 +588,10 @@ __device__ __forceinline__ void node_message_body(const EdgeArgs &A, const int r
         if (!live[r]) n[r] = first;
     constexpr int C0 = ST0 ? 0 : 4;
     constexpr int NCH = C0 + 7;           // chunks: [W_B x4,] W_G x3, W_mid x4
+#if defined(PP_X_TS) && defined(PP_X_TS_FINE)
+    const unsigned long long ts0f = __builtin_readcyclecounter();
+    int tsf[16] = {0};
+#endif
     PROLOGUE_PIPE(NCH)
 
     HT bt[2][R];
@@ -625,10 +659,15 @@ k_node_message(EdgeArgs A) {
 // ---------------------------------------------------------------------------------------------
 // FFN hidden block c (chunks 15 + 8c ..): W1 s=0..3 (input: the x1 tiles) -> hidden tile 4c+wave -> exchange ->
 // W2 s'=0..3 accumulate into out
+// The block's bias tile (global memory: LDS has no room for the 512 values in the one-residue instances) is requested a layer
+// ahead into `fib` -- under the W2 stages of the block before, block 0's before the second LayerNorm: read where it is
+// needed, its L2 round trip (~470 cycles, stage stamps: -DPP_X_TS_FINE) sat on the critical path of every block.
+#define FFN_BIAS_FETCH(c) load_tile(A.params + P_FIB + 128 * (c) + 32 * wave, h, fib);
 #define FFN_BLOCK(c)                                                                                         \
-    _Pragma("unroll") for (int r = 0; r < R; r++) load_tile(A.params + P_FIB + 128 * (c) + 32 * wave, h, acc[r]); \
+    _Pragma("unroll") for (int r = 0; r < R; r++) acc[r] = fib;                                              \
     XLAYER(C0 + 11 + 8 * (c), NCH, acc, x1buf, false)                                                        \
     PUBLISH_RELU()                                                                                           \
+    if constexpr ((c) < 3) { FFN_BIAS_FETCH((c) + 1) }                                                       \
     XLAYER(C0 + 11 + 8 * (c) + 4, NCH, out, xbuf, false)
 
 // -DPP_X_TS: phase timestamps (s_memtime, core-clock cycles since kernel start) of wave 0 to dbg[n][24]
@@ -680,6 +719,10 @@ __device__ __forceinline__ void edge_update_body(const EdgeArgs &A, const int re
     const unsigned long long ts0 = __builtin_readcyclecounter();
     int tsv[24];
 #endif
+#if defined(PP_X_TS) && defined(PP_X_TS_FINE)
+    const unsigned long long ts0f = __builtin_readcyclecounter();
+    int tsf[16] = {0};
+#endif
     PROLOGUE_PIPE(NCH)
 
     HT bt[2][R];
@@ -729,6 +772,8 @@ __device__ __forceinline__ void edge_update_body(const EdgeArgs &A, const int re
     TS(4)
     // ---- x1 = LN2(h_E + mask * m): own tile only, statistics merged across the four waves ---------------
     MF_END()
+    f32x16 fib;
+    FFN_BIAS_FETCH(0)
 #pragma unroll
     for (int r = 0; r < R; r++) {
 #pragma unroll
@@ -840,6 +885,10 @@ __device__ __forceinline__ void edge_update_body(const EdgeArgs &A, const int re
     TS(17)
     if (A.dbg && tid == 0)
         for (int q = 0; q < 18; q++) A.dbg[(size_t)n[0] * 24 + q] = (float)tsv[q];
+#ifdef PP_X_TS_FINE
+    if (A.dbg && tid == 0)
+        for (int q = 0; q < 16; q++) A.dbg[(size_t)n[0] * 24 + q] = (float)tsf[q];
+#endif
 #endif
 }
 
@@ -894,6 +943,10 @@ k_edge_static(EdgeArgs A) {
     const int K = A.K;
     if (A.rmask[n] == 0.f) return;        // never read: the layer kernels leave masked residues early as well
     constexpr int NCH = 8;                // chunks: W_B(node message) x4, W_B(edge message) x4
+#if defined(PP_X_TS) && defined(PP_X_TS_FINE)
+    const unsigned long long ts0f = __builtin_readcyclecounter();
+    int tsf[16] = {0};
+#endif
     PROLOGUE_PIPE(NCH)
     HT x[1][4];
     f32x16 acc[1];
@@ -972,6 +1025,10 @@ k_edge_embed_f16(EmbedArgs A) {
     const int jj = j < K ? j : K - 1;
     constexpr int R = 1;
     constexpr int NCH = 13;
+#if defined(PP_X_TS) && defined(PP_X_TS_FINE)
+    const unsigned long long ts0f = __builtin_readcyclecounter();
+    int tsf[16] = {0};
+#endif
     PROLOGUE_PIPE(NCH)
     for (int t = tid; t < 15; t += ET) s_pos[32][t] = A.bbpos[(size_t)n * 15 + t];
     for (int t = tid; t < 32 * 15; t += ET) {
