@@ -617,6 +617,15 @@ __device__ __forceinline__ void node_message_body(const EdgeArgs &A, const int r
     }
     __syncthreads();                      // geometry operands (and the h_E tiles) are in LDS
     FIRST_LAYER(NCH)
+    // the edge masks of the final reduction are requested before the last layer (read where they are used, their round trip
+    // followed the last MFMA)
+    f32x4v mmv[R][4];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const float *mrow = A.mask_att + (size_t)n[r] * 32 + 4 * h;
+#pragma unroll
+        for (int q = 0; q < 4; q++) mmv[r][q] = *reinterpret_cast<const f32x4v *>(mrow + 8 * q);
+    }
 #pragma unroll
     for (int r = 0; r < R; r++)
 #pragma unroll
@@ -626,11 +635,10 @@ __device__ __forceinline__ void node_message_body(const EdgeArgs &A, const int r
 #pragma unroll
     for (int r = 0; r < R; r++) {
         // rows (registers) are edges e = 8 (r>>2) + 4 h + (r&3); mask and reduce over them
-        const float *mrow = A.mask_att + (size_t)n[r] * 32 + 4 * h;
         float s = 0.f, ms = 0.f;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            const f32x4v mm = *reinterpret_cast<const f32x4v *>(mrow + 8 * q);
+            const f32x4v mm = mmv[r][q];
 #pragma unroll
             for (int pq = 0; pq < 4; pq++) {
                 s = fmaf(fmaxf(acc[r][4 * q + pq], 0.f), mm[pq], s);
@@ -850,6 +858,13 @@ __device__ __forceinline__ void edge_update_body(const EdgeArgs &A, const int re
         WSTAGE(NEU + 6, NCH, acc, (mfma_geo<R, 2>(AK, gbuf, lane, acc)))
         TS(14)
         PUBLISH_RELU()
+        f32x4v mmv[R][4];          // edge masks of the final reduction, requested a layer ahead (as in node_message_body)
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const float *mrow = A.mask_att + (size_t)n[r] * 32 + 4 * h;
+#pragma unroll
+            for (int q = 0; q < 4; q++) mmv[r][q] = *reinterpret_cast<const f32x4v *>(mrow + 8 * q);
+        }
 #pragma unroll
         for (int r = 0; r < R; r++)
 #pragma unroll
@@ -861,11 +876,10 @@ __device__ __forceinline__ void edge_update_body(const EdgeArgs &A, const int re
 #pragma unroll
         for (int r = 0; r < R; r++) {
             // rows (registers) are edges e = 8 (r>>2) + 4 h + (r&3); mask and reduce over them
-            const float *mrow = A.mask_att + (size_t)n[r] * 32 + 4 * h;
             float sacc = 0.f, ms = 0.f;
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                const f32x4v mm = *reinterpret_cast<const f32x4v *>(mrow + 8 * q);
+                const f32x4v mm = mmv[r][q];
 #pragma unroll
                 for (int pq = 0; pq < 4; pq++) {
                     sacc = fmaf(fmaxf(acc[r][4 * q + pq], 0.f), mm[pq], sacc);
