@@ -114,7 +114,7 @@ __device__ __forceinline__ void join_tile(const HT &t, f32x16 &v) {
 #define CH32 (128 * 32)                 // floats per packed weight chunk (16 KB); a wave's quarter is 1024 floats
 #define XBUF_FLOATS (4 * 4 * 64 * 4)    // exchange buffer: [tile][quad][lane] float4
 #define PARAM_FLOATS 1152               // edge kernel: small per-layer vectors, packed by pp_api.hip put_edge_params
-#define PARAM_LDS 640                   // ... of which b_mid | b_out | ffn_out_b | g2 | be2 are staged to LDS (ffn_in_b is read in place)
+#define PARAM_LDS 640                   // ... of which b_mid | b_out | ffn_out_b | g2 | be2 are staged to LDS (ffn_in_b is read in place), then g3 | be3 (256)
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
@@ -744,6 +744,10 @@ __device__ __forceinline__ void edge_update_body(const EdgeArgs &A, const int re
         const int i = min(tid + it * ET, PARAM_LDS / 4 - 1);
         *reinterpret_cast<f32x4v *>(prm + 4 * i) = *reinterpret_cast<const f32x4v *>(A.params + 4 * i);
     }
+    if (tid < 64) {           // the last LayerNorm's gain and bias as well (256 values behind the block above)
+        const float *src = tid < 32 ? A.g3 + 4 * tid : A.be3 + 4 * (tid - 32);
+        *reinterpret_cast<f32x4v *>(prm + PARAM_LDS + 4 * tid) = *reinterpret_cast<const f32x4v *>(src);
+    }
 #pragma unroll
     for (int r = 0; r < R; r++) {
         nbr[r] = A.eidx[(size_t)n[r] * K + jj];
@@ -827,7 +831,7 @@ __device__ __forceinline__ void edge_update_body(const EdgeArgs &A, const int re
         const float rstd = ln_merge(stat + r * STAT_FLOATS, j, mean3);
 #pragma unroll
         for (int q = 0; q < 16; q++) out[r][q] -= mean3;
-        ln_affine_tile(out[r], rstd, A.g3 + 32 * wave, A.be3 + 32 * wave, h);
+        ln_affine_tile(out[r], rstd, prm + PARAM_LDS + 32 * wave, prm + PARAM_LDS + 128 + 32 * wave, h);
 #pragma unroll
         for (int q = 0; q < 16; q++) out[r][q] *= me[r];
         // lanes j >= K mirror edge K - 1 (same inputs, same value): they store it again rather than being masked off
@@ -1184,7 +1188,7 @@ extern "C" void pp_debug_set_lds_pad(int bytes) { g_lds_pad = (size_t)bytes; }
 static size_t pad_smem(size_t b) { return b > g_lds_pad ? b : g_lds_pad; }
 static size_t nm_smem(int R) { return pad_smem(((R == 1 ? PP_NXB_R1 : 1) * R * XBUF_FLOATS + R * GBUF_FLOATS) * sizeof(float)); }
 static size_t eu_smem(int R) {
-    return pad_smem((((R == 1 ? PP_NXB_R1 : 1) + 1) * R * XBUF_FLOATS + R * STAT_FLOATS + PARAM_LDS) * sizeof(float));
+    return pad_smem((((R == 1 ? PP_NXB_R1 : 1) + 1) * R * XBUF_FLOATS + R * STAT_FLOATS + PARAM_LDS + 256) * sizeof(float));
 }
 #define ST_SMEM pad_smem(0)
 #define MAX_SMEM (160 * 1024)
