@@ -64,18 +64,30 @@ def needs_build(lib_path=LIB, flags=None, sources=None):
 def _compile_and_link(lib_path, sources, flags, tag, verbose, only=()):
     hipcc = _hipcc()
     stamp = build_id(flags, sources)
-    objs = []
+    objs, jobs = [], []
     for src in sources:
         obj = os.path.join(CSRC, src.replace(".hip", f".{tag}.o" if tag else ".o"))
         if tag and only and src not in only:
             objs.append(os.path.join(CSRC, src.replace(".hip", ".o")))
             continue
         extra = [f'-DPP_BUILD_ID="{stamp}"'] if src == "pp_api.hip" else []
-        cmd = [hipcc, *flags, *extra, "-c", os.path.join(CSRC, src), "-o", obj]
+        jobs.append([hipcc, *flags, *extra, "-c", os.path.join(CSRC, src), "-o", obj])
+        objs.append(obj)
+    # the translation units are independent: compile them side by side (the edge kernels alone take minutes)
+    workers = max(1, min(len(jobs), int(os.environ.get("PACKPPI_BUILD_JOBS", "0")) or min(5, os.cpu_count() or 1)))
+
+    def _run(cmd):
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
-        objs.append(obj)
+
+    if workers > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=workers) as pool:
+            list(pool.map(_run, jobs))
+    else:
+        for cmd in jobs:
+            _run(cmd)
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib_path, *objs]
     if verbose:
         print(" ".join(cmd), flush=True)
