@@ -192,8 +192,9 @@ void pp_set_error(const std::string &msg);
 // ---- sticky f16 saturation flag of the DEFAULT kernels ------------------------------------------------------------------
 // Hidden activations are clamped at the f16 maximum before they are split (one v_med3).  Every build remembers when that
 // happened: the clamped halves are folded into a per-lane running maximum (v_pk_max_u16 on the packed pair: non-negative
-// f16 bit patterns order like integers), and a lane that saw 0x7BFF (or a NaN pattern above it) ORs a bit into the
-// context's sticky word when the kernel ends.  pp_ctx_saturated reads it.
+// f16 bit patterns order like integers), and a lane that saw 0x7BFF ORs a bit into the
+// context's sticky word when the kernel ends.  pp_ctx_saturated reads it.  NaN activations are not flagged (v_med3 turns
+// them into a finite value first): they cannot arise from finite inputs here, see relu_sat in pp_node.hip.
 __device__ __forceinline__ bool pp_sat_hit(unsigned packed_max) {
     return (packed_max & 0xffffu) >= 0x7bffu || (packed_max >> 16) >= 0x7bffu;
 }

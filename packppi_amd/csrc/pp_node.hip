@@ -427,8 +427,10 @@ __device__ __forceinline__ void publish4(_Float16 *hi, _Float16 *lo, int off, co
     *reinterpret_cast<nu2 *>(lo + off) = l;
 }
 // hidden activations: ReLU, saturated at the f16 maximum (one v_med3)
-// `satm` keeps the largest pre-clamp value this lane has seen (sticky saturation flag, pp_internal.h); NaN inputs are caught
-// by the !(x < limit) form of the final test
+// `satm` keeps the largest pre-clamp value this lane has seen (sticky saturation flag, pp_internal.h).  A NaN is NOT caught
+// (v_max returns the other operand, v_med3 then yields a finite value): with finite weights (pp_plan_create checks them) and
+// f16-range operands an fp32 accumulator cannot overflow (65504^2 x 512 << 3.4e38), so a NaN can only enter through the
+// caller's batch tensors, which this flag is not about
 __device__ __forceinline__ nf4 relu_sat(const nf4 &v, float &satm) {
     satm = __builtin_fmaxf(__builtin_fmaxf(satm, __builtin_fmaxf(v[0], v[1])), __builtin_fmaxf(v[2], v[3]));
     return nf4{__builtin_amdgcn_fmed3f(v[0], 0.f, 65504.f), __builtin_amdgcn_fmed3f(v[1], 0.f, 65504.f),

@@ -91,7 +91,7 @@ __device__ __forceinline__ unsigned long long wave_min_key(unsigned hi, unsigned
 }
 
 __global__ void __launch_bounds__(KNN_THREADS)
-k_knn(const float *__restrict__ X, const float *__restrict__ rmask, const int2 *__restrict__ seg, int K, int ties,
+k_knn(const float *__restrict__ X, const float *__restrict__ rmask, const int2 *__restrict__ seg, int K, int ties, int Lmax,
       int32_t *__restrict__ eidx, float *__restrict__ mask_att) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     pp_tk_pair *q = reinterpret_cast<pp_tk_pair *>(smem_raw);   // [L] (adjusted distance, index in the complex)
@@ -138,7 +138,9 @@ k_knn(const float *__restrict__ X, const float *__restrict__ rmask, const int2 *
     int tie = 0;
     unsigned prev = 0;
     for (int k = 0; k < rounds; k++) {
-        unsigned bv = 0xffffffffu, bi = 0x7fffffffu;
+        // the scan starts at +inf: an element retired to +inf in an earlier round (or a non-finite distance) is never
+        // picked, so a segment with fewer than K finite entries falls through to the masked-out fallback below
+        unsigned bv = 0x7f800000u, bi = 0x7fffffffu;
         for (int j = tid; j < L; j += KNN_THREADS) {
             const unsigned v = __float_as_uint(q[j].v);
             if (v < bv) { bv = v; bi = (unsigned)j; }      // strided scan keeps the lowest j among equal values
@@ -178,7 +180,9 @@ k_knn(const float *__restrict__ X, const float *__restrict__ rmask, const int2 *
         // std::nth_element(q, q + K - 1, q + L) with the whole block: every partition pass is the closed form of
         // pp_topk_aten.h (pp_tk_partition_pivot_lists) -- stop positions by prefix sums, the number of exchanges by a
         // reduction, the exchanges themselves in parallel; then std::sort of the first K - 1 by one lane (31 elements).
-        short *Apos = reinterpret_cast<short *>(q + L), *Bpos = Apos + (KNN_PAR_MAX + 1);
+        // the two stop-position lists sit behind the LONGEST row of the context (Lmax, what the launch sized the allocation
+        // for), not behind this row: a packed context mixes rows of different lengths
+        short *Apos = reinterpret_cast<short *>(q + Lmax), *Bpos = Apos + (KNN_PAR_MAX + 1);
         __shared__ int wtL[2][KNN_THREADS / 64], wtR[2][KNN_THREADS / 64], wtT[KNN_THREADS / 64];
         const unsigned long long lt = (1ull << lane) - 1ull;
         int first = 0, last = L, depth = 2 * pp_tk_lg(L);
@@ -375,14 +379,15 @@ pp_status pp_launch_prepare(pp_ctx *c, hipStream_t s, const int64_t *E_idx) {
                            c->eidx, c->mask_att, reinterpret_cast<int *>(c->scal));
     } else {
     hipLaunchKernelGGL(k_frames, dim3((N + 127) / 128), dim3(128), 0, s, c->b.X, N, c->frames, c->bbpos);
-    size_t smem = (size_t)c->L * sizeof(pp_tk_pair);  // L = the longest complex of the context
-    if (c->L <= KNN_PAR_MAX) smem += 2 * (KNN_PAR_MAX + 1) * sizeof(short);      // stop-position lists of the parallel partition
+    // L = the longest complex of the context; the stop-position lists of the parallel partition (8 KB) always: in a packed
+    // context a shorter complex can take that branch next to one that is too long for it
+    const size_t smem = (size_t)c->L * sizeof(pp_tk_pair) + 2 * (KNN_PAR_MAX + 1) * sizeof(short);
     if (smem > 64 * 1024) {
         PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_knn),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     }
     hipLaunchKernelGGL(k_knn, dim3(N), dim3(KNN_THREADS), smem, s, c->b.X, c->b.residue_mask, c->seg, c->K,
-                       c->plan->knn_ties, c->eidx, c->mask_att);
+                       c->plan->knn_ties, c->L, c->eidx, c->mask_att);
     }
 #ifdef PP_EDGE_F16
     return pp_launch_edge_embed_f16(c, s);      // MFMA form (pp_edge_f16.hip); k_edge_embed below is the fp32 build's

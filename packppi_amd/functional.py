@@ -12,7 +12,7 @@ from typing import List, Tuple
 import torch
 
 from .batch import Batch
-from .lib import Context, Plan
+from .lib import BatchKey, Context, Plan
 
 _geometry_plans = {}
 
@@ -32,11 +32,11 @@ def _ctx_for(batch, plan=None) -> Context:
     """Context cached on the batch object (geometry only unless a network plan is given)."""
     plan = plan or geometry_plan(batch["X"].device)
     cache = batch.__dict__.setdefault("_pp_ctx", {}) if hasattr(batch, "__dict__") else {}
-    key = (id(plan), batch["X"].data_ptr(), tuple(batch["X"].shape))
-    if key not in cache:
+    hit = cache.get(id(plan))
+    if hit is None or not hit[0].matches(batch):       # tensor identity + version counters (lib.BatchKey), not data_ptr
         cache.clear()
-        cache[key] = Context(plan, batch)
-    return cache[key]
+        hit = cache[id(plan)] = (BatchKey(batch), Context(plan, batch))
+    return hit[1]
 
 
 def get_atom14_coords(X, S, BB_D, SC_D):

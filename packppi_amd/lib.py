@@ -46,7 +46,11 @@ def load():
                            "(hipcc --offload-arch=gfx950); there is no CPU fallback")
     lib = C.CDLL(_LIB_PATH)
     vp, f, i = C.c_void_p, C.c_float, C.c_int
-    lib.pp_build_id.restype = C.c_char_p
+    try:
+        lib.pp_build_id.restype = C.c_char_p
+    except AttributeError:
+        raise RuntimeError(f"{_LIB_PATH} is stale: it predates the build stamp (no pp_build_id); rebuild with "
+                           "`python -m packppi_amd.build` (or `python __graft_entry__.py`)") from None
     # a prebuilt library must come from the sources on disk (content hash, packppi_amd/build.py); PACKPPI_LIB variants differ
     # in flags only, so the <sources> half of the stamp is what is compared
     if not os.environ.get("PACKPPI_SKIP_BUILD_CHECK"):
@@ -165,6 +169,32 @@ _BATCH_SPEC = (("X", torch.float32), ("atom_mask", torch.float32), ("residue_typ
                ("chi_2pi_periodic_mask", torch.bool))
 
 
+def _get(batch, key):
+    return batch.get(key) if hasattr(batch, "get") else getattr(batch, key, None)
+
+
+class BatchKey:
+    """What a cached ``Context`` is valid for: the batch tensors themselves (held, so that their storage cannot be handed to
+    another batch while the key lives) and their version counters -- an in-place edit of ``batch.X``, ``residue_mask``,
+    ``residue_index`` ... bumps ``_version`` and the graph, frames and edge embedding are rebuilt, as the reference recomputes
+    them on every call (encoder.py:198-246).  A tensor the context had to copy (dtype / layout) is covered the same way: the
+    key watches the caller's tensor, not the copy."""
+
+    KEYS = tuple(k for k, _ in _BATCH_SPEC) + ("seg_offsets",)
+
+    def __init__(self, batch):
+        self.tensors = [t if isinstance(t, torch.Tensor) else None for t in (_get(batch, k) for k in self.KEYS)]
+        self.meta = self._meta(self.tensors)
+
+    @staticmethod
+    def _meta(ts):
+        return [None if t is None else (t._version, tuple(t.shape), t.dtype) for t in ts]
+
+    def matches(self, batch) -> bool:
+        ts = [t if isinstance(t, torch.Tensor) else None for t in (_get(batch, k) for k in self.KEYS)]
+        return all(a is b for a, b in zip(ts, self.tensors)) and self._meta(ts) == self.meta
+
+
 class Context:
     """One batch of complexes on one GPU: cached kNN graph, edge embedding, frames, workspaces."""
 
@@ -176,7 +206,7 @@ class Context:
         self.B, self.L, self.K = int(B), int(L), min(32, int(L))
         self._t = {}
         for key, dt in _BATCH_SPEC:
-            t = batch.get(key) if hasattr(batch, "get") else getattr(batch, key, None)
+            t = _get(batch, key)
             if t is None:
                 if plan.has_network or key in ("X", "residue_type", "BB_D"):
                     raise RuntimeError(f"batch.{key} is missing")
@@ -188,14 +218,20 @@ class Context:
         pb = PPBatch(self.B, self.L, *[(self._t[k].data_ptr() if self._t[k] is not None else None)
                                        for k, _ in _BATCH_SPEC])
         h = C.c_void_p()
-        seg = batch.get("seg_offsets") if hasattr(batch, "get") else getattr(batch, "seg_offsets", None)
+        seg = _get(batch, "seg_offsets")
         if seg is None:
             _check(lib.pp_complex_prepare(plan.handle, C.byref(pb), _stream(dev), C.byref(h)), "pp_complex_prepare")
         else:
             # ragged batch without padding rows (batch.pack): [1, sum of lengths, ...] + the complexes' first rows; the host
             # copy of the table that pack() carries along saves the read-back
-            host = batch.get("seg_offsets_host") if hasattr(batch, "get") else getattr(batch, "seg_offsets_host", None)
+            host = _get(batch, "seg_offsets_host")
             offs = [int(x) for x in (host if host is not None else seg.tolist())]
+            # the device table is what the kernels index with, the host copy is what K and the launch sizes come from: they
+            # must be the same table (a batch sliced or edited after pack() would only be clamped on the device)
+            if len(offs) != seg.numel():
+                raise RuntimeError(f"seg_offsets has {seg.numel()} entries, seg_offsets_host {len(offs)}")
+            if host is not None and seg.device.type == "cpu" and [int(x) for x in seg.tolist()] != offs:
+                raise RuntimeError("seg_offsets and seg_offsets_host disagree")
             lens = [b - a for a, b in zip(offs[:-1], offs[1:])]
             if self.B != 1 or len(offs) < 2 or offs[-1] != self.L or offs[0] != 0 or min(lens) < 1:
                 raise RuntimeError("seg_offsets does not describe this batch")

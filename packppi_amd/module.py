@@ -15,7 +15,7 @@ import numpy as np
 import torch
 
 from .functional import proximal_optimizer
-from .lib import Context, Plan
+from .lib import BatchKey, Context, Plan
 
 SAMPLE_DEFAULTS = dict(eval_epochs=1, sample_during_training=True, annealed_temp=3, mode="ode", use_proximal=True,
                        violation_tolerance_factor=12., clash_overlap_tolerance=0.5, lamda=1., num_steps=50)
@@ -126,19 +126,20 @@ class TDiffusionModule:
         return dict(self._state_dict)
 
     # ---- internals -------------------------------------------------------------------------
+    def _key_matches(self, batch) -> bool:
+        return self._ctx_key is not None and self._ctx_key.matches(batch)
+
     def _context(self, batch) -> Context:
-        X = batch["X"]
-        key = (X.data_ptr(), tuple(X.shape), batch["residue_mask"].data_ptr())
-        if key != self._ctx_key:
+        if not self._key_matches(batch):
+            self._ctx_key, self._ctx = None, None          # drop the old workspace first: the new context takes it over
             self._ctx = Context(self._plan, batch)
-            self._ctx_key = key
+            self._ctx_key = BatchKey(batch)
         return self._ctx
 
     def _geometry_context(self, batch) -> Context:
         """The batch's network context if it is the cached one, else a weight-free one (atom14 needs no graph or edge
         embedding: metrics of many small complexes must not pay a network preparation each)."""
-        X = batch["X"]
-        if (X.data_ptr(), tuple(X.shape), batch["residue_mask"].data_ptr()) == self._ctx_key:
+        if self._key_matches(batch):
             return self._ctx
         from .functional import _ctx_for
         return _ctx_for(batch)

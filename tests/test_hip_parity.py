@@ -654,6 +654,26 @@ def test_knn_ties_follow_the_reference_cpu_path(L, pitch, weights):
         TDiffusionModule(weights, device=DEV, knn_ties="random")
 
 
+def test_knn_ties_in_a_packed_batch_of_mixed_lengths(weights):
+    """A packed context holding a complex beyond the block-parallel nth_element limit (2 100 >= 2 048 rows: ATen's partial_sort
+    branch) next to one below it (1 600: nth_element by the whole block, with its two stop-position lists in LDS behind the row).
+    The lists are placed behind the LONGEST row of the context; placed behind the row's own length they lay outside the
+    allocation and every tied row of the shorter complex came out wrong (round-3 advisor finding).  Each complex must get the
+    lists it gets alone, which the single-complex test above holds to torch.topk."""
+    from packppi_amd.batch import pack, unpack
+    from packppi_amd.module import TDiffusionModule
+    m = TDiffusionModule(weights, device=DEV)
+    cs = [_gpu(_tie_batch(L, 7 + L, 3.8)) for L in (2100, 1600, 300)]
+    pb = pack(cs)
+    E = m._context(pb).graph()[0]
+    for c, E_c in zip(cs, unpack(pb, E)):
+        ca = c.X[:, :, 1, :].cpu()
+        S = ((ca[:, None] - ca[:, :, None]) ** 2).sum(3) + 1e-6
+        E_ref = torch.topk(torch.from_numpy(np.sqrt(S.numpy())), 32, dim=-1, largest=False)[1]
+        assert torch.equal(E_c.cpu(), E_ref)
+        assert torch.equal(m._context(c).graph()[0], E_c)
+
+
 def _c5_goldens():
     import glob
     out = {}

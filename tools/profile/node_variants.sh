@@ -3,6 +3,7 @@
 # Usage: bash tools/profile/node_variants.sh "<tag> <tag> ..."   ("base" = the default library)
 ROOT=$(pwd)
 export TMPDIR=/tmp
+export HIP_FORCE_DEV_KERNARG=${HIP_FORCE_DEV_KERNARG:-1}      # before rocprofv3 starts: its preloaded library initialises the HIP runtime ahead of python (packppi_amd/__init__.py would set it too late)
 for v in $1; do
   OUT=$ROOT/gpurun_out/nv_$v; mkdir -p $OUT
   if [ "$v" = base ]; then export PACKPPI_LIB=$ROOT/packppi_amd/csrc/libpackppi_hip.so; else export PACKPPI_LIB=$ROOT/packppi_amd/csrc/libpackppi_hip.$v.so; fi

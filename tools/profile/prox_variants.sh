@@ -2,6 +2,7 @@
 # GPU box: kernel-trace stats of the proximal bench for each prebuilt variant library.  Usage: bash tools/profile/prox_variants.sh "base tag ..."
 ROOT=$(pwd)
 export TMPDIR=/tmp
+export HIP_FORCE_DEV_KERNARG=${HIP_FORCE_DEV_KERNARG:-1}      # before rocprofv3 starts: its preloaded library initialises the HIP runtime ahead of python (packppi_amd/__init__.py would set it too late)
 for v in $1; do
   OUT=$ROOT/gpurun_out/pv_$v; mkdir -p $OUT
   if [ "$v" = base ]; then export PACKPPI_LIB=$ROOT/packppi_amd/csrc/libpackppi_hip.so; else export PACKPPI_LIB=$ROOT/packppi_amd/csrc/libpackppi_hip.$v.so; fi

@@ -5,10 +5,11 @@ set -e
 TAG=${1:-v1}; WL=${2:-s1500}
 ROOT=$(pwd); OUT=$ROOT/gpurun_out/stats_$WL; mkdir -p $OUT
 export TMPDIR=/tmp
+export HIP_FORCE_DEV_KERNARG=${HIP_FORCE_DEV_KERNARG:-1}      # before rocprofv3 starts: its preloaded library initialises the HIP runtime ahead of python (packppi_amd/__init__.py would set it too late)
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o run -- python3 $ROOT/bench.py --workload $WL --steps 2 --warmup 1 --cpu-steps 0 --no-secondary > $OUT/bench.json 2> $OUT/err.txt
 cd $ROOT
 f=$(find $OUT -name "*kernel_stats.csv" | head -1)
-cp $f gpurun_out/${GRAFT_ROUND:-r03}_${TAG}_kernel_stats_$WL.csv
+cp $f gpurun_out/${GRAFT_ROUND:-r04}_${TAG}_kernel_stats_$WL.csv
 find $OUT -type f ! -name "bench.json" -delete
-head -8 gpurun_out/${GRAFT_ROUND:-r03}_${TAG}_kernel_stats_$WL.csv | cut -c1-150
+head -8 gpurun_out/${GRAFT_ROUND:-r04}_${TAG}_kernel_stats_$WL.csv | cut -c1-150
