@@ -195,8 +195,9 @@ int pp_edge_variant(void);
  * PP_ERR_UNSUPPORTED.  (pp_plan_create rejects weights that are not finite or outside the f16 range in every build.) */
 int pp_has_range_check(void);
 pp_status pp_range_check(unsigned long long *events, int reset);
-/* The same count by kernel family: the edge-level kernels (which the PACKPPI_EDGE=f32 build replaces by exact-fp32 ones)
- * and the node-level kernels (split f16 in every build: there is no fp32 variant of them). */
+/* The same count by kernel family: the edge-level kernels and the node-level kernels.  libpackppi_hip.f32.so replaces BOTH
+ * families by fp32 ones (fp32-MFMA edge kernels, csrc/pp_edge.hip; fp32 VALU node update, k_node_update_valu in
+ * csrc/pp_node.hip): it has no f16 operand anywhere and is the build for a checkpoint that raises either count. */
 pp_status pp_range_check_parts(unsigned long long *edge_events, unsigned long long *node_events, int reset);
 
 /* Sticky saturation flag, every build (no reference counterpart).  The default kernels clamp hidden activations at the f16
@@ -205,9 +206,22 @@ pp_status pp_range_check_parts(unsigned long long *edge_events, unsigned long lo
  * context are not fp32-equivalent for this checkpoint (run python -m packppi_amd.rangecheck for the details). */
 pp_status pp_ctx_saturated(pp_ctx *ctx, int *flags, void *stream);
 
-/* The library also exports a few undocumented pp_debug_* entry points (single-kernel launches and internal-buffer
- * copies) used only by tools/debug/ to test kernels for run-to-run reproducibility.  They are not part of the
- * drop-in boundary and may change. */
+/* Diagnostics -- ONLY in libpackppi_hip.dbg.so (built with -DPP_DIAG; same kernels and results as the default library):
+ * single launches, internal-buffer copies and a prefix of one network evaluation, for tools/debug/ and the per-layer parity
+ * test (tests/test_hip_layers.py).  Not part of the drop-in boundary; the default, .f32 and .chk libraries do not export them
+ * and read no environment switches. */
+#ifdef PP_DIAG
+pp_status pp_debug_edge(pp_ctx *ctx, int layer, void *stream);     /* one edge-update launch (+ next node message) */
+pp_status pp_debug_nm(pp_ctx *ctx, int layer, void *stream);       /* one node-message launch */
+pp_status pp_debug_set_hE(pp_ctx *ctx, const float *src, size_t n);
+/* which: 0 h_E [N,K,128], 1 S [N,128], 2 msum [N], 3 h_E0, 4 Z_em, 5 h_V [N,128]; waits for the device */
+pp_status pp_debug_buffer(pp_ctx *ctx, int which, float *dst, size_t n);
+/* the first n_launches launches of pp_score's schedule (embed, NM0, NU0, EU0, NU1, EU1, NU2) */
+pp_status pp_debug_score_prefix(pp_ctx *ctx, const float *chi, float t, int n_launches, void *stream);
+void pp_debug_set_dbg(float *p);          /* stamp buffer of the -DPP_LAB -DPP_X_TS builds */
+void pp_debug_set_lds_pad(int bytes);     /* occupancy experiments */
+void pp_debug_set_edge_R(int R);          /* residues per edge workgroup: 1, 2, 0 = automatic */
+#endif
 
 #ifdef __cplusplus
 }

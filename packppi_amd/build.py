@@ -12,8 +12,11 @@ LIB = os.path.join(CSRC, "libpackppi_hip.so")
 # and pp_edge.hip (PACKPPI_EDGE=f32: exact-fp32 MFMA, three workgroups per CU).  Same launchers, same results to ~1e-6.
 EDGE_F16 = os.environ.get("PACKPPI_EDGE", "f16") != "f32"
 SOURCES = ["pp_api.hip", "pp_prepare.hip", "pp_node.hip", "pp_edge_f16.hip" if EDGE_F16 else "pp_edge.hip", "pp_clash.hip"]
+# The flags of the PRODUCT libraries are fixed here: PACKPPI_CFLAGS / -D arguments only reach TAGGED variant libraries
+# (python -m packppi_amd.build --tag NAME -DPP_LAB -DPP_X_...), which lib.load() refuses unless PACKPPI_ALLOW_LAB_LIBRARY=1.
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-variable",
-         "-Wno-unused-but-set-variable"] + (["-DPP_EDGE_F16"] if EDGE_F16 else []) + os.environ.get("PACKPPI_CFLAGS", "").split()
+         "-Wno-unused-but-set-variable"] + (["-DPP_EDGE_F16"] if EDGE_F16 else [])
+PRODUCT_TAGS = ("", "f32", "f16", "chk", "dbg")
 
 
 def _hipcc():
@@ -96,9 +99,16 @@ def _compile_and_link(lib_path, sources, flags, tag, verbose, only=()):
 
 
 def build_library(force=False, verbose=True, extra_flags=(), tag=""):
-    """Build the library; with ``tag`` a variant ``libpackppi_hip.<tag>.so`` (selected at run time by PACKPPI_LIB)."""
+    """Build the library; with ``tag`` a variant ``libpackppi_hip.<tag>.so`` (selected at run time by PACKPPI_LIB).  Extra
+    flags (and PACKPPI_CFLAGS) are for tagged laboratory variants only: the product libraries have fixed flag sets."""
     lib_path = LIB if not tag else LIB.replace(".so", f".{tag}.so")
-    flags = [*FLAGS, *extra_flags]
+    env_flags = os.environ.get("PACKPPI_CFLAGS", "").split()
+    if tag in PRODUCT_TAGS:
+        allowed = {"chk": ["-DPP_CHECK_RANGE"], "dbg": ["-DPP_DIAG"]}.get(tag, [])
+        if env_flags or list(extra_flags) != allowed:
+            raise RuntimeError(f"libpackppi_hip{'.' + tag if tag else ''}.so is a product library with a fixed flag set; extra flags "
+                               f"({' '.join([*extra_flags, *env_flags])}) need their own --tag NAME")
+    flags = [*FLAGS, *extra_flags, *env_flags]
     if not force and not needs_build(lib_path, flags, SOURCES):
         return lib_path
     only = os.environ.get("PACKPPI_VARIANT_SOURCES", "").split()      # tagged build: recompile only these, reuse the base objects
@@ -131,6 +141,29 @@ def build_check_variant(verbose=True):
     compared with the f16 limit and counted; packppi_amd/rangecheck.py runs a checkpoint through it)."""
     os.environ.pop("PACKPPI_VARIANT_SOURCES", None)
     return build_library(verbose=verbose, extra_flags=["-DPP_CHECK_RANGE"], tag="chk")
+
+
+def diag_variant_path():
+    return LIB.replace(".so", ".dbg.so")
+
+
+def build_diag_variant(verbose=True):
+    """``libpackppi_hip.dbg.so``: the default kernels plus -DPP_DIAG -- the pp_debug_* exports (single launches, buffer copies,
+    a prefix of one evaluation) and the launchers' environment switches (PP_NU_SPLIT, PP_EDGE_R ...).  Same kernels, same
+    results; the tests that force launch shapes or read per-layer tensors run on it, the product libraries carry none of it."""
+    os.environ.pop("PACKPPI_VARIANT_SOURCES", None)
+    return build_library(verbose=verbose, extra_flags=["-DPP_DIAG"], tag="dbg")
+
+
+def product_flag_stamps():
+    """{flags half of pp_build_id(): library name} of the four libraries this file builds without laboratory flags."""
+    f32_sources = ["pp_api.hip", "pp_prepare.hip", "pp_node.hip", "pp_edge.hip", "pp_clash.hip"]
+    f16_sources = ["pp_api.hip", "pp_prepare.hip", "pp_node.hip", "pp_edge_f16.hip", "pp_clash.hip"]
+    base = [f for f in FLAGS if f != "-DPP_EDGE_F16"]
+    return {flags_hash(base + ["-DPP_EDGE_F16"], f16_sources): "default (split-f16)",
+            flags_hash(base, f32_sources): "f32",
+            flags_hash(base + ["-DPP_EDGE_F16", "-DPP_CHECK_RANGE"], f16_sources): "chk",
+            flags_hash(base + ["-DPP_EDGE_F16", "-DPP_DIAG"], f16_sources): "dbg"}
 
 
 if __name__ == "__main__":

@@ -801,7 +801,7 @@ extern "C" pp_status pp_sample(pp_ctx *c, float *chi, const float *schedule, int
     // (A hipGraph replay of the loop was measured and dropped: with no stray event records in the stream the kernel
     // trace shows back-to-back dispatches, and capture + replay was 2 % slower than plain launches.)
     if ((st = pp_launch_node_embed(c, chi, steps[0], s)) != PP_OK) return st;
-    static const bool dbg = getenv("PP_DEBUG") != nullptr;
+    static const bool dbg = PP_GETENV("PP_DEBUG") != nullptr;
     const auto h0 = std::chrono::steady_clock::now();
     for (int j = 0; j < nsteps; j++) {
         if ((st = run_network(c, s, j, PP_NU_STEP, chi, mode, sde_noise, &steps[j], j + 1 < nsteps ? &steps[j + 1] : nullptr)) != PP_OK) return st;
@@ -852,7 +852,7 @@ extern "C" pp_status pp_time_kernel(pp_ctx *c, int which, int iters, float *avg_
     if (!c->plan->has_network) FAIL(PP_ERR_INVALID, "pp_time_kernel: plan was created without network weights");
     hipStream_t s = static_cast<hipStream_t>(stream);
     PP_HIP_CHECK(hipSetDevice(c->plan->device));
-    if (getenv("PP_DEBUG")) {
+    if (PP_GETENV("PP_DEBUG")) {
         int a = 0, b = 0;
         pp_edge_occupancy(&a, &b);
         fprintf(stderr, "[pp] resident workgroups/CU: k_node_message %d, k_edge_update %d\n", a, b);
@@ -874,8 +874,9 @@ extern "C" pp_status pp_time_kernel(pp_ctx *c, int which, int iters, float *avg_
     return st;
 }
 
-// Diagnostics (tools/debug only, not part of the documented ABI): run one edge / node-message launch, read or restore
-// an internal buffer.
+// Diagnostics -- libpackppi_hip.dbg.so only (-DPP_DIAG; tools/debug and the per-layer parity test): run single launches or a
+// prefix of one network evaluation, read or restore an internal buffer.  Declared in include/packppi_hip.h under PP_DIAG.
+#ifdef PP_DIAG
 extern "C" pp_status pp_debug_edge(pp_ctx *c, int layer, void *stream) {
     if (!c || !c->plan->has_network) FAIL(PP_ERR_INVALID, "pp_debug_edge: bad ctx");
     return pp_launch_edge_update(c, layer, static_cast<hipStream_t>(stream));
@@ -889,13 +890,36 @@ extern "C" pp_status pp_debug_set_hE(pp_ctx *c, const float *src, size_t n) {
     PP_HIP_CHECK(hipMemcpy(c->hE, src, n * sizeof(float), hipMemcpyDeviceToDevice));
     return PP_OK;
 }
+// which: 0 h_E, 1 S, 2 msum, 3 h_E0, 4 Z_em, 5 h_V
 extern "C" pp_status pp_debug_buffer(pp_ctx *c, int which, float *dst, size_t n) {
     if (!c || !dst) FAIL(PP_ERR_INVALID, "pp_debug_buffer: null");
-    const float *src = which == 0 ? c->hE : which == 1 ? c->S : which == 2 ? c->msum : which == 3 ? c->hE0 : c->Zem;
+    const float *src = which == 0 ? c->hE : which == 1 ? c->S : which == 2 ? c->msum : which == 3 ? c->hE0 : which == 4 ? c->Zem : c->hV;
     PP_HIP_CHECK(hipDeviceSynchronize());
     PP_HIP_CHECK(hipMemcpy(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice));
     return PP_OK;
 }
+// The first `n_launches` kernel launches of one network evaluation at time t (pp_score's schedule: node embedding, then
+// NM0, NU0, EU0(+NM1), NU1, EU1(+NM2), NU2): after 1 + 2 the layer-0 h_V is in place, after 1 + 3 the layer-0 h_E, after
+// 1 + 4 / 1 + 5 the same of layer 1, after 1 + 6 the final h_V (mpnn.py:47-62, layers.py:119-148).
+extern "C" pp_status pp_debug_score_prefix(pp_ctx *c, const float *chi, float t, int n_launches, void *stream) {
+    if (!c || !chi || !c->plan->has_network) FAIL(PP_ERR_INVALID, "pp_debug_score_prefix: bad argument");
+    if (!pp_edge_fused()) FAIL(PP_ERR_UNSUPPORTED, "pp_debug_score_prefix: needs the fused edge update");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    PP_HIP_CHECK(hipSetDevice(c->plan->device));
+    StepParams sp;
+    fill_step(&sp, t, 0.f);
+    pp_status st = PP_OK;
+    int k = 0;
+    auto more = [&]() { return st == PP_OK && k++ < n_launches; };
+    if (more()) st = pp_launch_node_embed(c, chi, sp, s);
+    if (more()) st = pp_launch_node_message(c, 0, s);
+    for (int l = 0; l < 3; l++) {
+        if (more()) st = pp_launch_node_update(c, l, l < 2 ? PP_NU_MID : PP_NU_SCORE, nullptr, 0, PP_MODE_ODE, nullptr, l < 2 ? nullptr : &sp, nullptr, s);
+        if (l < 2 && more()) st = pp_launch_edge_update(c, l, s);
+    }
+    return st;
+}
+#endif
 
 // Measurement aid (bench.py): in-situ duration of one hot kernel.  After pp_profile_kernel(ctx, which) every launch of
 // that kernel inside pp_score / pp_sample carries a start / stop HIP event pair (hipExtLaunchKernelGGL: the

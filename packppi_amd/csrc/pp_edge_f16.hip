@@ -1143,7 +1143,9 @@ pp_status pp_launch_edge_embed_f16(pp_ctx *c, hipStream_t s) {
 }
 
 static float *g_dbg = nullptr;
+#ifdef PP_DIAG
 extern "C" void pp_debug_set_dbg(float *p) { g_dbg = p; }
+#endif
 static EdgeArgs edge_args(pp_ctx *c, int layer, bool edge) {
     const pp_plan *p = c->plan;
     const LayerOff &o = p->off.layer[layer];
@@ -1184,7 +1186,9 @@ static EdgeArgs edge_args(pp_ctx *c, int layer, bool edge) {
 #define PP_LDS_PAD 0           // > 80 KB forces one workgroup per CU (occupancy experiments)
 #endif
 static size_t g_lds_pad = PP_LDS_PAD;     // pp_debug_set_lds_pad(): occupancy experiments
+#ifdef PP_DIAG
 extern "C" void pp_debug_set_lds_pad(int bytes) { g_lds_pad = (size_t)bytes; }
+#endif
 static size_t pad_smem(size_t b) { return b > g_lds_pad ? b : g_lds_pad; }
 static size_t nm_smem(int R) { return pad_smem(((R == 1 ? PP_NXB_R1 : 1) * R * XBUF_FLOATS + R * GBUF_FLOATS) * sizeof(float)); }
 static size_t eu_smem(int R) {
@@ -1237,10 +1241,12 @@ static bool edge_attrs() {
 // confined to one wave per SIMD, and lost to two co-resident R = 1 workgroups on every workload once they were not
 // (T1124 32.8 vs 42.4 k residues/s, S1500 41.5 vs 46.6, C5 shard 43.5 vs 51.0).
 static int g_forced_R = -1;
+#ifdef PP_DIAG
 extern "C" void pp_debug_set_edge_R(int R) { g_forced_R = R; }
+#endif
 static int pick_R(int N) {
     if (g_forced_R < 0) {
-        const char *e = getenv("PP_EDGE_R");
+        const char *e = PP_GETENV("PP_EDGE_R");
         g_forced_R = e ? atoi(e) : 0;
     }
     if (g_forced_R >= 1 && g_forced_R <= PP_RMAX) return g_forced_R;
@@ -1251,7 +1257,7 @@ static int pick_R(int N) {
 static int g_mix = -1;
 static bool use_mix(int N) {
     if (g_mix < 0) {
-        const char *e = getenv("PP_EDGE_MIX");
+        const char *e = PP_GETENV("PP_EDGE_MIX");
         g_mix = e ? atoi(e) : 1;
     }
     if (g_forced_R >= 1 || !g_mix) return false;
@@ -1283,7 +1289,7 @@ pp_status pp_launch_edge_static(pp_ctx *c, hipStream_t s) {
 pp_status pp_launch_node_message(pp_ctx *c, int layer, hipStream_t s) {
     EDGE_ATTR_CHECK()
     EdgeArgs A = edge_args(c, layer, false);
-    static const int nm_R = getenv("PP_NM_R") ? atoi(getenv("PP_NM_R")) : 0;       // measurement aid: residues per workgroup of this kernel only
+    static const int nm_R = PP_GETENV("PP_NM_R") ? atoi(PP_GETENV("PP_NM_R")) : 0;       // measurement aid: residues per workgroup of this kernel only
     const int R = (nm_R >= 1 && nm_R <= PP_RMAX) ? nm_R : pick_R(c->N);
     PP_LAUNCH(c, nm_kernel_r(R, layer == 0), dim3((c->N + R - 1) / R), dim3(ET), nm_smem(R), s, A);
     PP_HIP_CHECK(hipGetLastError());

@@ -9,6 +9,33 @@
 
 #include "../../include/packppi_hip.h"
 
+// ---- product vs laboratory ------------------------------------------------------------------------------------------
+// The kernels double as their own measurement bench: -DPP_X_* switches compile timing variants, most of which give WRONG
+// RESULTS (no weight fetches, no matrix instructions, stop points ...).  None of them may reach a shipped library:
+//   -DPP_LAB   is required by every PP_X_* switch (tools/debug, tools/profile build tagged libraries with it);
+//   -DPP_DIAG  (implied by PP_LAB; the libpackppi_hip.dbg.so build) compiles the pp_debug_* exports and the getenv switches
+//              of the launchers (PP_NU_SPLIT, PP_EDGE_MIX, PP_EDGE_R, PP_NM_R, PP_NODE_F16, PP_DEBUG): same kernels, same
+//              results, forced launch shapes -- the default / .f32 / .chk libraries have neither.
+// packppi_amd/build.py refuses these flags for the three product libraries and lib.load() refuses a library whose flag
+// stamp is not one of the known sets.
+#if defined(PP_LAB) && !defined(PP_DIAG)
+#define PP_DIAG
+#endif
+#if !defined(PP_LAB) &&                                                                                                       \
+    (defined(PP_X_NU_STOP) || defined(PP_X_TS) || defined(PP_X_TS_FINE) || defined(PP_X_PRIO) || defined(PP_X_NOWLOAD) ||        \
+     defined(PP_X_NOBT) || defined(PP_X_PRM_ALIAS) || defined(PP_X_PIPE) || defined(PP_X_NU_EMBED_LAUNCH) ||                     \
+     defined(PP_X_CVT_SCALAR) || defined(PP_X_CVT_PK) || defined(PP_X_NU_NOMFMA) || defined(PP_X_NU_NOLOAD) ||                   \
+     defined(PP_X_NOSAT) || defined(PP_X_NOMFMA) || defined(PP_X_NOACT) || defined(PP_X_E_NOMFMA) || defined(PP_X_CL_NOSCAN) ||  \
+     defined(PP_X_CL_NOPAIR) || defined(PP_WDEPTH) || defined(PP_NXB_R1) || defined(PP_WGS2) || defined(PP_WGS) ||               \
+     defined(PP_LDS_PAD) || defined(PP_NO_FUSE_NM) || defined(PP_NU_DEPTH))
+#error "PP_X_* / tuning switches compile laboratory variants (most give wrong results): add -DPP_LAB and build a TAGGED library (python -m packppi_amd.build --tag NAME -DPP_LAB -DPP_X_...)"
+#endif
+#ifdef PP_DIAG
+#define PP_GETENV(name) getenv(name)
+#else
+#define PP_GETENV(name) ((const char *)nullptr)      /* product builds read no environment switches */
+#endif
+
 #define PP_H 128          // hidden width
 #define PP_MSG_IN 456     // message MLP input width
 #define PP_NPTS 8         // invariant points per node

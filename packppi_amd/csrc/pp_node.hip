@@ -1335,7 +1335,7 @@ pp_status pp_launch_node_update(pp_ctx *c, int layer, int last_mode, float *chi,
     if (next) memcpy(te.v, next->temb, sizeof(te.v));
 #ifndef PP_EDGE_F16
     {       // exact-fp32 library: the VALU kernel (PP_NODE_F16=1 in the environment runs the matrix-pipe kernel here too, for A/B runs)
-        static const bool f16_node = getenv("PP_NODE_F16") != nullptr;
+        static const bool f16_node = PP_GETENV("PP_NODE_F16") != nullptr;
         if (!f16_node) {
             const LayerOff &o = p->off.layer[layer];
             NodeArgs NA = make_args(c);
@@ -1366,7 +1366,7 @@ pp_status pp_launch_node_update(pp_ctx *c, int layer, int last_mode, float *chi,
 #endif
     const bool multi = (int)grid.x > g_nu_cus;
     // middle layers of a launch that leaves most CUs idle: 4 (or 2) workgroups per tile share out the projections
-    static const int split_max = getenv("PP_NU_SPLIT") ? atoi(getenv("PP_NU_SPLIT")) : 4;     // measurement aid: 1 = never
+    static const int split_max = PP_GETENV("PP_NU_SPLIT") ? atoi(PP_GETENV("PP_NU_SPLIT")) : 4;     // measurement aid: 1 = never
     const int tiles = (int)grid.x;
     const int cl = last_mode != PP_NU_MID ? 1 : (split_max >= 4 && 4 * tiles <= g_nu_cus) ? 4 : (split_max >= 2 && 2 * tiles <= g_nu_cus) ? 2 : 1;
     if (cl > 1) {

@@ -51,14 +51,20 @@ def load():
     except AttributeError:
         raise RuntimeError(f"{_LIB_PATH} is stale: it predates the build stamp (no pp_build_id); rebuild with "
                            "`python -m packppi_amd.build` (or `python __graft_entry__.py`)") from None
-    # a prebuilt library must come from the sources on disk (content hash, packppi_amd/build.py); PACKPPI_LIB variants differ
-    # in flags only, so the <sources> half of the stamp is what is compared
+    # a prebuilt library must come from the sources on disk (content hash, packppi_amd/build.py), and from one of the four
+    # product flag sets: a tagged laboratory build (-DPP_LAB -DPP_X_...: timing variants, most with wrong results) only loads
+    # with PACKPPI_ALLOW_LAB_LIBRARY=1
     if not os.environ.get("PACKPPI_SKIP_BUILD_CHECK"):
-        from .build import source_hash
-        have, want = lib.pp_build_id().decode().split("-")[0], source_hash()
+        from .build import product_flag_stamps, source_hash
+        have, _, have_flags = lib.pp_build_id().decode().partition("-")
+        want = source_hash()
         if have != want:
             raise RuntimeError(f"{_LIB_PATH} is stale: built from sources {have}, csrc/ is now {want}; rebuild with "
                                "`python -m packppi_amd.build` (or `python __graft_entry__.py`)")
+        if have_flags not in product_flag_stamps() and not os.environ.get("PACKPPI_ALLOW_LAB_LIBRARY"):
+            raise RuntimeError(f"{_LIB_PATH} was built with flags (stamp {have_flags}) that are none of the product sets "
+                               f"{sorted(product_flag_stamps().values())}: a laboratory variant; set PACKPPI_ALLOW_LAB_LIBRARY=1 "
+                               "to load it for a measurement")
     lib.pp_plan_set_knn_ties.argtypes = [vp, i]
     lib.pp_topk_aten_host.argtypes = [vp, i, i, vp]
     lib.pp_version.restype = C.c_int
