@@ -106,6 +106,11 @@ pp_status pp_plan_set_clash_params(pp_plan *plan, float overlap_tolerance, const
  * csrc/pp_topk_aten.h).  Applies to contexts prepared afterwards. */
 pp_status pp_plan_set_knn_ties(pp_plan *plan, int mode);
 
+/* Replaces sample_cfg.annealed_temp as TDiffusionModule.__init__ hands it to both SO2VESchedule instances
+ * (TorsionalDiffusion.py:70-75; configs/model/sample_cfg/Sampling.yaml:4, default 3): the T of the annealed weight
+ * w = T / (alpha + (1 - alpha) T) in SO2VESchedule.step (schedule.py:205-208).  Applies to later pp_score / pp_sample calls. */
+pp_status pp_plan_set_annealed_temp(pp_plan *plan, float annealed_temp);
+
 /* HOST helper, no device call: idx_out[0..k-1] = torch.topk(values[0..n-1], k, largest=False) indices as ATen's CPU kernel
  * returns them -- the same code the neighbour search runs on the device for rows with ties.  Returns PP_OK / PP_ERR_INVALID. */
 pp_status pp_topk_aten_host(const float *values, int n, int k, int32_t *idx_out);

@@ -1,8 +1,11 @@
 """``eval_diffusion`` command line: PDB in -> sampled side chains -> OUTDIR/structure.pdb + metrics.
 
 Same required flags as the reference's src/eval_diffusion.py:86-93 (--input, --outdir, --molprobity_clash_loc,
---use_proximal, --device).  The reference takes its checkpoint path from Hydra (configs/eval_diffusion.yaml:24);
-here it is --ckpt_path / $PACKPPI_CKPT, and --steps exposes the number of diffusion steps (reference: fixed 30).
+--use_proximal, --device).  The reference composes configs/eval_diffusion.yaml with Hydra and takes its checkpoint path and
+the encoder / model / sampling settings from there (eval_diffusion.py:22-41); here --config_dir (or $PACKPPI_CONFIG_DIR)
+names that configs/ directory and the four hot-path YAML files are read as plain YAML (packppi_amd/config.py): sample_cfg
+(mode, annealed_temp, proximal parameters) is applied, the dimensions are checked against what the kernels are compiled for.
+--ckpt_path / $PACKPPI_CKPT override the tree's ckpt_path; --steps exposes the number of diffusion steps (reference: 30).
 """
 import argparse
 import os
@@ -17,15 +20,21 @@ from ..pdb_io import contains_sidechains, from_pdb_file, to_pdb
 
 
 def load_model(args):
-    ckpt = args.ckpt_path or os.environ.get("PACKPPI_CKPT")
+    from ..config import load_hot_path_configs, resolve_ckpt
+    config_dir = args.config_dir or os.environ.get("PACKPPI_CONFIG_DIR")
+    cfgs = load_hot_path_configs(config_dir) if config_dir else None
+    cfg_kw = dict(encoder_cfg=cfgs.encoder_cfg, model_cfg=cfgs.model_cfg, sample_cfg=cfgs.sample_cfg) if cfgs else {}
+    if cfgs is not None:
+        print(f"----- Using the configuration tree {cfgs.config_dir} -----")
+    ckpt = resolve_ckpt(args.ckpt_path, cfgs)
     if args.random_weights is not None:
         from ..weights import make_random_state_dict
         print(f"----- Using seeded random weights (seed {args.random_weights}); no checkpoint given! -----")
-        model = TDiffusionModule(make_random_state_dict(args.random_weights), device=args.device)
+        model = TDiffusionModule(make_random_state_dict(args.random_weights), device=args.device, **cfg_kw)
     else:
         assert ckpt is not None and os.path.exists(ckpt), "Invalid checkpoint path!"
         print(f"----- Loading {ckpt} checkpoint! -----")
-        model = TDiffusionModule.load_from_checkpoint(ckpt, map_location=args.device, strict=False)
+        model = TDiffusionModule.load_from_checkpoint(ckpt, map_location=args.device, strict=False, **cfg_kw)
     if args.steps is not None:
         model.schedule = torch.linspace(1, 0, args.steps + 1)
     return model.eval()
@@ -62,7 +71,9 @@ def main(argv=None):
     p.add_argument("--molprobity_clash_loc", type=str, help="Path to /build/bin/molprobity.clashscore.", required=True)
     p.add_argument("--use_proximal", action="store_true", help="Use proximal optimize.")
     p.add_argument("--device", type=str, help="cuda (the MI355X HIP device)", default="cuda")
-    p.add_argument("--ckpt_path", type=str, default=None, help="Lightning checkpoint (else $PACKPPI_CKPT).")
+    p.add_argument("--ckpt_path", type=str, default=None, help="Lightning checkpoint (else $PACKPPI_CKPT, else the config tree's ckpt_path).")
+    p.add_argument("--config_dir", type=str, default=None, help="The reference's configs/ directory (else $PACKPPI_CONFIG_DIR): "
+                   "encoder / model / sampling YAML files are read from it.")
     p.add_argument("--steps", type=int, default=None, help="Diffusion steps (reference schedule: 30).")
     p.add_argument("--seed", type=int, default=None, help="Seed of the device generator for the initial noise.")
     p.add_argument("--random_weights", type=int, default=None, help="Seeded stand-in weights instead of a checkpoint.")

@@ -392,6 +392,7 @@ extern "C" pp_status pp_plan_create(const float *weights, size_t n_weights, cons
     p->off = off;
     p->has_network = has_net;
     p->knn_ties = PP_KNN_TIES_ATEN_CPU;
+    p->annealed_temp = 3.0f;      // configs/model/sample_cfg/Sampling.yaml:4
     pp_status st;
     if (has_net) {
     if ((st = upload(&p->w, weights, off.total)) != PP_OK) return st;
@@ -487,6 +488,14 @@ extern "C" pp_status pp_plan_set_knn_ties(pp_plan *p, int mode) {
     if (mode != PP_KNN_TIES_LOWER_INDEX && mode != PP_KNN_TIES_ATEN_CPU && mode != PP_KNN_TIES_ATEN_MEMBER)
         FAIL(PP_ERR_INVALID, "pp_plan_set_knn_ties: unknown mode " + std::to_string(mode));
     p->knn_ties = mode;
+    return PP_OK;
+}
+
+// sample_cfg.annealed_temp (TorsionalDiffusion.py:70-75 -> SO2VESchedule(annealed_temp=...), schedule.py:205-208)
+extern "C" pp_status pp_plan_set_annealed_temp(pp_plan *p, float T) {
+    if (!p) FAIL(PP_ERR_INVALID, "pp_plan_set_annealed_temp: null plan");
+    if (!(T > 0.f) || !std::isfinite(T)) FAIL(PP_ERR_INVALID, "pp_plan_set_annealed_temp: annealed_temp must be a positive number");
+    p->annealed_temp = T;
     return PP_OK;
 }
 
@@ -698,7 +707,7 @@ extern "C" pp_status pp_ctx_set_graph(pp_ctx *c, const int64_t *E_idx, void *str
 
 // ---------------------------------------------------------------------------------------------
 // per-step scalars (schedule.py:165-174,198-235; layers.py:257-268), fp32 like the reference's tensors
-static void fill_step(StepParams *sp, float t, float dt) {
+static void fill_step(StepParams *sp, float t, float dt, float T) {
     const double PI_D = 3.14159265358979323846;
     const double lo = log(0.01 * PI_D), hi = log(PI_D);
     memset(sp, 0, sizeof(*sp));
@@ -715,7 +724,6 @@ static void fill_step(StepParams *sp, float t, float dt) {
     float g = sigma * (float)sqrt(2.0 * log(PI_D / (0.01 * PI_D)));
     float ratio = sigma / (float)exp(hi);
     float alpha = 1.0f - ratio * ratio;
-    const float T = 3.0f;
     sp->w = T / (alpha + (1.0f - alpha) * T);
     sp->c_ode = (0.5f * (g * g)) * dt;
     sp->c_drift = (g * g) * dt;
@@ -773,7 +781,7 @@ extern "C" pp_status pp_score(pp_ctx *c, const float *chi, float t, float *score
     hipStream_t s = static_cast<hipStream_t>(stream);
     PP_HIP_CHECK(hipSetDevice(c->plan->device));
     StepParams sp;
-    fill_step(&sp, t, 0.f);
+    fill_step(&sp, t, 0.f, c->plan->annealed_temp);
     pp_status st;
     if ((st = pp_launch_node_embed(c, chi, sp, s)) != PP_OK) return st;
     if ((st = run_network(c, s, 0, PP_NU_SCORE, nullptr, PP_MODE_ODE, nullptr, &sp, nullptr)) != PP_OK) return st;
@@ -796,7 +804,7 @@ extern "C" pp_status pp_sample(pp_ctx *c, float *chi, const float *schedule, int
     const int nsteps = n_schedule - 1;
     // per-step scalars are kernel arguments: nothing is staged, nothing waits for the stream
     std::vector<StepParams> steps((size_t)nsteps);
-    for (int j = 0; j < nsteps; j++) fill_step(&steps[j], schedule[j], schedule[j] - schedule[j + 1]);
+    for (int j = 0; j < nsteps; j++) fill_step(&steps[j], schedule[j], schedule[j] - schedule[j + 1], c->plan->annealed_temp);
     pp_status st;
     // (A hipGraph replay of the loop was measured and dropped: with no stray event records in the stream the kernel
     // trace shows back-to-back dispatches, and capture + replay was 2 % slower than plain launches.)
@@ -907,7 +915,7 @@ extern "C" pp_status pp_debug_score_prefix(pp_ctx *c, const float *chi, float t,
     hipStream_t s = static_cast<hipStream_t>(stream);
     PP_HIP_CHECK(hipSetDevice(c->plan->device));
     StepParams sp;
-    fill_step(&sp, t, 0.f);
+    fill_step(&sp, t, 0.f, c->plan->annealed_temp);
     pp_status st = PP_OK;
     int k = 0;
     auto more = [&]() { return st == PP_OK && k++ < n_launches; };

@@ -104,6 +104,7 @@ struct pp_plan {
     std::mutex pool_mutex;
     bool has_network;         // false: geometry-only plan (atom14 / clash / proximal)
     int knn_ties;             // PP_KNN_TIES_*: what the neighbour search does on exactly equal distances
+    float annealed_temp;      // sample_cfg.annealed_temp (the T of schedule.py:205-208), default 3
     float *w;                 // device copy of all weights, original layouts
     WeightOff off;
     float *wT;                // device arena of transposed copies

@@ -86,11 +86,18 @@ class TDiffusionModule:
 
     def __init__(self, state_dict: Dict[str, torch.Tensor], sample_cfg: Any = None, encoder_cfg: Any = None,
                  model_cfg: Any = None, device="cuda", knn_ties: Optional[str] = None, **kwargs):
+        """``encoder_cfg`` / ``model_cfg`` / ``sample_cfg``: what eval_diffusion.py:33-40 instantiates from the YAML files (dicts
+        or namespaces; ``config.load_hot_path_configs`` reads them).  The kernels are compiled for the reference's dimensions:
+        any other ``hidden_dim`` / ``top_k`` / ``n_points`` / ``num_rbf`` ... raises a RuntimeError naming the key."""
+        from .config import check_compiled_dims
+        check_compiled_dims(encoder_cfg, model_cfg)
         self._state_dict = {k: v.detach().float().cpu() for k, v in state_dict.items()}
         self.hparams = SimpleNamespace(sample_cfg=_cfg(sample_cfg, SAMPLE_DEFAULTS), encoder_cfg=encoder_cfg,
                                        model_cfg=model_cfg)
         if self.hparams.sample_cfg.mode not in ("ode", "sde"):
             raise NotImplementedError(self.hparams.sample_cfg.mode)
+        if not float(self.hparams.sample_cfg.annealed_temp) > 0:
+            raise RuntimeError(f"sample_cfg.annealed_temp = {self.hparams.sample_cfg.annealed_temp!r}: must be a positive number")
         self.schedule = torch.linspace(1, 0, 31)              # schedule.py:286-288
         self.device = torch.device("cpu")
         self._plan: Optional[Plan] = None
@@ -115,6 +122,7 @@ class TDiffusionModule:
             self._plan = Plan(self._state_dict, device)
             if self._knn_ties is not None:
                 self._plan.set_knn_ties(self._knn_ties)
+            self._plan.set_annealed_temp(self.hparams.sample_cfg.annealed_temp)      # Sampling.yaml:4 -> SO2VESchedule
             self._ctx_key, self._ctx = None, None
         self.device = device
         return self

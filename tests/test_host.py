@@ -125,6 +125,63 @@ def test_lightning_checkpoint_ingest(tmp_path, weights):
     assert set(sd) == set(weights) and all(torch.equal(sd[k], weights[k]) for k in weights)
 
 
+def _write_config_tree(root, **over):
+    """A directory laid out like the reference's configs/ with the four hot-path files (values of the reference's own YAMLs,
+    overridden per test)."""
+    import yaml
+    enc = dict(node_in=35, edge_in=468, node_features=128, edge_features=128, time_embedding_type="sinusoidal",
+               time_embedding_dim=16, num_positional_embeddings=16, num_rbf=16, top_k=32, af2_relpos=True)
+    mdl = dict(hidden_dim=128, num_mpnn_layers=3, n_points=8, dropout=0.1, act="relu", position_scale=1.0, use_ipmp=True,
+               k_neighbors=32)
+    smp = dict(eval_epochs=1, sample_during_training=True, annealed_temp=3, mode="ode", use_proximal=True,
+               violation_tolerance_factor=12., clash_overlap_tolerance=0.5, lamda=1., num_steps=50)
+    top = {"task_name": "eval", "tags": ["dev"], "seed": 42, "ckpt_path": "/path/to/PackPPI_pretrain_last.ckpt",
+           "defaults": ["_self_", {"model": "TorsionalDiffusion.yaml"}], "note": "${paths.root_dir}/x"}
+    for d, name in ((enc, "encoder_cfg"), (mdl, "model_cfg"), (smp, "sample_cfg"), (top, "top")):
+        d.update(over.get(name, {}))
+    for rel, d in (("model/encoder_cfg/ProteinEncoder.yaml", enc), ("model/model_cfg/MpnnNet.yaml", mdl),
+                   ("model/sample_cfg/Sampling.yaml", smp), ("eval_diffusion.yaml", top)):
+        f = root / rel
+        f.parent.mkdir(parents=True, exist_ok=True)
+        f.write_text(yaml.safe_dump(d))
+    return root
+
+
+def test_hot_path_configs_are_read_and_checked(tmp_path, weights):
+    """configs/{eval_diffusion, model/encoder_cfg/ProteinEncoder, model/model_cfg/MpnnNet, model/sample_cfg/Sampling}.yaml as
+    plain YAML (eval_diffusion.py:22-41 composes them with Hydra): sample_cfg reaches the module, dimensions other than the
+    compiled ones raise a RuntimeError that names the key -- before anything touches a device."""
+    from packppi_amd import config
+    from packppi_amd.module import TDiffusionModule
+    cfgs = config.load_hot_path_configs(_write_config_tree(tmp_path / "a", sample_cfg=dict(annealed_temp=2.5, num_steps=7)))
+    assert cfgs.sample_cfg["annealed_temp"] == 2.5 and cfgs.sample_cfg["num_steps"] == 7 and cfgs.encoder_cfg["top_k"] == 32
+    assert cfgs.ckpt_path is None and cfgs.seed == 42             # the shipped placeholder path is not a checkpoint
+    config.check_compiled_dims(cfgs.encoder_cfg, cfgs.model_cfg)
+    assert config.resolve_ckpt("x.ckpt", cfgs) == "x.ckpt"
+    real = tmp_path / "m.ckpt"
+    c2 = config.load_hot_path_configs(_write_config_tree(tmp_path / "b", top=dict(ckpt_path=str(real))))
+    assert c2.ckpt_path == str(real) and config.resolve_ckpt(None, c2) == str(real)
+    for name, key, val in (("model_cfg", "hidden_dim", 256), ("encoder_cfg", "top_k", 48), ("model_cfg", "n_points", 4),
+                           ("encoder_cfg", "num_rbf", 8), ("model_cfg", "num_mpnn_layers", 4), ("encoder_cfg", "af2_relpos", False),
+                           ("model_cfg", "act", "gelu"), ("encoder_cfg", "time_embedding_type", "fourier")):
+        bad = config.load_hot_path_configs(_write_config_tree(tmp_path / f"bad_{key}", **{name: {key: val}}))
+        with pytest.raises(RuntimeError, match=rf"{name}\.{key} = "):
+            config.check_compiled_dims(bad.encoder_cfg, bad.model_cfg)
+        with pytest.raises(RuntimeError, match=key):                 # the module refuses it as well, before any device call
+            TDiffusionModule(weights, encoder_cfg=bad.encoder_cfg, model_cfg=bad.model_cfg, device="cuda")
+    config.check_compiled_dims({"num_positional_embeddings": 99}, {"dropout": 0.5, "k_neighbors": 7})       # not read by the path
+    with pytest.raises(RuntimeError, match="does not exist"):
+        config.load_hot_path_configs(tmp_path / "nowhere")
+    with pytest.raises(RuntimeError, match="annealed_temp"):
+        TDiffusionModule(weights, sample_cfg={"annealed_temp": 0}, device="cuda")
+    ref = "/root/reference/configs"
+    if os.path.isdir(ref):                                           # the reference's own tree (absent on the GPU box)
+        r = config.load_hot_path_configs(ref)
+        config.check_compiled_dims(r.encoder_cfg, r.model_cfg)
+        assert r.sample_cfg["annealed_temp"] == 3 and r.sample_cfg["mode"] == "ode" and r.sample_cfg["num_steps"] == 50
+        assert r.ckpt_path is None
+
+
 def test_check_state_dict_rejects_bad_shapes(weights):
     from packppi_amd.weights import check_state_dict
     bad = dict(weights)

@@ -1,5 +1,6 @@
 #!/bin/bash
 # On the GPU box: bench every library variant under packppi_amd/csrc/variants/ (tools/debug/build_variants.sh).
+export PACKPPI_ALLOW_LAB_LIBRARY=1      # tagged variant libraries (lib.load() refuses them otherwise)
 for so in packppi_amd/csrc/variants/*.so; do
   PACKPPI_LIB=$PWD/$so timeout -k 10 200 python bench.py --steps 5 --warmup 2 --cpu-steps 0 "$@" 2>/dev/null | python -c "
 import sys,json

@@ -1,5 +1,6 @@
 #!/bin/bash
 # GPU box: the default library against one variant library, interleaved.   bash tools/debug/ab_lib.sh <variant tag> [workloads...]
+export PACKPPI_ALLOW_LAB_LIBRARY=1      # tagged variant libraries (lib.load() refuses them otherwise)
 TAG=$1; shift; WLS=${@:-t1124 s1500}
 for rep in 1 2; do
   for so in libpackppi_hip.so libpackppi_hip.$TAG.so; do

@@ -1,6 +1,7 @@
 #!/bin/bash
 # GPU box: the default library against the variant built without the sticky-flag bookkeeping (-DPP_X_NOSAT), interleaved, three
-# workloads.  Build the variant first: PACKPPI_VARIANT_SOURCES="pp_edge_f16.hip pp_api.hip" python -m packppi_amd.build --tag nosat -DPP_X_NOSAT ;  bash tools/debug/ab_sat.sh
+# workloads.  Build the variant first: PACKPPI_VARIANT_SOURCES="pp_edge_f16.hip pp_api.hip" python -m packppi_amd.build --tag nosat -DPP_LAB -DPP_X_NOSAT (load with PACKPPI_ALLOW_LAB_LIBRARY=1) ;  bash tools/debug/ab_sat.sh
+export PACKPPI_ALLOW_LAB_LIBRARY=1      # tagged variant libraries (lib.load() refuses them otherwise)
 for rep in 1 2; do
   for so in libpackppi_hip.so libpackppi_hip.nosat.so; do
     for wl in t1124 s1500; do

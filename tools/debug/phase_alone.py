@@ -1,5 +1,5 @@
 """Phase stamps of the two-residue edge-update workgroup with the CU to itself and with a neighbour (build with
-PACKPPI_CFLAGS=-DPP_X_TS, PP_EDGE_R=2): a synthetic complex of 512 residues gives 256 workgroups (one per CU), 1 024 residues 512
+python -m packppi_amd.build --tag ts -DPP_LAB -DPP_X_TS; PACKPPI_LIB=...ts.so PACKPPI_ALLOW_LAB_LIBRARY=1 PP_EDGE_R=2): a synthetic complex of 512 residues gives 256 workgroups (one per CU), 1 024 residues 512
 (two per CU).  Mean over workgroups of wave 0's stamps, core-clock cycles."""
 import os, sys, ctypes as C
 ROOT = os.path.abspath(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))

@@ -1,4 +1,4 @@
-"""Per-phase time of the fused edge update (build with PACKPPI_CFLAGS=-DPP_X_TS): mean over workgroups of wave 0's
+"""Per-phase time of the fused edge update (build with --tag ts -DPP_LAB -DPP_X_TS, load with PACKPPI_ALLOW_LAB_LIBRARY=1): mean over workgroups of wave 0's
 s_memtime stamps (core-clock cycles, ~2.1 GHz under load)."""
 import os, sys, ctypes as C
 ROOT = os.path.abspath(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))

@@ -1,4 +1,4 @@
-"""Per-stage clock of wave 0 through 16 consecutive stages of the edge update (build with PACKPPI_CFLAGS / --tag: -DPP_X_TS
+"""Per-stage clock of wave 0 through 16 consecutive stages of the edge update (build with --tag: -DPP_LAB -DPP_X_TS
 -DPP_X_TS_FINE=k0; run with PP_EDGE_R=2): one two-residue workgroup per CU (512 residues) and two (1 024)."""
 import os, sys, ctypes as C
 ROOT = os.path.abspath(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))

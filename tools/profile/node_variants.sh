@@ -1,6 +1,7 @@
 #!/bin/bash
 # GPU box: kernel-trace stats of the bench command for each prebuilt node-kernel variant library (timing experiments).
 # Usage: bash tools/profile/node_variants.sh "<tag> <tag> ..."   ("base" = the default library)
+export PACKPPI_ALLOW_LAB_LIBRARY=1      # tagged variant libraries (lib.load() refuses them otherwise)
 ROOT=$(pwd)
 export TMPDIR=/tmp
 export HIP_FORCE_DEV_KERNARG=${HIP_FORCE_DEV_KERNARG:-1}      # before rocprofv3 starts: its preloaded library initialises the HIP runtime ahead of python (packppi_amd/__init__.py would set it too late)

@@ -1,5 +1,6 @@
 #!/bin/bash
 # GPU box: kernel-trace stats of the proximal bench for each prebuilt variant library.  Usage: bash tools/profile/prox_variants.sh "base tag ..."
+export PACKPPI_ALLOW_LAB_LIBRARY=1      # tagged variant libraries (lib.load() refuses them otherwise)
 ROOT=$(pwd)
 export TMPDIR=/tmp
 export HIP_FORCE_DEV_KERNARG=${HIP_FORCE_DEV_KERNARG:-1}      # before rocprofv3 starts: its preloaded library initialises the HIP runtime ahead of python (packppi_amd/__init__.py would set it too late)
