@@ -76,19 +76,23 @@ def gather_metric_rows(ids: torch.Tensor, rows: torch.Tensor, group=None) -> Tup
     n = torch.tensor([ids.numel()], device=dev, dtype=torch.int64)
     counts = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(counts, n, group=group)
-    counts = [int(c.item()) for c in counts]
+    counts = [int(c) for c in torch.cat(counts).tolist()]            # one read-back for all ranks
     cap = max(max(counts), 1)
     W = rows.shape[1] if rows.dim() == 2 else len(METRIC_KEYS)
-    block = torch.zeros(cap, W + 1, device=dev, dtype=torch.float32)
+    # ids travel as int64 in their own block (a float32 column is exact to 2^24 only), the rows as float32
+    id_block = torch.zeros(cap, device=dev, dtype=torch.int64)
+    block = torch.zeros(cap, W, device=dev, dtype=torch.float32)
     if ids.numel():
-        block[: ids.numel(), 0] = ids.to(torch.float32)
-        block[: ids.numel(), 1:] = rows.to(torch.float32)
+        id_block[: ids.numel()] = ids.to(torch.int64)
+        block[: ids.numel()] = rows.to(torch.float32)
+    id_blocks = [torch.empty_like(id_block) for _ in range(world)]
     blocks = [torch.empty_like(block) for _ in range(world)]
+    dist.all_gather(id_blocks, id_block, group=group)
     dist.all_gather(blocks, block, group=group)
+    all_ids = torch.cat([b[:c] for b, c in zip(id_blocks, counts)], 0)
     all_rows = torch.cat([b[:c] for b, c in zip(blocks, counts)], 0)
-    order = torch.argsort(all_rows[:, 0])
-    all_rows = all_rows[order]
-    return all_rows[:, 0].to(torch.int64), all_rows[:, 1:]
+    order = torch.argsort(all_ids)
+    return all_ids[order], all_rows[order]
 
 
 def sample_sharded(model, complexes, use_proximal=False, group=None, init_chi=None, max_rows=200_000, lengths=None,

@@ -169,3 +169,29 @@ def test_get_metric_matches_reference(tmp_path):
     assert sorted(m) == sorted(keys)
     for k in keys:
         assert abs(float(m[k]) - float(z["metric." + k])) < 2e-5 * max(1.0, abs(float(z["metric." + k]))), (k, float(m[k]))
+
+
+@pytest.mark.parametrize("workload,rows", [("t1124", 2), ("c5", 256)])
+def test_bench_two_ranks_as_the_driver_launches_it(workload, rows):
+    """The driver's multi-GPU command line, rehearsed: `python bench.py --gpus 2 ...` started as a FRESH child process (it
+    spawns torch.distributed.run itself before anything touches the GPU), two ranks sharing this box's one GPU over gloo
+    (BENCH_DIST_BACKEND; on a multi-GPU node the backend is "nccl" = RCCL and nothing else differs).  One JSON line, both ranks
+    seen, every metric row gathered, exit code 0."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BENCH_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "PACKPPI_LIB"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--cpu-steps", "0", "--no-secondary", "--workload", workload],
+                       env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-2500:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["metrics_rows_gathered"] == rows
+    assert out["value"] > 0 and out["scaling"] == ("strong" if workload == "c5" else "weak")
+    if workload == "t1124":
+        assert out["parity"]["max_abs_dchi_vs_reference_rad"] < 1e-4

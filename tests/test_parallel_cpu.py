@@ -168,14 +168,17 @@ def test_gather_arguments_are_what_a_device_backend_needs(monkeypatch):
                 assert o.shape == t.shape and o.dtype == t.dtype and o.device == t.device and o.is_contiguous()
             calls.append((tuple(t.shape), t.dtype))
             outs[0].copy_(t)
-            if t.dtype == torch.int64:               # the counts
+            if t.dtype == torch.int64 and t.numel() == 1:          # the counts
                 outs[1].copy_(t + 1)
-            else:                                    # [cap, 1 + W] blocks: rank 1 = rank 0's rows with ids + 100, and one more
+            elif t.dtype == torch.int64:                          # [cap] ids: rank 1 = rank 0's ids + 100, and one more
                 other = torch.zeros_like(t)
-                n0 = int((t[:, 1:].abs().sum(1) > 0).sum())
-                other[:n0] = t[:n0]
-                other[:n0, 0] += 100
-                other[n0, 0], other[n0, 1:] = 999.0, 7.0
+                other[:3] = t[:3] + 100
+                other[3] = (1 << 40) + 7                           # survives: ids are not squeezed through float32
+                outs[1].copy_(other)
+            else:                                                 # [cap, W] rows: rank 1 = rank 0's rows, and one more
+                other = torch.zeros_like(t)
+                other[:3] = t[:3]
+                other[3] = 7.0
                 outs[1].copy_(other)
 
     monkeypatch.setattr(parallel, "dist", FakeDist)
@@ -183,8 +186,8 @@ def test_gather_arguments_are_what_a_device_backend_needs(monkeypatch):
     ids = torch.tensor([4, 2, 9])
     rows = torch.arange(3 * W, dtype=torch.float32).reshape(3, W) + 1
     ids_all, rows_all = gather_metric_rows(ids, rows)
-    assert calls == [((1,), torch.int64), ((4, W + 1), torch.float32)]          # padded to the longest shard (3 + 1)
-    assert ids_all.tolist() == [2, 4, 9, 102, 104, 109, 999] and rows_all.shape == (7, W)
+    assert calls == [((1,), torch.int64), ((4,), torch.int64), ((4, W), torch.float32)]      # padded to the longest shard (3 + 1)
+    assert ids_all.tolist() == [2, 4, 9, 102, 104, 109, (1 << 40) + 7] and rows_all.shape == (7, W) and ids_all.dtype == torch.int64
     assert torch.equal(rows_all[0], rows[1]) and torch.equal(rows_all[3], rows[1]) and bool((rows_all[6] == 7).all())
 
 
