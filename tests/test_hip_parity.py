@@ -158,15 +158,26 @@ def test_sampling_sde(weights):
 #       farthest the reference's own fp32 run gets from it on any fixture (REF_FP32_VS_FP64_WORST).
 PROX_STEPS = (1, 5, 10, 20, 50)
 REF_FP32_VS_FP64_WORST = 3.0e-3      # rad; max over g6_prox_{L64, L120, T1124} of |ref32 - ref64| after 50 steps (L64)
-# What a one-off run of THIS path recorded (tools/debug/prox_flip.py on the MI355X, round 3), per fixture:
-#   first_jump  the first Adam step at which the distance to the reference's fp32 run jumps (x20 within a step): a clash hinge
-#               (clash.py:139-149) that is on in one run and off in the other; 51 = none in 50 steps.  L120: step 19, the pair
-#               (res 23 atom 6) - (res 93 atom 11) has overlap -6.8e-6 A here and +1.6e-6 A in the reference's run at iterate 18.
-#   d64         |this path - ref64| after 50 steps.
-# The test fails if a hinge flips EARLIER than recorded (and names the pair), if the runs differ by more than the smooth
-# rounding growth allows before that step, or if the end state is farther from the fp64 run than recorded x 2.
-PROX_RECORDED = {"L64": dict(first_jump=51, d64=7.9e-4), "L120": dict(first_jump=19, d64=4.6e-3),
-                 "T1124": dict(first_jump=51, d64=2.5e-3), "S1500": dict(first_jump=51, d64=4.6e-3)}
+# A marginal hinge has two legitimate outcomes, and the REFERENCE supplies both (no recording of this path enters the test):
+# g6_prox_L120 holds, next to the reference's fp32 run (traj32) and its fp64 run, the reference's fp32 runs with the overlap
+# tolerance moved by +5e-6 / +1e-5 / +2e-5 / -1e-5 A (alt32_*; tools/oracle/make_golden_prox.py --append-alt-hinge).  Moving the
+# tolerance up by 5e-6 A or more turns the pair (res 23 atom 6) - (res 93 atom 11) off at iterate 18 -- as this path's
+# rounding does (overlap -6.8e-6 A here, +1.6e-6 A in the reference's run) -- and changes NOTHING else: those runs are bit-equal
+# to the tol = 0.5 run through step 18 and leave it at step 19 by exactly the distances measured for this path (7e-4 at step
+# 19, 1.5e-3 at 20, 4.5e-3 at 50).  The test fails if a hinge flips EARLIER than any reference run does (and names the pair), if
+# the runs differ by more than the smooth rounding growth allows before that step, or if the end state is farther than
+# 2 x max(|ref32 - ref64|, 1e-4) from EVERY reference end state (fp64 run, fp32 run, shifted-tolerance runs).
+
+
+def _prox_reference_branches(z):
+    """(first step at which any reference run leaves the tol = 0.5 fp32 run, [(name, end state [1, L, 4])])."""
+    ends = [("reference fp64", torch.from_numpy(z["chi64_step50"]).double()), ("reference fp32", torch.from_numpy(z["chi32_step50"]).double())]
+    first = 51
+    if "alt32_deltas" in z.files:
+        for k, dl in enumerate(z["alt32_deltas"]):
+            ends.append((f"reference fp32, tol {dl:+.0e}", torch.from_numpy(z[f"alt32_step50.{k}"]).double()))
+            first = min(first, int(z[f"alt32_first_jump.{k}"]))
+    return first, ends
 
 
 def _g6(tag):
@@ -213,34 +224,35 @@ def test_proximal(tag):
     host = [c.cpu() for c in chis]
     d = np.array([float(wrapped_absdiff(c[0, idx], ref[n]).max()) for n, c in enumerate(host)])
     assert all(torch.equal(c[0, other], chi0.cpu()[0, other]) for c in host[:10])
-    rec = PROX_RECORDED[tag]
+    ref_first_jump, ref_ends = _prox_reference_branches(z)
     # (1) a hinge that is on in one run and off in the other shows as a jump of the distance within one step
     jumps = [n + 1 for n in range(1, 50) if d[n] > 20 * max(d[n - 1], 2e-6)]
     first_jump = jumps[0] if jumps else 51
-    if first_jump < rec["first_jump"]:
+    if first_jump < ref_first_jump:
         pairs = "(complex too large for the pair search)"
         if chi0.shape[1] <= 800:
             from tools.debug.prox_flip import overlaps_that_differ
             full = chi0.cpu().clone()
             full[0, idx] = ref[first_jump - 2]
             pairs = overlaps_that_differ(b, host[first_jump - 2], full)[:4]
-        raise AssertionError(f"{tag}: a clash hinge flips at step {first_jump}, recorded {rec['first_jump']}: {pairs}")
+        raise AssertionError(f"{tag}: a clash hinge flips at step {first_jump}, in the reference's runs not before {ref_first_jump}: {pairs}")
     # (2) before that step only rounding separates the runs, and it grows the way it grows between the reference's own fp32 and
     # fp64 runs (div_32_64: Adam divides by sqrt(v) of nearly converged coordinates, which amplifies smoothly)
-    calm = min(first_jump, rec["first_jump"], 51) - 1
+    calm = min(first_jump, ref_first_jump, 51) - 1
     env = np.maximum(2e-5, 8 * z["div_32_64"])
     worst = int(np.argmax(d[:calm] / env[:calm]))
     assert (d[:calm] <= env[:calm]).all(), (tag, worst + 1, float(d[worst]), float(env[worst]))
     assert d[:10].max() < 2e-5, (tag, float(d[:10].max()))
-    # (3) the end state against the fp64 arbiter: twice this fixture's own |ref32 - ref64| (floor 1e-4), or twice what this path
-    # recorded where a flipped hinge (L120) or the smooth amplification put it beyond that
-    last = host[-1]
-    ref64 = torch.from_numpy(z["chi64_step50"])
-    d = wrapped_absdiff(last, ref64)
-    bound = 2 * max(float(z["div_32_64"][-1]), 1e-4, rec["d64"] or 0.0)
-    assert d.max() <= bound, (tag, float(d.max()), bound)
-    # a flipped hinge moves the residues of that atom pair (and, through later flips, a few neighbours)
-    assert (d > 1e-4).sum() <= 0.1 * int(mask.sum()), (tag, int((d > 1e-4).sum()), int(mask.sum()))
+    # (3) the end state: within 2 x max(|ref32 - ref64|, 1e-4) of ONE of the reference's own end states -- its fp64 run, its fp32
+    # run, or (L120) its fp32 runs on the other side of the marginal hinge; nothing this path recorded enters the bound
+    last = host[-1].double()
+    bound = 2 * max(float(z["div_32_64"][-1]), 1e-4)
+    dists = [(float(wrapped_absdiff(last, e).max()), name, e) for name, e in ref_ends]
+    dmin, which, end = min(dists, key=lambda t: t[0])
+    print(f"proximal {tag}: end state {dmin:.2e} rad from [{which}] (bound {bound:.1e}); all: " + ", ".join(f"{n} {d:.1e}" for d, n, _ in dists))
+    assert dmin <= bound, (tag, [(n, d) for d, n, _ in dists], bound)
+    # against the branch it follows, only rounding-sized differences; a flipped hinge would move the residues of that atom pair
+    assert (wrapped_absdiff(last, end) > 1e-4).sum() <= 0.1 * int(mask.sum()), (tag, which)
     # the accepted sample (TorsionalDiffusion.py:296-298) and its metric
     assert (losses[-1] < losses[0]) == bool(z["losses32"][-1] < z["losses32"][0])
     from packppi_amd.module import TDiffusionModule
@@ -841,7 +853,7 @@ def test_fp32_variant_library():
     env = dict(os.environ, PACKPPI_LIB=lib, PACKPPI_EXPECT_VARIANT="0" if lib.endswith(".f32.so") else "1")
     sel = ("test_library_variant_is_the_requested_one or test_graph or test_network or test_sampling_ode or test_sampling_sde "
            "or test_T1124_100_steps or test_S1500_100_steps or test_sampling_is_bit_reproducible or test_packed_batch or test_knn_ties "
-           "or test_checkpoint_outside_the_f16_range")
+           "or test_checkpoint_outside_the_f16_range or test_weight_range_envelope_T1124")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_hip_parity.py"), "-q", "-x", "-m", "gpu",
                         "-k", sel, "-p", "no:cacheprovider"], env=env, cwd=root, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
@@ -905,6 +917,55 @@ def test_weight_range_envelope():
         d32 = float(wrapped_absdiff(out3, ref3)[mask3].max())             # and against the fp32 oracle itself where that is meaningful
         assert d32 < max(1e-4, 3 * cond), (name, d32, cond)
         assert m.saturated() == 0, name
+
+
+def _envelope_key(name):
+    return name.replace(" ", "_").replace(",", "").replace("/", "_").replace(":", "").replace("+-", "pm")
+
+
+def test_weight_range_envelope_T1124():
+    """BASELINE configs[1] (T1124, 100 steps, the reference's own initial noise) under weights OUTSIDE the seeded xavier
+    statistics: rescaled linear layers, LayerNorm gain x5 with shifted biases, heavy tails, a "trained-like" draw (LayerNorm
+    gains log-uniform 0.1-10, per-matrix scale log-uniform 1/8-8, 1 % x30 tails) and three variants that push whole operand
+    vectors of the edge kernels below 2^-4, where the unscaled f16 low part is subnormal (tools/oracle/envelope_weights.py).
+    Reference = the UNMODIFIED reference's fp32 and fp64 runs on the same weights and noise (fixture g10_envelope_T1124,
+    tools/oracle/make_golden_envelope.py): this path must end within max(1e-4, 3 |ref32 - ref64|) of the fp64 run -- as
+    close to fp64 as the reference's own fp32 arithmetic is, and inside the 1e-4 rad tolerance wherever 100 reverse steps
+    are well conditioned under those weights -- with the sticky saturation flag clean.  test_fp32_variant_library runs the
+    same on libpackppi_hip.f32.so; PACKPPI_ENVELOPE_REPORT=<file> appends the measured distances (profiles/r04_envelope_T1124.txt)."""
+    from packppi_amd import lib as L
+    from packppi_amd.module import TDiffusionModule
+    from packppi_amd.weights import make_random_state_dict
+    from tools.oracle.envelope_weights import envelope_variants, tiny_operand_variants
+    z = np.load(os.path.join(GOLD, "g10_envelope_T1124.npz"))
+    assert int(z["steps"]) == 100
+    b, g = load_golden("g4_T1124")
+    gb, init = _gpu(b), g["init_chi_seed1124"].to(DEV)
+    mask = b.SC_D_mask.bool()
+    sd0 = make_random_state_dict(20251003)
+    variants = dict(envelope_variants(sd0))
+    variants.update({"tiny operands: " + k: v for k, v in tiny_operand_variants(sd0).items()})
+    assert list(z["variants"]) == list(variants)
+    libname = os.path.basename(os.environ.get("PACKPPI_LIB") or "libpackppi_hip.so")
+    lines = []
+    for name, sd in variants.items():
+        key = _envelope_key(name)
+        ref32, ref64, cond = torch.from_numpy(z["chi32." + key]), torch.from_numpy(z["chi64." + key]), float(z["cond." + key])
+        m = TDiffusionModule(sd, device=DEV)
+        m.schedule = torch.linspace(1, 0, 101)
+        out = m.sample_from(gb, init).cpu()
+        d64 = float(wrapped_absdiff(out, ref64)[mask].max())
+        d32 = float(wrapped_absdiff(out, ref32)[mask].max())
+        lines.append(f"{libname:24s} {name:40s} |ref32 - ref64| {cond:.2e}   |this - ref64| {d64:.2e}   |this - ref32| {d32:.2e}   "
+                     f"saturated {m.saturated()}")
+        print(lines[-1])
+        assert d64 < max(1e-4, 3 * cond), (name, d64, cond)
+        assert d32 < max(1e-4, 3 * cond), (name, d32, cond)
+        if L.load().pp_edge_variant() == 1:
+            assert m.saturated() == 0, name
+    if os.environ.get("PACKPPI_ENVELOPE_REPORT"):
+        with open(os.environ["PACKPPI_ENVELOPE_REPORT"], "a") as fh:
+            fh.write("\n".join(lines) + "\n")
 
 
 def test_checkpoint_outside_the_f16_range(weights):

@@ -200,9 +200,48 @@ def append_trajectory(args, cases, proximal_optimizer):
         print(f"  rewrote {os.path.basename(path)} {os.path.getsize(path) / 1e6:.2f} MB", flush=True)
 
 
+def append_alt_hinge(args, cases, proximal_optimizer):
+    """A hinge of the clash loss whose overlap r_a + r_b - tol - d is within fp32 rounding of zero is on in one fp32
+    implementation and off in another, and the two runs then end O(lr) apart (L120: the pair (res 23 atom 6)-(res 93 atom 11)
+    at iterate 18, +1.6e-6 A here).  The OTHER branch as the reference itself computes it: its fp32 run with the overlap
+    tolerance moved by a few 1e-6 A (tol + delta: every hinge threshold shifts by delta, far below anything but such a marginal
+    pair).  Stored per delta: every step on the residues of traj32 (alt32_traj.<k>), the step at which the run leaves the
+    tol = 0.5 run (alt32_first_jump.<k>) and the end state (alt32_step50.<k>).  A test may require the end state of a run whose
+    hinge flipped to be as close to ONE of the reference's end states as fp32 allows, instead of to a recording of itself."""
+    deltas = [float(x) for x in args.deltas.split(",")]
+    for tag in args.only.split(","):
+        path = os.path.join(GOLD, f"g6_prox_{tag}.npz")
+        old = dict(np.load(path))
+        fx, key = cases[tag]
+        z, b = load_fixture(fx)
+        chi0 = torch.from_numpy(z[key]).float()
+        idx = torch.from_numpy(old["traj32_residues"].astype(np.int64))
+        base = torch.from_numpy(old["traj32"])
+        old["alt32_deltas"] = np.array(deltas, np.float64)
+        for k, dl in enumerate(deltas):
+            t0 = time.time()
+            chis, losses = proximal_optimizer(ref_batch(b), chi0.clone(), 12., 0.5 + dl, 1., 50)
+            chis = [c.detach() for c in chis]
+            d = np.array([float(wrapped(c[0, idx], base[n]).max()) for n, c in enumerate(chis)])
+            jumps = [n + 1 for n in range(1, 50) if d[n] > 20 * max(d[n - 1], 2e-6)]
+            moved_elsewhere = max(float((c[0] != chi0[0]).any(-1)[~torch.isin(torch.arange(chi0.shape[1]), idx)].sum()) for c in chis)
+            old[f"alt32_traj.{k}"] = torch.stack([c[0, idx] for c in chis]).numpy()
+            old[f"alt32_step50.{k}"] = chis[-1].numpy()
+            old[f"alt32_first_jump.{k}"] = np.int64(jumps[0] if jumps else 51)
+            old[f"alt32_losses.{k}"] = np.array(losses, np.float64)
+            print(f"  {tag} tol 0.5 {dl:+.1e}: {time.time() - t0:.0f}s, leaves the tol = 0.5 run at step {jumps[0] if jumps else None} "
+                  f"(distance by step: " + " ".join(f"{x:.1e}" for x in d[[0, 9, 17, 18, 19, 29, 49]]) + f"), residues outside traj32 that move: {moved_elsewhere:.0f}",
+                  flush=True)
+        np.savez_compressed(path, **old)
+        print(f"  rewrote {os.path.basename(path)} {os.path.getsize(path) / 1e6:.2f} MB", flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="L64,L120,T1124,S1500")
+    ap.add_argument("--append-alt-hinge", action="store_true",
+                    help="add the reference's fp32 runs with the overlap tolerance moved by --deltas (the other branch of a marginal hinge)")
+    ap.add_argument("--deltas", default="1e-5,2e-5,-1e-5,5e-6")
     ap.add_argument("--no64", default="S1500", help="cases without the fp64 run (host memory)")
     ap.add_argument("--threads", type=int, default=6)
     ap.add_argument("--append-grads", action="store_true",
@@ -221,6 +260,9 @@ def main():
              "T1124": ("g4_T1124", "chi_ode_100"), "S1500": ("g5_S1500", "chi_ode_100")}
     if args.append_trajectory:
         append_trajectory(args, cases, proximal_optimizer)
+        return
+    if args.append_alt_hinge:
+        append_alt_hinge(args, cases, proximal_optimizer)
         return
     if args.append_grads:
         from src.models.components.clash import compute_residue_clash
