@@ -135,7 +135,7 @@ static void put_chunk_f16(std::vector<float> &arena, const float *W, int ld, int
             for (int lane = 0; lane < 64; lane++)
                 for (int i = 0; i < 8; i++) {
                     const int row = row0 + 32 * wave + (lane & 31), h = lane >> 5;
-                    const int col = colmap(s, h, i);
+                    const int col = colmap(wave, s, h, i);
                     const float w = col >= 0 ? W[(size_t)row * ld + col] : 0.f;
                     const uint16_t hi = f2h(w);
                     const uint16_t lo = f2h(w - h2f(hi));
@@ -146,14 +146,21 @@ static void put_chunk_f16(std::vector<float> &arena, const float *W, int ld, int
 }
 static void put_chunk(std::vector<float> &arena, const float *W, int ld, int row0, int col0, int ncols) {
     (void)ncols;
-    put_chunk_f16(arena, W, ld, row0, [col0](int s, int h, int i) { return col0 + 8 * (2 * s + (i >> 2)) + 4 * h + (i & 3); });
+    put_chunk_f16(arena, W, ld, row0, [col0](int, int s, int h, int i) { return col0 + 8 * (2 * s + (i >> 2)) + 4 * h + (i & 3); });
+}
+// chunk at position p of a ROTATED layer (pp_edge_f16.hip, "ROTATED TILE ORDER"): wave w's quarter holds the columns of input
+// tile (w + p) & 3 of the 128-wide block at col_base -- every wave starts a layer with the tile it produced itself
+static void put_chunk_rot(std::vector<float> &arena, const float *W, int ld, int row0, int col_base, int p) {
+    put_chunk_f16(arena, W, ld, row0, [col_base, p](int wave, int s, int h, int i) {
+        return col_base + 32 * ((wave + p) & 3) + 8 * (2 * s + (i >> 2)) + 4 * h + (i & 3);
+    });
 }
 // geometry chunk C of a message MLP's first layer: features f = 16 (2 C + s) + 8 h + i of the 72 (columns 384 + f)
 // Lane half h of the geometry operand carries the features of points 4h .. 4h+3 only (so the four waves of a workgroup
 // compute one point each), point-major: k-step q = 0..3 holds point 4h + q as
 // p_loc xyz | |p_loc| | local neighbour xyz | its norm; k-step 4 holds the four distances | 0 x4.  k-step S = 2 C + s.
 static void put_geo_chunk(std::vector<float> &arena, const float *W, int C) {
-    put_chunk_f16(arena, W, 456, 0, [C](int s, int h, int i) {
+    put_chunk_f16(arena, W, 456, 0, [C](int, int s, int h, int i) {
         const int S5 = 2 * C + s;
         int f;
         if (S5 < 4) {
@@ -190,6 +197,10 @@ static void put_chunk(std::vector<float> &arena, const float *W, int ld, int row
                 }
 }
 static void put_geo_chunk(std::vector<float> &arena, const float *W, int C) { put_chunk(arena, W, 456, 0, 384 + 24 * C, 24); }
+// (the exact-fp32 edge kernels of pp_edge.hip read their input tiles in natural order)
+static void put_chunk_rot(std::vector<float> &arena, const float *W, int ld, int row0, int col_base, int p) {
+    put_chunk(arena, W, ld, row0, col_base + 32 * p, 32);
+}
 #endif
 // chunk stream of one message MLP: [W_in[:,128:256] x4 unless `skip_wb`,] W_in[:,384:456] x3 (24 cols), W_mid x4
 // [, W_out x4, FFN blocks].  Layer 0 skips the W_B chunks: its W_B h_E0 is precomputed once per complex (k_edge_static).
@@ -197,15 +208,16 @@ static size_t put_stream(std::vector<float> &arena, const float *w, const LayerO
     size_t at = (arena.size() + 3) & ~size_t(3);
     arena.resize(at);
     const float *win = w + (edge ? L.em_in_w : L.nm_in_w), *wmid = w + (edge ? L.em_mid_w : L.nm_mid_w);
+    // the four chunks of a 128-wide input are consumed in rotated tile order by the split-f16 kernels (put_chunk_rot)
     if (!skip_wb)
-        for (int s = 0; s < 4; s++) put_chunk(arena, win, 456, 0, 128 + 32 * s, 32);
+        for (int p = 0; p < 4; p++) put_chunk_rot(arena, win, 456, 0, 128, p);
     for (int g = 0; g < 3; g++) put_geo_chunk(arena, win, g);
-    for (int s = 0; s < 4; s++) put_chunk(arena, wmid, 128, 0, 32 * s, 32);
+    for (int p = 0; p < 4; p++) put_chunk_rot(arena, wmid, 128, 0, 0, p);
     if (edge) {
-        for (int s = 0; s < 4; s++) put_chunk(arena, w + L.em_out_w, 128, 0, 32 * s, 32);
+        for (int p = 0; p < 4; p++) put_chunk_rot(arena, w + L.em_out_w, 128, 0, 0, p);
         for (int c = 0; c < 4; c++) {
-            for (int s = 0; s < 4; s++) put_chunk(arena, w + L.ed_in_w, 128, 128 * c, 32 * s, 32);
-            for (int s = 0; s < 4; s++) put_chunk(arena, w + L.ed_out_w, 512, 0, 128 * c + 32 * s, 32);
+            for (int p = 0; p < 4; p++) put_chunk_rot(arena, w + L.ed_in_w, 128, 128 * c, 0, p);
+            for (int p = 0; p < 4; p++) put_chunk_rot(arena, w + L.ed_out_w, 512, 0, 128 * c, p);
         }
     }
     return at;
@@ -428,7 +440,7 @@ extern "C" pp_status pp_plan_create(const float *weights, size_t n_weights, cons
     size_t o_embed = (arena.size() + 3) & ~size_t(3);
     arena.resize(o_embed);
     for (int cch = 0; cch < 13; cch++)
-        put_chunk_f16(arena, weights + off.edge_emb_w, 468, 0, [cch](int s2, int h, int i) {
+        put_chunk_f16(arena, weights + off.edge_emb_w, 468, 0, [cch](int, int s2, int h, int i) {
             const int k = 32 * cch + 16 * s2 + 8 * h + i;
             return k < 400 ? 65 + k : -1;
         });

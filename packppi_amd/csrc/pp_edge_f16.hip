@@ -164,9 +164,6 @@ enum { P_BMID = 0, P_BOUT = 128, P_FOB = 256, P_G2 = 384, P_BE2 = 512, P_FIB = 6
 #else
 #define TSF(k)
 #endif
-#ifndef PP_NXB_R1
-#define PP_NXB_R1 2        // exchange buffers of the one-residue instances (1: 35.5 KB of LDS, four workgroups per CU fit)
-#endif
 #ifndef PP_WGS2
 #define PP_WGS2 2          // same for the two-residue instances
 #endif
@@ -225,26 +222,23 @@ __device__ __forceinline__ void mfma_x(const AOp &a, const HT (&x)[R][4], f32x16
         }
     }
 }
-// same with one tile per residue (the FFN's hidden tiles, read from the exchange buffer stage by stage)
-template <int R, bool SWAP = false>
-__device__ __forceinline__ void mfma_h(const AOp &a, const HT (&x)[R], f32x16 (&acc)[R]) {
+// one k-step S of a stage (3 R MFMAs) on one tile per residue; a stage = k-steps 0 and 1 of its weight chunk
+template <int R, bool SWAP, int S>
+__device__ __forceinline__ void mfma_hs(const AOp &a, const HT (&x)[R], f32x16 (&acc)[R]) {
+    if (SWAP) {
 #pragma unroll
-    for (int s = 0; s < 2; s++) {
-        if (SWAP) {
+        for (int r = 0; r < R; r++) acc[r] = MFMA16(x[r].hi[S], a.r[2 * S], acc[r]);
 #pragma unroll
-            for (int r = 0; r < R; r++) acc[r] = MFMA16(x[r].hi[s], a.r[2 * s], acc[r]);
+        for (int r = 0; r < R; r++) acc[r] = MFMA16(x[r].lo[S], a.r[2 * S], acc[r]);
 #pragma unroll
-            for (int r = 0; r < R; r++) acc[r] = MFMA16(x[r].lo[s], a.r[2 * s], acc[r]);
+        for (int r = 0; r < R; r++) acc[r] = MFMA16(x[r].hi[S], a.r[2 * S + 1], acc[r]);
+    } else {
 #pragma unroll
-            for (int r = 0; r < R; r++) acc[r] = MFMA16(x[r].hi[s], a.r[2 * s + 1], acc[r]);
-        } else {
+        for (int r = 0; r < R; r++) acc[r] = MFMA16(a.r[2 * S], x[r].hi[S], acc[r]);
 #pragma unroll
-            for (int r = 0; r < R; r++) acc[r] = MFMA16(a.r[2 * s], x[r].hi[s], acc[r]);
+        for (int r = 0; r < R; r++) acc[r] = MFMA16(a.r[2 * S], x[r].lo[S], acc[r]);
 #pragma unroll
-            for (int r = 0; r < R; r++) acc[r] = MFMA16(a.r[2 * s], x[r].lo[s], acc[r]);
-#pragma unroll
-            for (int r = 0; r < R; r++) acc[r] = MFMA16(a.r[2 * s + 1], x[r].hi[s], acc[r]);
-        }
+        for (int r = 0; r < R; r++) acc[r] = MFMA16(a.r[2 * S + 1], x[r].hi[S], acc[r]);
     }
 }
 // the 72 invariant-point features as operands: lane half h carries the features of points 4h .. 4h+3, one point per
@@ -426,10 +420,25 @@ __device__ __forceinline__ void geometry_share(const float *__restrict__ pts_i, 
 
 // ---- activations between layers -----------------------------------------------------------------------------------
 // A layer's input (B operands) is read from LDS tile by tile, one stage ahead of its use, into two rotating operand sets
-// `bt` -- never as a whole 128-feature vector in registers (64 VGPRs): that is what lets three workgroups share a CU
-// (<= 168 VGPRs).  Buffers per residue: xbuf (the exchange buffer every layer publishes into) and, in the edge update,
-// x1buf (the LayerNorm-2 output, which all four FFN blocks and nobody else read) -- 16 KB each, split-f16 tiles.
-// -DPP_X_PRIO=n: wave priority experiments (1/2: static per workgroup kind in the mixed launch, 3: raised inside the MFMA
+// `bt` -- never as a whole 128-feature vector in registers (64 VGPRs): that is what lets two two-residue workgroups share a
+// CU.  Buffers per residue: xbuf (the exchange buffer every layer publishes into) and, in the edge update, x1buf (the
+// LayerNorm-2 output, which all four FFN blocks and nobody else read) -- 16 KB each, split-f16 tiles.
+//
+// ROTATED TILE ORDER (round 4).  Wave w owns output tile w of every layer, so after a layer it holds tile w of the next
+// layer's input in registers -- the one tile it does not have to wait for.  The stages of a layer therefore visit the input
+// tiles in the order w, w+1, w+2, w+3 (mod 4): position 0 takes its B operands straight from the split (registers), and the
+// two workgroup barriers of a hand-over move INSIDE matrix stages, where the wave's own MFMAs (and the other workgroup's)
+// cover them:
+//   barrier B ("every wave has published its tile") sits between the two k-steps of position 0; the LDS reads of the second
+//             tile are issued right behind it and land under the second k-step;
+//   barrier A ("every wave has read the buffer the next publication overwrites") sits between the two k-steps of a later
+//             stage whose operands have arrived -- position 3 of the layer, or of the W1 block in front of the publication.
+// A hand-over used to be: barrier, ReLU + split, LDS write, barrier, LDS read latency, all exposed (~1 300 cycles of a lone
+// workgroup, x10 per launch: profiles/r03_edge_stage_stamps.txt); what stays exposed is the split itself.  The weight stream
+// is private to each wave, so the rotation costs nothing: pp_api.hip put_chunk_rot packs wave w's quarter of the chunk at
+// position p from input tile (w + p) & 3.  (Accumulation order per output feature changes with the wave: results differ
+// from round 3 by fp32 rounding, deterministically.)
+// -DPP_LAB -DPP_X_PRIO=n: wave priority experiments (1/2: static per workgroup kind in the mixed launch, 3: raised inside the MFMA
 // blocks, 4: raised outside them)
 #ifndef PP_X_PRIO
 #define PP_X_PRIO 0
@@ -444,66 +453,63 @@ __device__ __forceinline__ void geometry_share(const float *__restrict__ pts_i, 
 #define MF_BEGIN()
 #define MF_END()
 #endif
+#define ROT(p) ((wave + (p)) & 3)        // input tile at position p of a rotated layer (wave-uniform)
 #define BT_FETCH(BUF, t, set)                                                     \
     _Pragma("unroll") for (int r = 0; r < R; r++) xbuf_get_h((BUF) + r * XBUF_FLOATS, t, lane, bt[set][r]);
-// stage k: B operand = tile T of BUF (tile T+1 is requested first), SWAP as in mfma_h
-// PP_X_PIPE: issue order inside a stage -- the next tile's LDS reads and the weight fetches go out between the first MFMAs (the
-// scheduler otherwise lets them sink to the end of the stage, where the next stage waits for them at once)
-#ifdef PP_X_PIPE
-#define STAGE_ORDER()                                                                                      \
-    _Pragma("unroll") for (int i_ = 0; i_ < 4 * R; i_++) {                                                 \
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                 \
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                 \
-    }                                                                                                      \
-    _Pragma("unroll") for (int i_ = 0; i_ < 2; i_++) {                                                     \
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                 \
-        __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);                                                 \
-    }                                                                                                      \
-    __builtin_amdgcn_sched_group_barrier(0x008, 6 * R, 0);
-#else
-#define STAGE_ORDER()
-#endif
-#define XSTAGE(k, NCH, ACC, BUF, T, SWAP)                                         \
-    WSTAGE(k, NCH, ACC, {                                                         \
-        if constexpr ((T) < 3 && !PP_X_NOBT_) { BT_FETCH(BUF, (T) + 1, ((T) + 1) & 1) }          \
-        (mfma_h<R, SWAP>(AK, bt[(T) & 1], ACC));                                  \
-        STAGE_ORDER()                                                             \
+// every accumulator chain reaches this point before anything behind it is issued (MFMAs are pure: without a use the
+// instruction selection would let them sink past a barrier)
+#define ACC_FENCE(ACC) _Pragma("unroll") for (int r_ = 0; r_ < R; r_++) asm volatile("" ::"v"(ACC[r_][0]));
+// stage k = position P of a rotated layer reading BUF: B operand = bt[P & 1] (tile ROT(P)); the next tile is requested first,
+// or -- FETCH_LATE -- behind the barrier in the middle of the stage (position 0: the tile was published by another wave).
+// BAR: a workgroup barrier between the two k-steps.
+#define RSTAGE(k, NCH, ACC, BUF, P, SWAP, BAR, FETCH_LATE)                                                  \
+    WSTAGE(k, NCH, ACC, {                                                                                   \
+        if constexpr ((P) < 3 && !(FETCH_LATE) && !PP_X_NOBT_) { BT_FETCH(BUF, ROT((P) + 1), ((P) + 1) & 1) }   \
+        (mfma_hs<R, SWAP, 0>(AK, bt[(P) & 1], ACC));                                                        \
+        if constexpr (BAR) { ACC_FENCE(ACC) __syncthreads(); }                                              \
+        if constexpr ((P) < 3 && (FETCH_LATE) && !PP_X_NOBT_) { BT_FETCH(BUF, ROT((P) + 1), ((P) + 1) & 1) }    \
+        (mfma_hs<R, SWAP, 1>(AK, bt[(P) & 1], ACC));                                                        \
     })
-#define XLAYER(k0, NCH, ACC, BUF, SWAP)                                           \
+// a layer whose first B operands (the wave's own tile) are in bt[0] already -- PUBLISH_OWN() put them there and into BUF.
+// BAR_A: barrier A in position 3 (the next publication overwrites BUF and no other barrier lies in between).
+#define RLAYER_OWN(k0, NCH, ACC, BUF, SWAP, BAR_A)                                \
     MF_BEGIN()                                                                    \
-    BT_FETCH(BUF, 0, 0)                                                           \
-    XSTAGE((k0) + 0, NCH, ACC, BUF, 0, SWAP)                                      \
-    XSTAGE((k0) + 1, NCH, ACC, BUF, 1, SWAP)                                      \
-    XSTAGE((k0) + 2, NCH, ACC, BUF, 2, SWAP)                                      \
-    XSTAGE((k0) + 3, NCH, ACC, BUF, 3, SWAP)
-// publish this wave's tile of every residue (ReLU, split) into the exchange buffer and meet the other waves.  With one
-// residue per workgroup there are TWO exchange buffers used alternately (NEXT_XBUF): a buffer is rewritten only after every
-// wave has passed the barrier of the publication in between, so no barrier is needed before writing.  With two residues
-// (LDS is short) there is one, and PRE_PUBLISH is a barrier: every wave must have read the previous exchange.
-#define NEXT_XBUF()   { if constexpr (NXB == 2) xbuf = xbuf == xb0 ? xb0 + R * XBUF_FLOATS : xb0; }
-#define PRE_PUBLISH() { if constexpr (NXB == 1) __syncthreads(); NEXT_XBUF() }
-#define PUBLISH_RELU()                                                            \
+    RSTAGE((k0) + 0, NCH, ACC, BUF, 0, SWAP, true, true)                          \
+    RSTAGE((k0) + 1, NCH, ACC, BUF, 1, SWAP, false, false)                        \
+    RSTAGE((k0) + 2, NCH, ACC, BUF, 2, SWAP, false, false)                        \
+    RSTAGE((k0) + 3, NCH, ACC, BUF, 3, SWAP, BAR_A, false)
+// a layer reading a buffer that was published long ago (x1buf in the FFN blocks 1..3): every tile comes from LDS
+#define RLAYER_BUF(k0, NCH, ACC, BUF, SWAP, BAR_A)                                \
+    MF_BEGIN()                                                                    \
+    BT_FETCH(BUF, ROT(0), 0)                                                      \
+    RSTAGE((k0) + 0, NCH, ACC, BUF, 0, SWAP, false, false)                        \
+    RSTAGE((k0) + 1, NCH, ACC, BUF, 1, SWAP, false, false)                        \
+    RSTAGE((k0) + 2, NCH, ACC, BUF, 2, SWAP, false, false)                        \
+    RSTAGE((k0) + 3, NCH, ACC, BUF, 3, SWAP, BAR_A, false)
+// publish this wave's tile of every residue (split, RELU or not) into BUF and keep it as the B operands of position 0.  No
+// barrier here: B follows inside position 0 of the consuming layer, A was passed inside an earlier stage.
+#define PUBLISH_OWN(RELU, SRC, BUF)                                               \
     MF_END()                                                                      \
-    PRE_PUBLISH()                                                                 \
     _Pragma("unroll") for (int r = 0; r < R; r++) {                               \
-        HT ht;                                                                    \
-        split_tile<true>(acc[r], ht, sat);                                             \
-        xbuf_put_h(xbuf + r * XBUF_FLOATS, wave, lane, ht);                       \
-    }                                                                             \
-    __syncthreads();
+        split_tile<RELU>(SRC[r], bt[0][r], sat);                                  \
+        xbuf_put_h((BUF) + r * XBUF_FLOATS, wave, lane, bt[0][r]);                \
+    }
 
-// shared first layer: acc (tile `wave`) = PA_i + PC_j + W_B h_E + W_G geom, ReLU.  Chunks W_B x4 (absent when ST0:
-// layer 0's W_B h_E0 is timestep-invariant and arrives precomputed in acc), then W_G x3.  C0 = number of W_B chunks.
-// The h_E tiles were published into xbuf by the prologue (each wave its own tile).
-#define FIRST_LAYER(NCH)                                                          \
+// shared first layer: acc (tile `wave`) = PA_i + PC_j + W_B h_E + W_G geom, ReLU.  Chunks W_B x4 (absent when ST0: layer 0's
+// W_B h_E0 is timestep-invariant and arrives precomputed in acc), then W_G x3.  C0 = number of W_B chunks.  The h_E tiles
+// were published by the caller (PUBLISH_OWN: each wave its own tile; position 0's barrier also publishes the geometry
+// operands); with ST0 the caller's barrier did.  Barrier A for the publication that follows sits in front of the last
+// geometry stage (!ST0 only: with ST0 nothing has read xbuf yet).
+#define FIRST_LAYER(K0, NCH)                                                      \
     if constexpr (!ST0) {                                                         \
-        XLAYER(0, NCH, acc, xbuf, false)                                          \
+        RLAYER_OWN((K0) + 0, NCH, acc, xbuf, false, false)                        \
     }                                                                             \
     MF_BEGIN()                                                                    \
-    WSTAGE(C0 + 0, NCH, acc, (mfma_geo<R, 0>(AK, gbuf, lane, acc)))                        \
-    WSTAGE(C0 + 1, NCH, acc, (mfma_geo<R, 1>(AK, gbuf, lane, acc)))                        \
-    WSTAGE(C0 + 2, NCH, acc, (mfma_geo<R, 2>(AK, gbuf, lane, acc)))                        \
-    PUBLISH_RELU()
+    WSTAGE((K0) + C0 + 0, NCH, acc, (mfma_geo<R, 0>(AK, gbuf, lane, acc)))        \
+    WSTAGE((K0) + C0 + 1, NCH, acc, (mfma_geo<R, 1>(AK, gbuf, lane, acc)))        \
+    if constexpr (!ST0) { __syncthreads(); }                                      \
+    WSTAGE((K0) + C0 + 2, NCH, acc, (mfma_geo<R, 2>(AK, gbuf, lane, acc)))        \
+    PUBLISH_OWN(true, acc, xbuf)
 
 #define PROLOGUE_PIPE(NCH)                                                                                     \
     const h8 *wq = reinterpret_cast<const h8 *>(A.wstream) + wave * 256 + lane;    /* this wave's quarter, this lane */ \
@@ -567,9 +573,7 @@ __device__ __forceinline__ float ln_merge(const float *st, int j, float &mean_ou
 // ---------------------------------------------------------------------------------------------
 template <int R, bool ST0>
 __device__ __forceinline__ void node_message_body(const EdgeArgs &A, const int res0, float *smem) {
-    constexpr int NXB = R == 1 ? PP_NXB_R1 : 1;
-    float *const xb0 = smem;
-    float *xbuf = xb0;
+    float *const xbuf = smem;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, h = lane >> 5;
@@ -596,27 +600,27 @@ __device__ __forceinline__ void node_message_body(const EdgeArgs &A, const int r
 
     HT bt[2][R];
     f32x16 acc[R];
-    float *gbuf = smem + NXB * R * XBUF_FLOATS;
+    float *gbuf = smem + R * XBUF_FLOATS;
     const int jj = j < K ? j : K - 1;
     const float bmid = A.b_mid[32 * wave + j];            // SWAP form: feature on the lane
+    int nbr[R];
 #pragma unroll
     for (int r = 0; r < R; r++) {
-        const int nbr = A.eidx[(size_t)n[r] * K + jj];
-        geometry_share(A.pts + (size_t)n[r] * 48, A.frames + (size_t)n[r] * 12, A.pts + (size_t)nbr * 48, h, wave, lane,
+        nbr[r] = A.eidx[(size_t)n[r] * K + jj];
+        geometry_share(A.pts + (size_t)n[r] * 48, A.frames + (size_t)n[r] * 12, A.pts + (size_t)nbr[r] * 48, h, wave, lane,
                        gbuf + r * GBUF_FLOATS);
         const float *hrow = A.hE_in + ((size_t)n[r] * K + jj) * 128;
-        if constexpr (!ST0) {             // this wave's tile of h_E -> split -> exchange buffer
-            HT ht;
-            load_tile(hrow + 32 * wave, h, acc[r]);
-            split_tile<false>(acc[r], ht, sat);
-            xbuf_put_h(xbuf + r * XBUF_FLOATS, wave, lane, ht);
-        }
+        if constexpr (!ST0) load_tile(hrow + 32 * wave, h, acc[r]);      // this wave's tile of h_E (split and published below)
+    }
+    if constexpr (!ST0) { PUBLISH_OWN(false, acc, xbuf) }
+#pragma unroll
+    for (int r = 0; r < R; r++) {
         load_tile(A.PA + (size_t)n[r] * 128 + 32 * wave, h, acc[r]);
-        add_tile(A.PC + (size_t)nbr * 128 + 32 * wave, h, acc[r]);
+        add_tile(A.PC + (size_t)nbr[r] * 128 + 32 * wave, h, acc[r]);
         if constexpr (ST0) add_tile(A.Z + ((size_t)n[r] * K + jj) * 128 + 32 * wave, h, acc[r]);
     }
-    __syncthreads();                      // geometry operands (and the h_E tiles) are in LDS
-    FIRST_LAYER(NCH)
+    if constexpr (ST0) __syncthreads();   // geometry operands are in LDS (otherwise the first W_B stage's barrier says so)
+    FIRST_LAYER(0, NCH)
     // the edge masks of the final reduction are requested before the last layer (read where they are used, their round trip
     // followed the last MFMA)
     f32x4v mmv[R][4];
@@ -630,7 +634,7 @@ __device__ __forceinline__ void node_message_body(const EdgeArgs &A, const int r
     for (int r = 0; r < R; r++)
 #pragma unroll
         for (int q = 0; q < 16; q++) acc[r][q] = bmid;
-    XLAYER(C0 + 3, NCH, acc, xbuf, true)
+    RLAYER_OWN(C0 + 3, NCH, acc, xbuf, true, false)
     MF_END()
 #pragma unroll
     for (int r = 0; r < R; r++) {
@@ -671,12 +675,16 @@ k_node_message(EdgeArgs A) {
 // ahead into `fib` -- under the W2 stages of the block before, block 0's before the second LayerNorm: read where it is
 // needed, its L2 round trip (~470 cycles, stage stamps: -DPP_X_TS_FINE) sat on the critical path of every block.
 #define FFN_BIAS_FETCH(c) load_tile(A.params + P_FIB + 128 * (c) + 32 * wave, h, fib);
+// hidden block c: W1 (input x1buf: block 0 right behind its publication -- own tile first --, blocks 1..3 from LDS, with
+// barrier A for the publication of the hidden tile in their last position: every wave is done with the previous block's W2
+// reads of xbuf by then), ReLU + split + publish into xbuf, W2 (own hidden tile first) accumulating into `out`
 #define FFN_BLOCK(c)                                                                                         \
     _Pragma("unroll") for (int r = 0; r < R; r++) acc[r] = fib;                                              \
-    XLAYER(C0 + 11 + 8 * (c), NCH, acc, x1buf, false)                                                        \
-    PUBLISH_RELU()                                                                                           \
+    if constexpr ((c) == 0) { RLAYER_OWN(C0 + 11 + 8 * (c), NCH, acc, x1buf, false, false) }                 \
+    else { RLAYER_BUF(C0 + 11 + 8 * (c), NCH, acc, x1buf, false, true) }                                     \
+    PUBLISH_OWN(true, acc, xbuf)                                                                             \
     if constexpr ((c) < 3) { FFN_BIAS_FETCH((c) + 1) }                                                       \
-    XLAYER(C0 + 11 + 8 * (c) + 4, NCH, out, xbuf, false)
+    RLAYER_OWN(C0 + 11 + 8 * (c) + 4, NCH, out, xbuf, false, false)
 
 // -DPP_X_TS: phase timestamps (s_memtime, core-clock cycles since kernel start) of wave 0 to dbg[n][24]
 // (tools/debug/phase_times.py)
@@ -690,10 +698,8 @@ k_node_message(EdgeArgs A) {
 // launch, one prologue and one read of h_E less per layer.
 template <int R, bool ST0, bool FUSE>
 __device__ __forceinline__ void edge_update_body(const EdgeArgs &A, const int res0, float *smem) {
-    constexpr int NXB = R == 1 ? PP_NXB_R1 : 1;
-    float *const xb0 = smem;
-    float *xbuf = xb0, *x1buf = smem + NXB * R * XBUF_FLOATS, *stat = x1buf + R * XBUF_FLOATS,
-          *prm = stat + R * STAT_FLOATS;
+    float *const xbuf = smem, *const x1buf = smem + R * XBUF_FLOATS, *const stat = x1buf + R * XBUF_FLOATS,
+                 *const prm = stat + R * STAT_FLOATS;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, h = lane >> 5;
@@ -738,7 +744,7 @@ __device__ __forceinline__ void edge_update_body(const EdgeArgs &A, const int re
     float *gbuf = x1buf;      // the geometry operands borrow the x1 buffer: dead until LayerNorm 2 and again after the FFN
     int nbr[R];
     float me[R];
-    // the small per-layer vectors go to LDS once (published by the first exchange barrier)
+    // the small per-layer vectors go to LDS once (published by the first barrier)
 #pragma unroll
     for (int it = 0; it < (PARAM_LDS / 4 + ET - 1) / ET; it++) {
         const int i = min(tid + it * ET, PARAM_LDS / 4 - 1);
@@ -755,32 +761,31 @@ __device__ __forceinline__ void edge_update_body(const EdgeArgs &A, const int re
         geometry_share(A.pts + (size_t)n[r] * 48, A.frames + (size_t)n[r] * 12, A.pts + (size_t)nbr[r] * 48, h, wave, lane,
                        gbuf + r * GBUF_FLOATS);
         // this wave's tile of h_E: the residual input of the first LayerNorm (kept in `out`) and, split, a quarter of
-        // the first layer's B operands (published; layer 0 needs no B operands: W_B h_E0 arrives in Z)
+        // the first layer's B operands (layer 0 needs no B operands: W_B h_E0 arrives in Z)
         load_tile(A.hE_in + ((size_t)n[r] * K + jj) * 128 + 32 * wave, h, out[r]);
-        if constexpr (!ST0) {
-            HT ht;
-            split_tile<false>(out[r], ht, sat);
-            xbuf_put_h(xbuf + r * XBUF_FLOATS, wave, lane, ht);
-        }
+    }
+    if constexpr (!ST0) { PUBLISH_OWN(false, out, xbuf) }
+#pragma unroll
+    for (int r = 0; r < R; r++) {
         load_tile(A.PA + (size_t)n[r] * 128 + 32 * wave, h, acc[r]);
         add_tile(A.PC + (size_t)nbr[r] * 128 + 32 * wave, h, acc[r]);
         if constexpr (ST0) add_tile(A.Z + ((size_t)n[r] * K + jj) * 128 + 32 * wave, h, acc[r]);
     }
-    __syncthreads();                      // geometry operands (and the h_E tiles) are in LDS
+    if constexpr (ST0) __syncthreads();   // geometry operands and parameters are in LDS (otherwise the first W_B stage's barrier says so)
     TS(0)
-    FIRST_LAYER(NCH)
+    FIRST_LAYER(0, NCH)
     TS(1)
-    // ---- second layer (chunks 7..10) -------------------------------------------------------------
+    // ---- second layer (chunks C0 + 3 ..): barrier A in its last position, the third layer's input overwrites xbuf --------
 #pragma unroll
     for (int r = 0; r < R; r++) load_tile(prm + P_BMID + 32 * wave, h, acc[r]);
-    XLAYER(C0 + 3, NCH, acc, xbuf, false)
+    RLAYER_OWN(C0 + 3, NCH, acc, xbuf, false, true)
     TS(2)
-    PUBLISH_RELU()
+    PUBLISH_OWN(true, acc, xbuf)
     TS(3)
-    // ---- third layer (chunks 11..14) --------------------------------------------------------------
+    // ---- third layer (chunks C0 + 7 ..) -----------------------------------------------------------
 #pragma unroll
     for (int r = 0; r < R; r++) load_tile(prm + P_BOUT + 32 * wave, h, acc[r]);
-    XLAYER(C0 + 7, NCH, acc, xbuf, false)
+    RLAYER_OWN(C0 + 7, NCH, acc, xbuf, false, false)
     TS(4)
     // ---- x1 = LN2(h_E + mask * m): own tile only, statistics merged across the four waves ---------------
     MF_END()
@@ -801,14 +806,12 @@ __device__ __forceinline__ void edge_update_body(const EdgeArgs &A, const int re
 #pragma unroll
         for (int q = 0; q < 16; q++) out[r][q] -= mean;
         ln_affine_tile(out[r], rstd, prm + P_G2 + 32 * wave, prm + P_BE2 + 32 * wave, h);
-        HT ht;
-        split_tile<false>(out[r], ht, sat);
-        xbuf_put_h(x1buf + r * XBUF_FLOATS, wave, lane, ht);
-        // `out` keeps x1 (this wave's tile, fp32) as the residual of the second LayerNorm and collects the FFN output
-        // on top of it: out = x1 + b + W2 relu(W1 x1 + b1)
-        add_tile(prm + P_FOB + 32 * wave, h, out[r]);
     }
-    __syncthreads();
+    PUBLISH_OWN(false, out, x1buf)        // (x1buf last held the geometry operands: read before the barriers above)
+    // `out` keeps x1 (this wave's tile, fp32) as the residual of the second LayerNorm and collects the FFN output
+    // on top of it: out = x1 + b + W2 relu(W1 x1 + b1)
+#pragma unroll
+    for (int r = 0; r < R; r++) add_tile(prm + P_FOB + 32 * wave, h, out[r]);
     TS(6)
     // ---- FFN 128 -> 512 -> 128 in four hidden blocks of 128 ------------------------------------------
     FFN_BLOCK(0)
@@ -840,28 +843,26 @@ __device__ __forceinline__ void edge_update_body(const EdgeArgs &A, const int re
     TS(12)
     if constexpr (FUSE) {
         // ---- next layer's node message on the fresh edges ------------------------------------------------
-        // (the buffer written here was last read by the W2 stages of an FFN block: every wave has passed the LayerNorm
-        //  barrier since)
-        NEXT_XBUF()
+        // (xbuf was last read by the W2 stages of FFN block 3, the geometry block = x1buf by its W1 stages: every wave
+        //  has passed the LayerNorm barrier since)
+        PUBLISH_OWN(false, out, xbuf)
 #pragma unroll
         for (int r = 0; r < R; r++) {
-            HT ht;
-            split_tile<false>(out[r], ht, sat);
-            xbuf_put_h(xbuf + r * XBUF_FLOATS, wave, lane, ht);
             geometry_share(A.pts2 + (size_t)n[r] * 48, A.frames + (size_t)n[r] * 12, A.pts2 + (size_t)nbr[r] * 48, h, wave,
                            lane, gbuf + r * GBUF_FLOATS);
             load_tile(A.PA2 + (size_t)n[r] * 128 + 32 * wave, h, acc[r]);
             add_tile(A.PC2 + (size_t)nbr[r] * 128 + 32 * wave, h, acc[r]);
         }
         const float bmid = A.b_mid2[32 * wave + j];           // SWAP form: feature on the lane
-        __syncthreads();
         TS(13)
-        XLAYER(NEU + 0, NCH, acc, xbuf, false)
+        // the next message's first layer always has its W_B stages (the edges are fresh): NM_FIRST = FIRST_LAYER with ST0 false
+        RLAYER_OWN(NEU + 0, NCH, acc, xbuf, false, false)
         WSTAGE(NEU + 4, NCH, acc, (mfma_geo<R, 0>(AK, gbuf, lane, acc)))
         WSTAGE(NEU + 5, NCH, acc, (mfma_geo<R, 1>(AK, gbuf, lane, acc)))
+        __syncthreads();                  // barrier A of the publication below
         WSTAGE(NEU + 6, NCH, acc, (mfma_geo<R, 2>(AK, gbuf, lane, acc)))
         TS(14)
-        PUBLISH_RELU()
+        PUBLISH_OWN(true, acc, xbuf)
         f32x4v mmv[R][4];          // edge masks of the final reduction, requested a layer ahead (as in node_message_body)
 #pragma unroll
         for (int r = 0; r < R; r++) {
@@ -874,7 +875,7 @@ __device__ __forceinline__ void edge_update_body(const EdgeArgs &A, const int re
 #pragma unroll
             for (int q = 0; q < 16; q++) acc[r][q] = bmid;
         TS(15)
-        XLAYER(NEU + 7, NCH, acc, xbuf, true)
+        RLAYER_OWN(NEU + 7, NCH, acc, xbuf, true, false)
         TS(16)
         MF_END()
 #pragma unroll
@@ -1190,9 +1191,9 @@ static size_t g_lds_pad = PP_LDS_PAD;     // pp_debug_set_lds_pad(): occupancy e
 extern "C" void pp_debug_set_lds_pad(int bytes) { g_lds_pad = (size_t)bytes; }
 #endif
 static size_t pad_smem(size_t b) { return b > g_lds_pad ? b : g_lds_pad; }
-static size_t nm_smem(int R) { return pad_smem(((R == 1 ? PP_NXB_R1 : 1) * R * XBUF_FLOATS + R * GBUF_FLOATS) * sizeof(float)); }
+static size_t nm_smem(int R) { return pad_smem((R * XBUF_FLOATS + R * GBUF_FLOATS) * sizeof(float)); }
 static size_t eu_smem(int R) {
-    return pad_smem((((R == 1 ? PP_NXB_R1 : 1) + 1) * R * XBUF_FLOATS + R * STAT_FLOATS + PARAM_LDS + 256) * sizeof(float));
+    return pad_smem((2 * R * XBUF_FLOATS + R * STAT_FLOATS + PARAM_LDS + 256) * sizeof(float));
 }
 #define ST_SMEM pad_smem(0)
 #define MAX_SMEM (160 * 1024)
