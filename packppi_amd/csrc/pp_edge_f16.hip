@@ -242,7 +242,7 @@ __device__ __forceinline__ void mfma_hs(const AOp &a, const HT (&x)[R], f32x16 (
     }
 }
 // the 72 invariant-point features as operands: lane half h carries the features of points 4h .. 4h+3, one point per
-// k-step S5 = 0..3 and the four distances in k-step 4 (geometry_share below); geometry chunk C holds k-steps 2C and 2C+1
+// k-step S5 = 0..3 and the four distances in k-step 4 (geometry_put below); geometry chunk C holds k-steps 2C and 2C+1
 // (the last one is all padding and skipped).  The operands live in a 10 KB LDS block per residue, [k-step][hi | lo][lane] h8.
 #define GBUF_FLOATS (5 * 2 * 64 * 4)
 template <int R, int C>
@@ -279,6 +279,21 @@ __device__ __forceinline__ void add_tile(const float *__restrict__ row32, int h,
     for (int q = 0; q < 4; q++) {
         f32x4v a = *reinterpret_cast<const f32x4v *>(row32 + 8 * q + 4 * h);
         d[4 * q] += a[0]; d[4 * q + 1] += a[1]; d[4 * q + 2] += a[2]; d[4 * q + 3] += a[3];
+    }
+}
+// a tile that is only ever ADDED to another one travels as four independent 16-byte pieces: a 16-register tuple for it would
+// fragment the register file where many tiles are in flight at once (the batched prologue loads)
+struct TileQ {
+    f32x4v q[4];
+};
+__device__ __forceinline__ void load_tile_q(const float *__restrict__ row32, int h, TileQ &t) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) t.q[q] = *reinterpret_cast<const f32x4v *>(row32 + 8 * q + 4 * h);
+}
+__device__ __forceinline__ void add_tile_q(const TileQ &t, f32x16 &d) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        d[4 * q] += t.q[q][0]; d[4 * q + 1] += t.q[q][1]; d[4 * q + 2] += t.q[q][2]; d[4 * q + 3] += t.q[q][3];
     }
 }
 __device__ __forceinline__ void store_tile(float *__restrict__ row32, int h, const f32x16 &d) {
@@ -360,12 +375,28 @@ __device__ __forceinline__ void ln_affine_tile(f32x16 &v, float rstd, const floa
 // points | 0 x4.  All four waves need all of it as B operand, so they SHARE the work: wave w computes point 4h + w of its
 // lanes, splits its eight values into ONE operand vector (hi, lo: two lane-linear 16-byte LDS writes) and drops its
 // distance into k-step 4; a workgroup barrier follows at the call site.
-__device__ __forceinline__ void geometry_share(const float *__restrict__ pts_i, const float *__restrict__ fr,
-                                               const float *__restrict__ pts_j, int h, int wave, int lane, float *gbuf) {
+// The inputs come in two levels: geo_load_i needs only the residue index (the residue's own point 4h + q, local and global,
+// and its frame), geo_load_j the neighbour index (the neighbour's global point); geometry_put is arithmetic + LDS writes.
+struct GeoI {
+    float lx, ly, lz, gx, gy, gz;
+    float fr[12];
+};
+__device__ __forceinline__ void geo_load_i(const float *__restrict__ pts_i, const float *__restrict__ fr, int h, int q, GeoI &g) {
+    const float *pl = pts_i + 12 * h + 3 * q, *pg = pts_i + 24 + 12 * h + 3 * q;
+    g.lx = pl[0]; g.ly = pl[1]; g.lz = pl[2];
+    g.gx = pg[0]; g.gy = pg[1]; g.gz = pg[2];
+#pragma unroll
+    for (int k = 0; k < 12; k++) g.fr[k] = fr[k];
+}
+__device__ __forceinline__ void geo_load_j(const float *__restrict__ pts_j, int h, int q, float (&pj)[3]) {
+    const float *p = pts_j + 24 + 12 * h + 3 * q;
+    pj[0] = p[0]; pj[1] = p[1]; pj[2] = p[2];
+}
+__device__ __forceinline__ void geometry_put(const GeoI &g, const float (&pj)[3], int wave, int lane, float *gbuf) {
     const int q = wave;
-    const float *pl = pts_i + 12 * h + 3 * q, *pg = pts_i + 24 + 12 * h + 3 * q, *pj = pts_j + 24 + 12 * h + 3 * q;
-    const float lx = pl[0], ly = pl[1], lz = pl[2];
-    const float gx = pg[0], gy = pg[1], gz = pg[2];
+    const float *fr = g.fr;
+    const float lx = g.lx, ly = g.ly, lz = g.lz;
+    const float gx = g.gx, gy = g.gy, gz = g.gz;
     const float jx = pj[0], jy = pj[1], jz = pj[2];
     float v[10];
     v[0] = lx; v[1] = ly; v[2] = lz;
@@ -521,12 +552,16 @@ __device__ __forceinline__ void geometry_share(const float *__restrict__ pts_i, 
 #define GROUP_SETUP()                                                                          \
     int n[R];                                                                                  \
     bool live[R], inr[R];                                                                      \
+    float rm_[R];                                                                              \
     int first = -1;                                                                            \
     _Pragma("unroll") for (int r = 0; r < R; r++) {                                            \
         const int nr = res0 + r;                                                               \
         inr[r] = nr < A.N;                                                                     \
         n[r] = inr[r] ? nr : A.N - 1;                                                          \
-        live[r] = inr[r] && A.rmask[n[r]] != 0.f;                                              \
+        rm_[r] = A.rmask[n[r]];                                                                \
+    }                                                                                          \
+    _Pragma("unroll") for (int r = 0; r < R; r++) {                                            \
+        live[r] = inr[r] && rm_[r] != 0.f;                                                     \
         if (live[r] && first < 0) first = n[r];                                                \
     }
 
@@ -596,28 +631,39 @@ __device__ __forceinline__ void node_message_body(const EdgeArgs &A, const int r
     const unsigned long long ts0f = __builtin_readcyclecounter();
     int tsf[16] = {0};
 #endif
-    PROLOGUE_PIPE(NCH)
-
     HT bt[2][R];
     f32x16 acc[R];
     float *gbuf = smem + R * XBUF_FLOATS;
     const int jj = j < K ? j : K - 1;
-    const float bmid = A.b_mid[32 * wave + j];            // SWAP form: feature on the lane
+    // loads in two levels, each for every residue at once (as in edge_update_body): what needs only the row index, then the
+    // neighbour-dependent gathers together with the accumulator tiles
     int nbr[R];
 #pragma unroll
-    for (int r = 0; r < R; r++) {
-        nbr[r] = A.eidx[(size_t)n[r] * K + jj];
-        geometry_share(A.pts + (size_t)n[r] * 48, A.frames + (size_t)n[r] * 12, A.pts + (size_t)nbr[r] * 48, h, wave, lane,
-                       gbuf + r * GBUF_FLOATS);
-        const float *hrow = A.hE_in + ((size_t)n[r] * K + jj) * 128;
-        if constexpr (!ST0) load_tile(hrow + 32 * wave, h, acc[r]);      // this wave's tile of h_E (split and published below)
-    }
-    if constexpr (!ST0) { PUBLISH_OWN(false, acc, xbuf) }
+    for (int r = 0; r < R; r++) nbr[r] = A.eidx[(size_t)n[r] * K + jj];
+    GeoI gi0[R];
+    float pj[R][3];
+    f32x16 hin[R];
 #pragma unroll
     for (int r = 0; r < R; r++) {
+        geo_load_i(A.pts + (size_t)n[r] * 48, A.frames + (size_t)n[r] * 12, h, wave, gi0[r]);
+        if constexpr (!ST0) load_tile(A.hE_in + ((size_t)n[r] * K + jj) * 128 + 32 * wave, h, hin[r]);   // this wave's tile of h_E
+    }
+    const float bmid = A.b_mid[32 * wave + j];            // SWAP form: feature on the lane
+    PROLOGUE_PIPE(NCH)
+    TileQ pc[R], zt[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        geo_load_j(A.pts + (size_t)nbr[r] * 48, h, wave, pj[r]);
         load_tile(A.PA + (size_t)n[r] * 128 + 32 * wave, h, acc[r]);
-        add_tile(A.PC + (size_t)nbr[r] * 128 + 32 * wave, h, acc[r]);
-        if constexpr (ST0) add_tile(A.Z + ((size_t)n[r] * K + jj) * 128 + 32 * wave, h, acc[r]);
+        load_tile_q(A.PC + (size_t)nbr[r] * 128 + 32 * wave, h, pc[r]);
+        if constexpr (ST0) load_tile_q(A.Z + ((size_t)n[r] * K + jj) * 128 + 32 * wave, h, zt[r]);
+    }
+    if constexpr (!ST0) { PUBLISH_OWN(false, hin, xbuf) }
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        geometry_put(gi0[r], pj[r], wave, lane, gbuf + r * GBUF_FLOATS);
+        add_tile_q(pc[r], acc[r]);
+        if constexpr (ST0) add_tile_q(zt[r], acc[r]);
     }
     if constexpr (ST0) __syncthreads();   // geometry operands are in LDS (otherwise the first W_B stage's barrier says so)
     FIRST_LAYER(0, NCH)
@@ -737,39 +783,52 @@ __device__ __forceinline__ void edge_update_body(const EdgeArgs &A, const int re
     const unsigned long long ts0f = __builtin_readcyclecounter();
     int tsf[16] = {0};
 #endif
-    PROLOGUE_PIPE(NCH)
-
     HT bt[2][R];
     f32x16 acc[R], out[R];
     float *gbuf = x1buf;      // the geometry operands borrow the x1 buffer: dead until LayerNorm 2 and again after the FFN
     int nbr[R];
     float me[R];
-    // the small per-layer vectors go to LDS once (published by the first barrier)
-#pragma unroll
-    for (int it = 0; it < (PARAM_LDS / 4 + ET - 1) / ET; it++) {
-        const int i = min(tid + it * ET, PARAM_LDS / 4 - 1);
-        *reinterpret_cast<f32x4v *>(prm + 4 * i) = *reinterpret_cast<const f32x4v *>(A.params + 4 * i);
-    }
-    if (tid < 64) {           // the last LayerNorm's gain and bias as well (256 values behind the block above)
-        const float *src = tid < 32 ? A.g3 + 4 * tid : A.be3 + 4 * (tid - 32);
-        *reinterpret_cast<f32x4v *>(prm + PARAM_LDS + 4 * tid) = *reinterpret_cast<const f32x4v *>(src);
-    }
+    GeoI gi0[R];
+    float pj[R][3];
 #pragma unroll
     for (int r = 0; r < R; r++) {
         nbr[r] = A.eidx[(size_t)n[r] * K + jj];
         me[r] = A.mask_att[(size_t)n[r] * 32 + jj];            // (lanes j >= K mirror edge K - 1 throughout)
-        geometry_share(A.pts + (size_t)n[r] * 48, A.frames + (size_t)n[r] * 12, A.pts + (size_t)nbr[r] * 48, h, wave, lane,
-                       gbuf + r * GBUF_FLOATS);
-        // this wave's tile of h_E: the residual input of the first LayerNorm (kept in `out`) and, split, a quarter of
-        // the first layer's B operands (layer 0 needs no B operands: W_B h_E0 arrives in Z)
+    }
+    // the small per-layer vectors go to LDS once (published by the first barrier)
+    constexpr int PRM_IT = (PARAM_LDS / 4 + ET - 1) / ET;
+    f32x4v prv[PRM_IT], prg;
+#pragma unroll
+    for (int it = 0; it < PRM_IT; it++) prv[it] = *reinterpret_cast<const f32x4v *>(A.params + 4 * min(tid + it * ET, PARAM_LDS / 4 - 1));
+    {
+        const int t64 = min(tid, 63);
+        prg = *reinterpret_cast<const f32x4v *>((t64 < 32 ? A.g3 + 4 * t64 : A.be3 + 4 * (t64 - 32)));
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        geo_load_i(A.pts + (size_t)n[r] * 48, A.frames + (size_t)n[r] * 12, h, wave, gi0[r]);
         load_tile(A.hE_in + ((size_t)n[r] * K + jj) * 128 + 32 * wave, h, out[r]);
     }
-    if constexpr (!ST0) { PUBLISH_OWN(false, out, xbuf) }
+    PROLOGUE_PIPE(NCH)
+#pragma unroll
+    for (int r = 0; r < R; r++) geo_load_j(A.pts + (size_t)nbr[r] * 48, h, wave, pj[r]);
+    TileQ pc[R], zt[R];
 #pragma unroll
     for (int r = 0; r < R; r++) {
         load_tile(A.PA + (size_t)n[r] * 128 + 32 * wave, h, acc[r]);
-        add_tile(A.PC + (size_t)nbr[r] * 128 + 32 * wave, h, acc[r]);
-        if constexpr (ST0) add_tile(A.Z + ((size_t)n[r] * K + jj) * 128 + 32 * wave, h, acc[r]);
+        load_tile_q(A.PC + (size_t)nbr[r] * 128 + 32 * wave, h, pc[r]);
+        if constexpr (ST0) load_tile_q(A.Z + ((size_t)n[r] * K + jj) * 128 + 32 * wave, h, zt[r]);
+    }
+#pragma unroll
+    for (int it = 0; it < PRM_IT; it++) *reinterpret_cast<f32x4v *>(prm + 4 * min(tid + it * ET, PARAM_LDS / 4 - 1)) = prv[it];
+    if (tid < 64) *reinterpret_cast<f32x4v *>(prm + PARAM_LDS + 4 * tid) = prg;
+#pragma unroll
+    for (int r = 0; r < R; r++) geometry_put(gi0[r], pj[r], wave, lane, gbuf + r * GBUF_FLOATS);
+    if constexpr (!ST0) { PUBLISH_OWN(false, out, xbuf) }
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        add_tile_q(pc[r], acc[r]);
+        if constexpr (ST0) add_tile_q(zt[r], acc[r]);
     }
     if constexpr (ST0) __syncthreads();   // geometry operands and parameters are in LDS (otherwise the first W_B stage's barrier says so)
     TS(0)
@@ -845,22 +904,35 @@ __device__ __forceinline__ void edge_update_body(const EdgeArgs &A, const int re
         // ---- next layer's node message on the fresh edges ------------------------------------------------
         // (xbuf was last read by the W2 stages of FFN block 3, the geometry block = x1buf by its W1 stages: every wave
         //  has passed the LayerNorm barrier since)
-        PUBLISH_OWN(false, out, xbuf)
+        GeoI gi_[R];
+        float pj2[R][3];
 #pragma unroll
         for (int r = 0; r < R; r++) {
-            geometry_share(A.pts2 + (size_t)n[r] * 48, A.frames + (size_t)n[r] * 12, A.pts2 + (size_t)nbr[r] * 48, h, wave,
-                           lane, gbuf + r * GBUF_FLOATS);
+            asm volatile("" : "+v"(nbr[r]));      // the gather addresses are formed HERE, not hoisted to the prologue
+            geo_load_i(A.pts2 + (size_t)n[r] * 48, A.frames + (size_t)n[r] * 12, h, wave, gi_[r]);
+            geo_load_j(A.pts2 + (size_t)nbr[r] * 48, h, wave, pj2[r]);
             load_tile(A.PA2 + (size_t)n[r] * 128 + 32 * wave, h, acc[r]);
-            add_tile(A.PC2 + (size_t)nbr[r] * 128 + 32 * wave, h, acc[r]);
         }
+#pragma unroll
+        for (int pk = 0; pk < PP_WDEPTH; pk++) {}       // the ring starts again
+        __builtin_amdgcn_sched_barrier(0);
+        PUBLISH_OWN(false, out, xbuf)
+        __builtin_amdgcn_sched_barrier(0);
+        TileQ pc2[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) load_tile_q(A.PC2 + (size_t)nbr[r] * 128 + 32 * wave, h, pc2[r]);
+#pragma unroll
+        for (int r = 0; r < R; r++) geometry_put(gi_[r], pj2[r], wave, lane, gbuf + r * GBUF_FLOATS);
         const float bmid = A.b_mid2[32 * wave + j];           // SWAP form: feature on the lane
         TS(13)
-        // the next message's first layer always has its W_B stages (the edges are fresh): NM_FIRST = FIRST_LAYER with ST0 false
+        // the next message's first layer always has its W_B stages (the edges are fresh)
         RLAYER_OWN(NEU + 0, NCH, acc, xbuf, false, false)
         WSTAGE(NEU + 4, NCH, acc, (mfma_geo<R, 0>(AK, gbuf, lane, acc)))
         WSTAGE(NEU + 5, NCH, acc, (mfma_geo<R, 1>(AK, gbuf, lane, acc)))
         __syncthreads();                  // barrier A of the publication below
         WSTAGE(NEU + 6, NCH, acc, (mfma_geo<R, 2>(AK, gbuf, lane, acc)))
+#pragma unroll
+        for (int r = 0; r < R; r++) add_tile_q(pc2[r], acc[r]);
         TS(14)
         PUBLISH_OWN(true, acc, xbuf)
         f32x4v mmv[R][4];          // edge masks of the final reduction, requested a layer ahead (as in node_message_body)
