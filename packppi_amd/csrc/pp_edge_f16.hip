@@ -156,8 +156,13 @@ enum { P_BMID = 0, P_BOUT = 128, P_FOB = 256, P_G2 = 384, P_BE2 = 512, P_FIB = 6
 // The chunk offset is made opaque and every stage starts with a scheduling barrier, so each fetch is issued where it is
 // written (as read-only kernel arguments the compiler would otherwise hoist all of them to the top of the kernel).
 #ifndef PP_WDEPTH
-#define PP_WDEPTH 2
+#define PP_WDEPTH 2        // stages a weight fetch runs ahead of its use, two-residue workgroups (a stage = 384 cycles of MFMAs)
 #endif
+#ifndef PP_WDEPTH_R1
+#define PP_WDEPTH_R1 2     // ... one-residue workgroups (4 and 6 measured: no change, profiles/r04_ab_experiments.txt)
+#endif
+// ring depth of the instance in scope: every kernel body defines R (residues per workgroup)
+#define WDEPTH_ (R == 1 ? PP_WDEPTH_R1 : PP_WDEPTH)
 // -DPP_X_TS -DPP_X_TS_FINE=k0: wave 0's clock after each of the 16 stages k0 .. k0 + 15 of the edge update (measurement aid)
 #if defined(PP_X_TS) && defined(PP_X_TS_FINE)
 #define TSF(k) if constexpr ((k) >= PP_X_TS_FINE && (k) < PP_X_TS_FINE + 16) tsf[(k) - PP_X_TS_FINE] = (int)(__builtin_readcyclecounter() - ts0f);
@@ -170,7 +175,7 @@ enum { P_BMID = 0, P_BOUT = 128, P_FOB = 256, P_G2 = 384, P_BE2 = 512, P_FIB = 6
 #ifndef PP_WGS
 #define PP_WGS 3           // register budget = 512 / PP_WGS per lane: three workgroups per CU (the kernels need ~140 VGPRs, 38.4 KB of LDS)
 #endif
-#define NRING (PP_WDEPTH + 1)
+#define NRING (WDEPTH_ + 1)
 #ifdef PP_X_NOWLOAD      /* timing experiment (results are wrong): no weight fetches after the prologue */
 #define PP_X_NOWLOAD_ true
 #else
@@ -441,8 +446,8 @@ __device__ __forceinline__ void geometry_put(const GeoI &g, const float (&pj)[3]
 #define WSTAGE(k, NCH, ACC, BODY)                                                                              \
     {                                                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
-        if constexpr ((k) + PP_WDEPTH < (NCH) && !PP_X_NOWLOAD_)                                               \
-            gload_A(wq, (k) + PP_WDEPTH, AR[((k) + PP_WDEPTH) % NRING]);                                       \
+        if constexpr ((k) + WDEPTH_ < (NCH) && !PP_X_NOWLOAD_)                                                 \
+            gload_A(wq, (k) + WDEPTH_, AR[((k) + WDEPTH_) % NRING]);                                           \
         const AOp &AK = AR[(k) % NRING];                                                                       \
         BODY;                                                                                                  \
         _Pragma("unroll") for (int r_ = 0; r_ < R; r_++) asm volatile("" ::"v"(ACC[r_][0]));                   \
@@ -545,7 +550,7 @@ __device__ __forceinline__ void geometry_put(const GeoI &g, const float (&pj)[3]
 #define PROLOGUE_PIPE(NCH)                                                                                     \
     const h8 *wq = reinterpret_cast<const h8 *>(A.wstream) + wave * 256 + lane;    /* this wave's quarter, this lane */ \
     AOp AR[NRING];                                                                                             \
-    _Pragma("unroll") for (int pk = 0; pk < PP_WDEPTH && pk < (NCH); pk++) gload_A(wq, pk, AR[pk]);
+    _Pragma("unroll") for (int pk = 0; pk < WDEPTH_ && pk < (NCH); pk++) gload_A(wq, pk, AR[pk]);
 
 // The R residues of a workgroup are rows res0 .. res0 + R - 1.  `live` = in range and not masked; a dead slot computes on
 // a live residue's inputs (no garbage enters the pipes) and stores nothing.  All of it is wave-uniform.
@@ -913,8 +918,6 @@ __device__ __forceinline__ void edge_update_body(const EdgeArgs &A, const int re
             geo_load_j(A.pts2 + (size_t)nbr[r] * 48, h, wave, pj2[r]);
             load_tile(A.PA2 + (size_t)n[r] * 128 + 32 * wave, h, acc[r]);
         }
-#pragma unroll
-        for (int pk = 0; pk < PP_WDEPTH; pk++) {}       // the ring starts again
         __builtin_amdgcn_sched_barrier(0);
         PUBLISH_OWN(false, out, xbuf)
         __builtin_amdgcn_sched_barrier(0);
@@ -1007,6 +1010,9 @@ k_edge_update_mix(EdgeArgs A) {
         const int ns = gridDim.x - A.n_pairs;
         if (b < 2 * ns) { if (b & 1) single = b >> 1; else pair = b >> 1; }
         else pair = b - ns;
+    } else if (A.mix_mode == 3) {        // experiment: the one-residue workgroups first in dispatch order
+        const int ns = gridDim.x - A.n_pairs;
+        if (b < ns) single = b; else pair = b - ns;
     } else {
         if (b < A.n_pairs) pair = b; else single = b - A.n_pairs;
     }
@@ -1331,7 +1337,7 @@ static int g_mix = -1;
 static bool use_mix(int N) {
     if (g_mix < 0) {
         const char *e = PP_GETENV("PP_EDGE_MIX");
-        g_mix = e ? atoi(e) : 1;
+        g_mix = e ? atoi(e) : 3;       // 3: the one-residue workgroups first in dispatch order (they are the longer ones now: +0.5-1 %)
     }
     if (g_forced_R >= 1 || !g_mix) return false;
     return N > 2 * g_num_cu && N <= 3 * g_num_cu;
@@ -1362,7 +1368,8 @@ pp_status pp_launch_edge_static(pp_ctx *c, hipStream_t s) {
 pp_status pp_launch_node_message(pp_ctx *c, int layer, hipStream_t s) {
     EDGE_ATTR_CHECK()
     EdgeArgs A = edge_args(c, layer, false);
-    static const int nm_R = PP_GETENV("PP_NM_R") ? atoi(PP_GETENV("PP_NM_R")) : 0;       // measurement aid: residues per workgroup of this kernel only
+    static const char *nm_env = PP_GETENV("PP_NM_R");
+    static const int nm_R = nm_env ? atoi(nm_env) : 0;       // measurement aid: residues per workgroup of this kernel only
     const int R = (nm_R >= 1 && nm_R <= PP_RMAX) ? nm_R : pick_R(c->N);
     PP_LAUNCH(c, nm_kernel_r(R, layer == 0), dim3((c->N + R - 1) / R), dim3(ET), nm_smem(R), s, A);
     PP_HIP_CHECK(hipGetLastError());

@@ -1366,7 +1366,8 @@ pp_status pp_launch_node_update(pp_ctx *c, int layer, int last_mode, float *chi,
 #endif
     const bool multi = (int)grid.x > g_nu_cus;
     // middle layers of a launch that leaves most CUs idle: 4 (or 2) workgroups per tile share out the projections
-    static const int split_max = PP_GETENV("PP_NU_SPLIT") ? atoi(PP_GETENV("PP_NU_SPLIT")) : 4;     // measurement aid: 1 = never
+    static const char *split_env = PP_GETENV("PP_NU_SPLIT");
+    static const int split_max = split_env ? atoi(split_env) : 4;     // measurement aid: 1 = never
     const int tiles = (int)grid.x;
     const int cl = last_mode != PP_NU_MID ? 1 : (split_max >= 4 && 4 * tiles <= g_nu_cus) ? 4 : (split_max >= 2 && 2 * tiles <= g_nu_cus) ? 2 : 1;
     if (cl > 1) {
