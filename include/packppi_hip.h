@@ -111,6 +111,13 @@ pp_status pp_plan_set_knn_ties(pp_plan *plan, int mode);
  * w = T / (alpha + (1 - alpha) T) in SO2VESchedule.step (schedule.py:205-208).  Applies to later pp_score / pp_sample calls. */
 pp_status pp_plan_set_annealed_temp(pp_plan *plan, float annealed_temp);
 
+/* No reference counterpart.  The split-f16 build rebalances every ReLU chain of the edge-level MLPs by powers of two when the
+ * plan is created (W1, b1 times s; W2 divided by s: the same function, hidden activations of size O(1) whatever the checkpoint's
+ * split of scale between consecutive layers; csrc/pp_api.hip rebalance_relu_chains): this returns how many of the 15 chains
+ * were rescaled (0 for weights whose layer row norms lie within [1/8, 8], e.g. the seeded fixtures; always 0 in
+ * libpackppi_hip.f32.so, which needs no such care), -1 for a null plan. */
+int pp_plan_rebalanced_chains(const pp_plan *plan);
+
 /* HOST helper, no device call: idx_out[0..k-1] = torch.topk(values[0..n-1], k, largest=False) indices as ATen's CPU kernel
  * returns them -- the same code the neighbour search runs on the device for rows with ties.  Returns PP_OK / PP_ERR_INVALID. */
 pp_status pp_topk_aten_host(const float *values, int n, int k, int32_t *idx_out);

@@ -10,6 +10,7 @@
 
 #include "pp_internal.h"
 #include "pp_topk_aten.h"
+#include <algorithm>
 #include <cstring>
 #include <cmath>
 #include <chrono>
@@ -325,6 +326,63 @@ static size_t put_edge_params(std::vector<float> &arena, const float *w, const L
     return at;
 }
 
+#ifdef PP_EDGE_F16
+// ---- power-of-two rebalancing of the ReLU chains (split-f16 build) ---------------------------------------------------------
+// The edge kernels carry an activation as hi + lo with an UNSCALED low part: below |x| = 2^-4 the low part is a subnormal f16
+// number and carries an absolute error of 2^-25 instead of a relative 2^-22.  LayerNorm outputs and geometry are O(1); a HIDDEN
+// activation is as large as the checkpoint happens to make it -- a network that computes relu(W2 relu(W1 x + b1) + b2) with
+// W1 a thousand times smaller and W2 a thousand times larger is the same function, and its hidden operands sit at 1e-3, where
+// 15 bits are left (measured: T1124, 100 steps, 1.9e-4 rad from the reference against 8e-6 for the balanced network;
+// tests/test_hip_parity.py::test_weight_range_envelope_T1124, "tiny operands").  ReLU commutes with a positive scale, so the
+// chain is rebalanced here, once, exactly: W1, b1 times s, W2 divided by s, s a power of two chosen so that the rows of the
+// producing layer have a median norm of about 1 (nothing is touched while that norm is within [1/8, 8]: the seeded fixtures
+// keep their bits).  In fp32 the rebalanced network is the same function to the last bit (no overflow / underflow at these
+// magnitudes); every consumer -- the edge kernels, the node update's projections and its W_out of the node message, the
+// first node embedding, the static layer-0 products -- is packed from the rebalanced vector.  Cost at run time: none.
+static float row_norm_median(const float *W, int rows, int cols, int ld, const float *bias, float col_scale) {
+    std::vector<float> nrm((size_t)rows);
+    for (int i = 0; i < rows; i++) {
+        double a = bias ? (double)bias[i] * bias[i] : 0.0;
+        for (int c = 0; c < cols; c++) { const double w = (double)W[(size_t)i * ld + c] * col_scale; a += w * w; }
+        nrm[i] = (float)std::sqrt(a);
+    }
+    std::nth_element(nrm.begin(), nrm.begin() + rows / 2, nrm.end());
+    return nrm[rows / 2];
+}
+static float pow2_rebalance(float norm) {
+    if (!(norm > 0.f) || !std::isfinite(norm) || (norm >= 0.125f && norm <= 8.f)) return 1.f;
+    int e = (int)std::lround(-std::log2((double)norm));
+    e = e < -24 ? -24 : (e > 24 ? 24 : e);
+    return std::ldexp(1.f, e);
+}
+static void scale_block(float *w, size_t n, float s) {
+    if (s != 1.f) for (size_t i = 0; i < n; i++) w[i] *= s;
+}
+// in place on a host copy of the weight vector; returns how many chains were rescaled
+static int rebalance_relu_chains(float *w, const WeightOff &off) {
+    int changed = 0;
+    for (int l = 0; l < 3; l++) {
+        const LayerOff &L = off.layer[l];
+        const size_t in_w[2] = {L.nm_in_w, L.em_in_w}, in_b[2] = {L.nm_in_b, L.em_in_b}, mid_w[2] = {L.nm_mid_w, L.em_mid_w},
+                     mid_b[2] = {L.nm_mid_b, L.em_mid_b}, out_w[2] = {L.nm_out_w, L.em_out_w};
+        for (int f = 0; f < 2; f++) {      // node message, edge message: hidden 1 after W_in, hidden 2 after W_inter.0
+            const float s1 = pow2_rebalance(row_norm_median(w + in_w[f], 128, 456, 456, w + in_b[f], 1.f));
+            // W_inter.0 sees hidden 1, which is O(1) once multiplied by s1: its pre-activation has the size of the rows of W / s1
+            const float s2 = pow2_rebalance(row_norm_median(w + mid_w[f], 128, 128, 128, w + mid_b[f], 1.f / s1));
+            scale_block(w + in_w[f], (size_t)128 * 456, s1); scale_block(w + in_b[f], 128, s1);
+            scale_block(w + mid_w[f], (size_t)128 * 128, s2 / s1); scale_block(w + mid_b[f], 128, s2);
+            scale_block(w + out_w[f], (size_t)128 * 128, 1.f / s2);
+            changed += (s1 != 1.f) + (s2 != 1.f);
+        }
+        const float sf = pow2_rebalance(row_norm_median(w + L.ed_in_w, 512, 128, 128, w + L.ed_in_b, 1.f));      // edge FFN hidden
+        scale_block(w + L.ed_in_w, (size_t)512 * 128, sf); scale_block(w + L.ed_in_b, 512, sf);
+        scale_block(w + L.ed_out_w, (size_t)128 * 512, 1.f / sf);
+        changed += sf != 1.f;
+    }
+    return changed;
+}
+#endif
+
 template <typename T>
 static pp_status upload(T **dst, const T *src, size_t n) {
     PP_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(dst), n * sizeof(T)));
@@ -405,7 +463,22 @@ extern "C" pp_status pp_plan_create(const float *weights, size_t n_weights, cons
     p->has_network = has_net;
     p->knn_ties = PP_KNN_TIES_ATEN_CPU;
     p->annealed_temp = 3.0f;      // configs/model/sample_cfg/Sampling.yaml:4
+    p->rebalanced_chains = 0;
     pp_status st;
+#ifdef PP_EDGE_F16
+    std::vector<float> rebalanced;
+    if (has_net) {
+        rebalanced.assign(weights, weights + off.total);
+        p->rebalanced_chains = rebalance_relu_chains(rebalanced.data(), off);
+        for (size_t i = 0; i < off.total; i++)
+            if (!(std::fabs(rebalanced[i]) < 65504.f)) {
+                delete p;
+                FAIL(PP_ERR_INVALID, "pp_plan_create: weight " + std::to_string(i) + " leaves the f16 range when its ReLU chain is "
+                                     "rebalanced (run this checkpoint on libpackppi_hip.f32.so)");
+            }
+        weights = rebalanced.data();       // everything below -- device copy, packed streams, transposed copies -- is made from it
+    }
+#endif
     if (has_net) {
     if ((st = upload(&p->w, weights, off.total)) != PP_OK) return st;
 
@@ -502,6 +575,8 @@ extern "C" pp_status pp_plan_set_knn_ties(pp_plan *p, int mode) {
     p->knn_ties = mode;
     return PP_OK;
 }
+
+extern "C" int pp_plan_rebalanced_chains(const pp_plan *p) { return p ? p->rebalanced_chains : -1; }
 
 // sample_cfg.annealed_temp (TorsionalDiffusion.py:70-75 -> SO2VESchedule(annealed_temp=...), schedule.py:205-208)
 extern "C" pp_status pp_plan_set_annealed_temp(pp_plan *p, float T) {

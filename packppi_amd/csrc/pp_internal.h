@@ -105,6 +105,7 @@ struct pp_plan {
     bool has_network;         // false: geometry-only plan (atom14 / clash / proximal)
     int knn_ties;             // PP_KNN_TIES_*: what the neighbour search does on exactly equal distances
     float annealed_temp;      // sample_cfg.annealed_temp (the T of schedule.py:205-208), default 3
+    int rebalanced_chains;    // split-f16 build: ReLU chains whose layers were rescaled by a power of two (pp_api.hip rebalance_relu_chains)
     float *w;                 // device copy of all weights, original layouts
     WeightOff off;
     float *wT;                // device arena of transposed copies

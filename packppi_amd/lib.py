@@ -15,7 +15,7 @@ from .weights import check_state_dict
 _LIB_PATH = os.environ.get("PACKPPI_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libpackppi_hip.so")     # PACKPPI_LIB: A/B runs of build variants
 _lib = None
 
-SYMBOLS = ("pp_version", "pp_last_error", "pp_build_id", "pp_plan_set_knn_ties", "pp_plan_set_annealed_temp", "pp_topk_aten_host", "pp_plan_create", "pp_plan_destroy", "pp_plan_set_clash_params",
+SYMBOLS = ("pp_version", "pp_last_error", "pp_build_id", "pp_plan_set_knn_ties", "pp_plan_set_annealed_temp", "pp_plan_rebalanced_chains", "pp_topk_aten_host", "pp_plan_create", "pp_plan_destroy", "pp_plan_set_clash_params",
            "pp_complex_prepare", "pp_complex_prepare_packed", "pp_ctx_destroy", "pp_ctx_get_graph", "pp_ctx_set_graph", "pp_score", "pp_sample", "pp_atom14",
            "pp_clash", "pp_proximal", "pp_time_kernel", "pp_profile_kernel", "pp_profile_read", "pp_edge_variant", "pp_has_range_check", "pp_range_check", "pp_range_check_parts", "pp_ctx_saturated")
 
@@ -67,6 +67,8 @@ def load():
                                "to load it for a measurement")
     lib.pp_plan_set_knn_ties.argtypes = [vp, i]
     lib.pp_plan_set_annealed_temp.argtypes = [vp, f]
+    lib.pp_plan_rebalanced_chains.argtypes = [vp]
+    lib.pp_plan_rebalanced_chains.restype = C.c_int
     lib.pp_topk_aten_host.argtypes = [vp, i, i, vp]
     lib.pp_version.restype = C.c_int
     lib.pp_last_error.restype = C.c_char_p
@@ -151,6 +153,10 @@ class Plan:
             raise ValueError(f"knn ties mode must be one of {sorted(KNN_TIES)}")
         _check(load().pp_plan_set_knn_ties(self.handle, KNN_TIES[mode]), "pp_plan_set_knn_ties")
         self.knn_ties = mode
+
+    def rebalanced_chains(self) -> int:
+        """How many ReLU chains of the edge-level MLPs the split-f16 build rescaled by a power of two at plan creation."""
+        return int(load().pp_plan_rebalanced_chains(self.handle))
 
     def set_annealed_temp(self, T):
         """sample_cfg.annealed_temp (Sampling.yaml:4): the T of the annealed score weight in SO2VESchedule.step."""
