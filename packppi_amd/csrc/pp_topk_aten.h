@@ -11,6 +11,15 @@
 // plain array of pairs so that ONE lane of the kNN kernel can run them on a row held in LDS.  The same code compiles for the
 // host: `pp_topk_aten_host` (pp_api.hip) is checked against torch.topk on tie-heavy rows by the CPU tests, and against
 // std::nth_element / std::sort / std::partial_sort themselves by tests/test_topk_aten.py.
+//
+// PROVENANCE / LICENCE NOTE.  The control flow below follows, step for step, the algorithms of the GNU C++ Library (libstdc++),
+// files bits/stl_algo.h and bits/stl_heap.h, Copyright (C) 2001-2023 Free Software Foundation, Inc. (and, for the portions
+// derived from the SGI STL, Copyright (c) 1994 Hewlett-Packard Company and Copyright (c) 1996 Silicon Graphics Computer Systems,
+// Inc.), distributed under the GNU General Public License version 3 or later WITH the GCC Runtime Library Exception 3.1, which
+// permits use of the library's algorithms in programs of any licence.  No libstdc++ source text is reproduced here: the
+// functions are rewritten for a fixed element type and a fixed comparator, for host and device, because bit-exact agreement
+// with torch.topk on ties REQUIRES the same sequence of comparisons and moves.  ATen's TopKImpl.h (the call pattern quoted
+// above) is part of PyTorch, BSD-3-Clause.
 #pragma once
 #include <stdint.h>
 
