@@ -1,21 +1,26 @@
 #!/bin/bash
-# GPU box: the whole committed measurement set of a build (rocprofv3 stats + PMC passes, L2 counters, per-workload stats, the
-# bench lines); summaries land in profiles/ on the box and are copied to gpurun_out/ for the trip home.
+# GPU box: the whole committed measurement set of a build (rocprofv3 stats + PMC passes, L2 counters, SQ counters, per-workload
+# stats, the bench lines); summaries land in profiles/ on the box and are copied to gpurun_out/ for the trip home.
+#   GRAFT_ROUND=r04 PROFILE_TAG=r04_v1 bash tools/profile/run_round_set.sh
 set -e
-export PROFILE_TAG=${PROFILE_TAG:-r04_v1}
-bash tools/profile/run_profiles.sh v3 > gpurun_out/v2_profiles.log 2>&1
+export GRAFT_ROUND=${GRAFT_ROUND:-r04}
+export PROFILE_TAG=${PROFILE_TAG:-${GRAFT_ROUND}_v1}
+V=${PROFILE_TAG#${GRAFT_ROUND}_}
+bash tools/profile/run_profiles.sh $V > gpurun_out/set_profiles.log 2>&1
 echo profiles done
-bash tools/profile/run_tcc.sh t1124 > gpurun_out/v2_tcc.log 2>&1
+bash tools/profile/run_tcc.sh t1124 > gpurun_out/set_tcc.log 2>&1
 echo tcc done
-bash tools/profile/run_stats_workload.sh v3 s1500 > gpurun_out/v2_stats_s1500.log 2>&1
-bash tools/profile/run_stats_workload.sh v3 c5 > gpurun_out/v2_stats_c5.log 2>&1
+bash tools/profile/run_sq.sh > gpurun_out/${PROFILE_TAG}_sq_counters.txt 2> gpurun_out/set_sq.err
+bash tools/profile/run_sq_workload.sh c5 > gpurun_out/${PROFILE_TAG}_sq_c5.txt 2>> gpurun_out/set_sq.err
+bash tools/profile/run_sq_workload.sh s1500 > gpurun_out/${PROFILE_TAG}_sq_s1500.txt 2>> gpurun_out/set_sq.err
+echo sq done
+bash tools/profile/run_stats_workload.sh $V s1500 > gpurun_out/set_stats_s1500.log 2>&1
+bash tools/profile/run_stats_workload.sh $V c5 > gpurun_out/set_stats_c5.log 2>&1
 echo stats done
-python bench.py > gpurun_out/${PROFILE_TAG}_bench_t1124.json 2> gpurun_out/v2_bench.err
-python bench.py --proximal > gpurun_out/${PROFILE_TAG}_bench_t1124_prox.json 2>> gpurun_out/v2_bench.err
-python bench.py --workload s1500 > gpurun_out/${PROFILE_TAG}_bench_s1500.json 2>> gpurun_out/v2_bench.err
-python bench.py --workload s1500 --proximal > gpurun_out/${PROFILE_TAG}_bench_s1500_prox.json 2>> gpurun_out/v2_bench.err
-python bench.py --workload c5 > gpurun_out/${PROFILE_TAG}_bench_c5.json 2>> gpurun_out/v2_bench.err
+python bench.py --steps 20 --warmup 5 > gpurun_out/${PROFILE_TAG}_bench_t1124.json 2> gpurun_out/set_bench.err
+python bench.py --proximal > gpurun_out/${PROFILE_TAG}_bench_t1124_prox.json 2>> gpurun_out/set_bench.err
+python bench.py --workload s1500 > gpurun_out/${PROFILE_TAG}_bench_s1500.json 2>> gpurun_out/set_bench.err
+python bench.py --workload s1500 --proximal > gpurun_out/${PROFILE_TAG}_bench_s1500_prox.json 2>> gpurun_out/set_bench.err
+python bench.py --workload c5 > gpurun_out/${PROFILE_TAG}_bench_c5.json 2>> gpurun_out/set_bench.err
 echo bench done
-python -m pytest tests/test_hip_parity.py -x -q -m gpu -k "split_launch" > gpurun_out/v2_split_test.log 2>&1
-tail -2 gpurun_out/v2_split_test.log
 cp profiles/${PROFILE_TAG}_* gpurun_out/ 2>/dev/null || true
