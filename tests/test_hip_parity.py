@@ -525,6 +525,50 @@ def test_context_workspace_reuse(weights):
         assert torch.equal(o, ref[L]), (L, float((o - ref[L]).abs().max()))
 
 
+def test_in_place_edit_of_the_batch_rebuilds_the_context(weights):
+    """The module caches the context of the last batch (graph, frames, edge embedding).  The reference recomputes all of it
+    on every call (encoder.py:198-246), so an IN-PLACE edit of the batch between two calls must be seen: the cache is keyed on
+    the tensors themselves and their version counters (lib.BatchKey; round 3 keyed on data_ptr and silently reused the old
+    graph).  Also: a tensor the context has to copy (dtype) is watched through the caller's tensor."""
+    from packppi_amd import synth
+    from packppi_amd.featurize import protein_to_batch
+    from packppi_amd.module import TDiffusionModule
+    m = TDiffusionModule(weights, device=DEV)
+    m.schedule = torch.linspace(1, 0, 7)
+    b = protein_to_batch(synth.make_complex(70, 12)).to(DEV)
+    g = torch.Generator().manual_seed(2)
+    init = ((torch.rand(1, 70, 4, generator=g) * 2 - 1) * 3.0).to(DEV) * b.SC_D_mask
+    first = m.sample_from(b, init)
+    ctx0 = m._ctx
+    assert m._context(b) is ctx0                                        # untouched batch: the cached context
+    # move the backbone of ten residues (a different neighbour graph), in place: same storage, same data_ptr
+    ptr = b.X.data_ptr()
+    b.X[0, 20:30] += torch.tensor([7.0, -3.0, 5.0], device=DEV)
+    assert b.X.data_ptr() == ptr
+    edited = m.sample_from(b, init)
+    assert m._ctx is not ctx0
+    fresh = TDiffusionModule(weights, device=DEV)
+    fresh.schedule = m.schedule
+    assert torch.equal(edited, fresh.sample_from(b, init))              # what a module that never saw the old batch gives
+    assert not torch.equal(edited, first)
+    # masking a residue in place is seen as well
+    ctx1 = m._ctx
+    b.residue_mask[0, 5] = 0.0
+    masked = m.sample_from(b, init)
+    assert m._ctx is not ctx1
+    f2 = TDiffusionModule(weights, device=DEV)
+    f2.schedule = m.schedule
+    assert torch.equal(masked, f2.sample_from(b, init))
+    # a residue_index stored as int32 has to be converted by the context: the key still watches the caller's tensor
+    b32 = protein_to_batch(synth.make_complex(70, 12)).to(DEV)
+    b32["residue_index"] = b32.residue_index.to(torch.int32)
+    a1 = m.sample_from(b32, init)
+    ctx2 = m._ctx
+    b32.residue_index[0, 35:] += 150                                    # a chain break appears (relative positions change)
+    a2 = m.sample_from(b32, init)
+    assert m._ctx is not ctx2 and not torch.equal(a1, a2)
+
+
 # ---- ragged batches without padding rows (batch.pack / pp_complex_prepare_packed) ---------------------------------------
 def test_packed_batch_equals_per_complex(weights):
     """Complexes of different lengths packed back to back (no padding rows launched) give every complex the angles it
