@@ -355,6 +355,16 @@ static float pow2_rebalance(float norm) {
     e = e < -24 ? -24 : (e > 24 ? 24 : e);
     return std::ldexp(1.f, e);
 }
+static float max_abs(const float *w, size_t n) {
+    float m = 0.f;
+    for (size_t i = 0; i < n; i++) m = std::max(m, std::fabs(w[i]));
+    return m;
+}
+// the smallest power of two >= x (x <= 0: the smallest scale there is, i.e. no constraint)
+static float pow2_at_least(float x) {
+    if (!(x > 0.f) || !std::isfinite(x)) return std::ldexp(1.f, -60);
+    return std::ldexp(1.f, (int)std::ceil(std::log2((double)x)));
+}
 static void scale_block(float *w, size_t n, float s) {
     if (s != 1.f) for (size_t i = 0; i < n; i++) w[i] *= s;
 }
@@ -366,15 +376,20 @@ static int rebalance_relu_chains(float *w, const WeightOff &off) {
         const size_t in_w[2] = {L.nm_in_w, L.em_in_w}, in_b[2] = {L.nm_in_b, L.em_in_b}, mid_w[2] = {L.nm_mid_w, L.em_mid_w},
                      mid_b[2] = {L.nm_mid_b, L.em_mid_b}, out_w[2] = {L.nm_out_w, L.em_out_w};
         for (int f = 0; f < 2; f++) {      // node message, edge message: hidden 1 after W_in, hidden 2 after W_inter.0
-            const float s1 = pow2_rebalance(row_norm_median(w + in_w[f], 128, 456, 456, w + in_b[f], 1.f));
+            float s1 = pow2_rebalance(row_norm_median(w + in_w[f], 128, 456, 456, w + in_b[f], 1.f));
             // W_inter.0 sees hidden 1, which is O(1) once multiplied by s1: its pre-activation has the size of the rows of W / s1
-            const float s2 = pow2_rebalance(row_norm_median(w + mid_w[f], 128, 128, 128, w + mid_b[f], 1.f / s1));
+            float s2 = pow2_rebalance(row_norm_median(w + mid_w[f], 128, 128, 128, w + mid_b[f], 1.f / s1));
+            // the consuming layers are divided by the scale: they must stay inside the f16 range themselves (a hidden layer that
+            // really is huge keeps part of its size -- and saturates, flagged, if that is beyond 65504)
+            s2 = std::max(s2, pow2_at_least(max_abs(w + out_w[f], (size_t)128 * 128) / 32768.f));
+            s1 = std::max(s1, pow2_at_least(max_abs(w + mid_w[f], (size_t)128 * 128) * s2 / 32768.f));
             scale_block(w + in_w[f], (size_t)128 * 456, s1); scale_block(w + in_b[f], 128, s1);
             scale_block(w + mid_w[f], (size_t)128 * 128, s2 / s1); scale_block(w + mid_b[f], 128, s2);
             scale_block(w + out_w[f], (size_t)128 * 128, 1.f / s2);
             changed += (s1 != 1.f) + (s2 != 1.f);
         }
-        const float sf = pow2_rebalance(row_norm_median(w + L.ed_in_w, 512, 128, 128, w + L.ed_in_b, 1.f));      // edge FFN hidden
+        float sf = pow2_rebalance(row_norm_median(w + L.ed_in_w, 512, 128, 128, w + L.ed_in_b, 1.f));      // edge FFN hidden
+        sf = std::max(sf, pow2_at_least(max_abs(w + L.ed_out_w, (size_t)128 * 512) / 32768.f));
         scale_block(w + L.ed_in_w, (size_t)512 * 128, sf); scale_block(w + L.ed_in_b, 512, sf);
         scale_block(w + L.ed_out_w, (size_t)128 * 512, 1.f / sf);
         changed += sf != 1.f;
