@@ -441,11 +441,12 @@ def main():
         roof = {"bound": "mfma", "kernel": "k_edge_update", "achieved": achieved,
                 "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                 "peak_is": "dense F16 MFMA (the pipe the kernel runs on)" if split_f16 else "FP32 matrix",
-                "limiter": "not the matrix pipe (SQ counters: ~33 % busy here, 45-49 % on multi-round batches): the L2 -> CU operand "
-                           "stream (every workgroup pulls the layer's 0.93 MB packed weight set; `l2_stream`: ~3/4 of what a pure "
-                           "L2-row-pulling kernel reaches on this chip) together with the LDS reads of the B operands and the VALU "
-                           "work of the f16 splits, about equally loaded (DESIGN.md 4.5); `bound` names the roofline that would bind "
-                           "at the limit",
+                "limiter": "not the matrix pipe (SQ counters: 38.8 % busy here, 45-49 % on multi-round batches): the per-CU vector-memory "
+                           "path (64 B/clk), spent on the weight stream -- every workgroup pulls the layer's 0.93 MB packed weight set, 1.86 MB "
+                           "per CU and launch at three residues per CU; the workgroup kind of the mixed launch that is dispatched second "
+                           "queues its prologue loads behind the other's stream (17 k-cycle prologues, profiles/r04_edge_workgroup_tail.txt). "
+                           "`l2_stream` is the same quantity seen from the L2; LDS operand reads and the VALU work of the f16 splits are "
+                           "loaded alongside (DESIGN.md 4.5, 4.6); `bound` names the roofline that would bind at the limit",
                 "achieved_is": "the reference's fp32 dense-layer arithmetic (2 FLOP per MAC) per second; the kernel "
                                "issues 3 f16 MFMAs per product, see executed_mfma_tflops",
                 "achieved_over_fp32_matrix_peak": achieved / FP32_MFMA_PEAK_TFLOPS,
