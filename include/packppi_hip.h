@@ -117,6 +117,10 @@ pp_status pp_plan_set_annealed_temp(pp_plan *plan, float annealed_temp);
  * were rescaled (0 for weights whose layer row norms lie within [1/8, 8], e.g. the seeded fixtures; always 0 in
  * libpackppi_hip.f32.so, which needs no such care), -1 for a null plan. */
 int pp_plan_rebalanced_chains(const pp_plan *plan);
+/* HOST helper, no device call: `out` [n_weights] = the weight vector as pp_plan_create packs it (the rebalanced one in the
+ * split-f16 build, a copy in libpackppi_hip.f32.so), `chains` (may be NULL) = how many chains were rescaled.  For tests: the
+ * rebalanced network must be the original function (tests/test_host.py runs both through the CPU oracle). */
+pp_status pp_rebalance_weights_host(const float *weights, size_t n_weights, float *out, int *chains);
 
 /* HOST helper, no device call: idx_out[0..k-1] = torch.topk(values[0..n-1], k, largest=False) indices as ATen's CPU kernel
  * returns them -- the same code the neighbour search runs on the device for rows with ties.  Returns PP_OK / PP_ERR_INVALID. */

@@ -593,6 +593,20 @@ extern "C" pp_status pp_plan_set_knn_ties(pp_plan *p, int mode) {
 
 extern "C" int pp_plan_rebalanced_chains(const pp_plan *p) { return p ? p->rebalanced_chains : -1; }
 
+// HOST helper, no device call: the weight vector as pp_plan_create packs it (split-f16 build: ReLU chains rebalanced by powers of
+// two; exact-fp32 build: a copy).  Lets a CPU test hold the rebalanced network to the original one through the oracle.
+extern "C" pp_status pp_rebalance_weights_host(const float *weights, size_t n_weights, float *out, int *chains) {
+    const WeightOff off = pp_weight_offsets();
+    if (!weights || !out || n_weights != off.total) FAIL(PP_ERR_INVALID, "pp_rebalance_weights_host: bad argument");
+    memcpy(out, weights, n_weights * sizeof(float));
+    int c = 0;
+#ifdef PP_EDGE_F16
+    c = rebalance_relu_chains(out, off);
+#endif
+    if (chains) *chains = c;
+    return PP_OK;
+}
+
 // sample_cfg.annealed_temp (TorsionalDiffusion.py:70-75 -> SO2VESchedule(annealed_temp=...), schedule.py:205-208)
 extern "C" pp_status pp_plan_set_annealed_temp(pp_plan *p, float T) {
     if (!p) FAIL(PP_ERR_INVALID, "pp_plan_set_annealed_temp: null plan");

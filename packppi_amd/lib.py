@@ -15,7 +15,7 @@ from .weights import check_state_dict
 _LIB_PATH = os.environ.get("PACKPPI_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libpackppi_hip.so")     # PACKPPI_LIB: A/B runs of build variants
 _lib = None
 
-SYMBOLS = ("pp_version", "pp_last_error", "pp_build_id", "pp_plan_set_knn_ties", "pp_plan_set_annealed_temp", "pp_plan_rebalanced_chains", "pp_topk_aten_host", "pp_plan_create", "pp_plan_destroy", "pp_plan_set_clash_params",
+SYMBOLS = ("pp_version", "pp_last_error", "pp_build_id", "pp_plan_set_knn_ties", "pp_plan_set_annealed_temp", "pp_plan_rebalanced_chains", "pp_rebalance_weights_host", "pp_topk_aten_host", "pp_plan_create", "pp_plan_destroy", "pp_plan_set_clash_params",
            "pp_complex_prepare", "pp_complex_prepare_packed", "pp_ctx_destroy", "pp_ctx_get_graph", "pp_ctx_set_graph", "pp_score", "pp_sample", "pp_atom14",
            "pp_clash", "pp_proximal", "pp_time_kernel", "pp_profile_kernel", "pp_profile_read", "pp_edge_variant", "pp_has_range_check", "pp_range_check", "pp_range_check_parts", "pp_ctx_saturated")
 
@@ -68,6 +68,7 @@ def load():
     lib.pp_plan_set_knn_ties.argtypes = [vp, i]
     lib.pp_plan_set_annealed_temp.argtypes = [vp, f]
     lib.pp_plan_rebalanced_chains.argtypes = [vp]
+    lib.pp_rebalance_weights_host.argtypes = [vp, C.c_size_t, vp, C.POINTER(C.c_int)]
     lib.pp_plan_rebalanced_chains.restype = C.c_int
     lib.pp_topk_aten_host.argtypes = [vp, i, i, vp]
     lib.pp_version.restype = C.c_int
@@ -113,6 +114,22 @@ def _stream(device):
 
 def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def rebalanced_state_dict(state_dict):
+    """(state_dict as pp_plan_create packs it, number of ReLU chains rescaled): host only, no device call.  The split-f16 build
+    rescales the ReLU chains of the edge-level MLPs by powers of two (same function, hidden activations O(1))."""
+    lib = load()
+    sd = check_state_dict(state_dict)
+    flat = np.ascontiguousarray(torch.cat([v.reshape(-1) for v in sd.values()]).numpy(), dtype=np.float32)
+    out = np.empty_like(flat)
+    n = C.c_int(0)
+    _check(lib.pp_rebalance_weights_host(flat.ctypes.data, flat.size, out.ctypes.data, C.byref(n)), "pp_rebalance_weights_host")
+    res, at = {}, 0
+    for k, v in sd.items():
+        res[k] = torch.from_numpy(out[at:at + v.numel()].reshape(tuple(v.shape)).copy())
+        at += v.numel()
+    return res, int(n.value)
 
 
 class Plan:

@@ -182,6 +182,47 @@ def test_hot_path_configs_are_read_and_checked(tmp_path, weights):
         assert r.ckpt_path is None
 
 
+def test_rebalanced_relu_chains_are_the_same_network(weights):
+    """pp_plan_create (split-f16 build) rescales the ReLU chains of the edge-level MLPs by powers of two so that hidden
+    activations are O(1) whatever the checkpoint's split of scale between consecutive layers (csrc/pp_api.hip
+    rebalance_relu_chains).  Host-side statement of that, through the CPU oracle: the rebalanced weights are the SAME network
+    (every scale a power of two: identical in fp32 up to the order of roundings), the seeded fixtures are left alone, and a
+    checkpoint with a layer a thousand times too small / a second layer a thousand times too large is brought back."""
+    from oracle import ref_cpu as O
+    from packppi_amd import synth
+    from packppi_amd.featurize import protein_to_batch
+    from packppi_amd.lib import rebalanced_state_dict
+    from tools.oracle.envelope_weights import envelope_variants, tiny_operand_variants
+    same, n0 = rebalanced_state_dict(weights)
+    assert n0 == 0 and all(torch.equal(same[k], weights[k]) for k in weights)
+    b = protein_to_batch(synth.make_complex(48, 5))
+    g = torch.Generator().manual_seed(4)
+    chi = (torch.rand(1, 48, 4, generator=g) * 2 - 1) * 3.0 * b.SC_D_mask
+    t = torch.full((48,), 0.4)
+    variants = dict(tiny_operand_variants(weights))
+    variants.update({k: v for k, v in envelope_variants(weights).items() if k in ("linear x1/32", "trained-like")})
+    scaled = dict(weights)
+    scaled["mpnn.mpnn_layers.1.edge_dense.W_in.weight"] = weights["mpnn.mpnn_layers.1.edge_dense.W_in.weight"] * 3e5
+    variants["edge FFN first layer x3e5"] = scaled
+    for name, sd in variants.items():
+        reb, n = rebalanced_state_dict(sd)
+        assert n > 0, name
+        for k in sd:                                   # every tensor times ONE power of two (or untouched)
+            ratio = (reb[k] / sd[k])[sd[k] != 0]
+            r0 = float(ratio.flatten()[0])
+            assert torch.all(ratio == r0) and abs(np.log2(r0) - round(np.log2(r0))) < 1e-12, (name, k, r0)
+            assert float(reb[k].abs().max()) < 65504.0
+        with torch.no_grad():
+            s_a, h_a = O.network(sd, b, chi, t)
+            s_b, h_b = O.network(reb, b, chi, t)
+        assert float((h_a - h_b).abs().max() / h_a.abs().max()) < 2e-6, name
+        assert float((s_a - s_b).abs().max() / s_a.abs().max()) < 2e-6, name
+    # the tiny-operand variant comes back to the balanced network it was made from (its scales undo the 1/1024, x1024)
+    reb, n = rebalanced_state_dict(tiny_operand_variants(weights)["edge FFN, layer 1"])
+    k = "mpnn.mpnn_layers.1.edge_dense.W_in.weight"
+    assert 0.25 <= float(reb[k].abs().max() / weights[k].abs().max()) <= 4.0
+
+
 def test_check_state_dict_rejects_bad_shapes(weights):
     from packppi_amd.weights import check_state_dict
     bad = dict(weights)
