@@ -22,6 +22,24 @@ import os
 import subprocess
 import sys
 
+# LayerNorms whose OUTPUT is an f16-split operand of the edge kernels (h_E0, x1 = LN2 output, h_E = LN3 output): a gain vector
+# far below 1 makes those operand vectors small, and below 2^-4 the unscaled low part of the split loses resolution (DESIGN.md
+# section 4.1).  ReLU chains are rebalanced when the plan is made; a LayerNorm gain is not (it is not an exact reparametrisation).
+SMALL_GAIN = 1.0 / 16.0
+EDGE_OPERAND_NORMS = ["encoder.norm_edges.weight"] + [f"mpnn.mpnn_layers.{l}.norm.{k}.weight" for l in range(3) for k in (2, 3)]
+
+
+def small_gain_layernorms(state_dict):
+    """[(name, median |gain|)] of the LayerNorms in front of edge-kernel operands whose median gain is below 2^-4."""
+    import torch
+    out = []
+    for name in EDGE_OPERAND_NORMS:
+        if name in state_dict:
+            med = float(torch.as_tensor(state_dict[name]).float().abs().median())
+            if med < SMALL_GAIN:
+                out.append((name, med))
+    return out
+
 
 def _run(args):
     import torch
@@ -71,6 +89,8 @@ def _run(args):
     report["edge_kernels"], report["node_kernels"] = edge, node
     report["total"] = edge + node
     report["sticky_flag"] = model._ctx.saturated() if model._ctx is not None else 0
+    report["rebalanced_relu_chains"] = model._plan.rebalanced_chains()
+    report["small_gain_layernorms"] = small_gain_layernorms(model.state_dict())
     print("RANGECHECK " + json.dumps(report))
     return report
 
@@ -106,6 +126,9 @@ def main(argv=None):
     rep = check(argv)
     for k, v in rep.items():
         print(f"{k:24s} {v}")
+    if rep.get("small_gain_layernorms"):
+        print("NOTE: LayerNorm gains with a median below 2^-4 in front of split-f16 operands: " + ", ".join(f"{n} ({m:.3g})" for n, m in rep["small_gain_layernorms"])
+              + " -- the operand resolution of the default library drops below fp32 level there: prefer libpackppi_hip.f32.so")
     if rep["total"] == 0:
         print("f16 operand range: OK")
     else:

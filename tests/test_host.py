@@ -223,6 +223,18 @@ def test_rebalanced_relu_chains_are_the_same_network(weights):
     assert 0.25 <= float(reb[k].abs().max() / weights[k].abs().max()) <= 4.0
 
 
+def test_rangecheck_names_small_layernorm_gains(weights):
+    """What the plan-time rebalancing does not cover (a LayerNorm gain is not an exact reparametrisation): gains with a median
+    below 2^-4 in front of edge-kernel operands are named by the range-check tool."""
+    from packppi_amd.rangecheck import small_gain_layernorms
+    assert small_gain_layernorms(weights) == []
+    sd = dict(weights)
+    sd["mpnn.mpnn_layers.1.norm.3.weight"] = weights["mpnn.mpnn_layers.1.norm.3.weight"] * 0.01
+    sd["mpnn.mpnn_layers.1.norm.0.weight"] = weights["mpnn.mpnn_layers.1.norm.0.weight"] * 0.01      # a node LayerNorm: scaled lo', fine
+    found = small_gain_layernorms(sd)
+    assert [n for n, _ in found] == ["mpnn.mpnn_layers.1.norm.3.weight"] and found[0][1] < 0.02
+
+
 def test_check_state_dict_rejects_bad_shapes(weights):
     from packppi_amd.weights import check_state_dict
     bad = dict(weights)
