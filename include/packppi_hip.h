@@ -144,7 +144,9 @@ void pp_ctx_destroy(pp_ctx *ctx);
  * search, clash partners and E_idx numbering stay inside each complex; every other stage is per row or per
  * edge.  Results equal those of each complex prepared on its own (K = min(32, length): complexes shorter
  * than 32 residues cannot be mixed with longer ones -> PP_ERR_UNSUPPORTED).  pp_proximal needs one complex
- * per ctx. */
+ * per ctx.  CONTRACT: the device table must describe the batch (seg_offsets[0] = 0, seg_offsets[n_seg] = the number of rows,
+ * every length within [min_len, max_len]): the library sizes its launches from min_len / max_len and cannot read the table
+ * back without stalling the stream; a table that disagrees is clamped where that is cheap, but the behaviour is undefined. */
 pp_status pp_complex_prepare_packed(pp_plan *plan, const pp_batch *batch, const int32_t *seg_offsets, int n_seg,
                                     int min_len, int max_len, void *stream, pp_ctx **ctx);
 
