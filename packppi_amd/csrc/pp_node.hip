@@ -536,25 +536,28 @@ k_node_update(NUpdArgs A, float *chi, int step, int sde, const float *noise, int
     const nf4 hv4 = *reinterpret_cast<const nf4 *>(A.hV + (size_t)nc * 128 + fc);
     const float ms = A.msum[nc], rm = A.rmask[nc];
     const nf4 zero4i = {0.f, 0.f, 0.f, 0.f};
+    // Every load of this prologue is UNCONDITIONAL and every comparison on a loaded value is left to its use: a load inside a
+    // run-time branch (wave 0 only, `embed_next`, thread ranges) makes the compiler wait for it INSIDE the branch, with a vmcnt
+    // that covers every input requested before it -- and the weight stream below would only start a memory round trip later
+    // (ISA of the layer-2 instance, round 4: two such waits in front of the first weight fetch).  The waves that do not need a
+    // value read the same addresses as the one that does.
     float chi1 = 0.f, scm1 = 0.f, nz1 = 0.f, nz2 = 0.f;       // wave 0: lane (r, g) steps chi g of residue r
-    bool p1 = false, p2 = false;
+    unsigned char m1raw = 0, m2raw = 0;
     int rt = 0;
     nf4 spv = zero4i;                          // c_ode, w, c_drift, c_diff of this step
     if constexpr (MODE == PP_NU_STEP) {
-        if (wv == 0) {
-            spv = nf4{sp.c_ode, sp.w, sp.c_drift, sp.c_diff};
-            chi1 = chi[(size_t)nc * 4 + g];
-            scm1 = A.sc_mask[(size_t)nc * 4 + g];
-            p1 = A.m1pi[(size_t)nc * 4 + g] != 0;
-            p2 = A.m2pi[(size_t)nc * 4 + g] != 0;
-            if (sde) {
-                const size_t NN = (size_t)N * 4;
-                const float *nz = noise + (size_t)step * 2 * NN + (size_t)nc * 4 + g;
-                nz1 = nz[0];
-                nz2 = nz[NN];
-            }
+        spv = nf4{sp.c_ode, sp.w, sp.c_drift, sp.c_diff};
+        chi1 = chi[(size_t)nc * 4 + g];
+        scm1 = A.sc_mask[(size_t)nc * 4 + g];
+        m1raw = A.m1pi[(size_t)nc * 4 + g];
+        m2raw = A.m2pi[(size_t)nc * 4 + g];
+        if (sde) {           // (the noise tensor only exists in sde mode)
+            const size_t NN = (size_t)N * 4;
+            const float *nz = noise + (size_t)step * 2 * NN + (size_t)nc * 4 + g;
+            nz1 = nz[0];
+            nz2 = nz[NN];
         }
-        if (embed_next) rt = (int)A.rtype[nc];
+        rt = (int)A.rtype[nc];
     }
     // small inputs of the kernel's tail, staged in LDS now (a dependent fetch there would sit on the critical path): the
     // tile's backbone frames (threads 0..47) and, in layer 2, the chi-independent dense inputs of the next step's node
@@ -564,21 +567,14 @@ k_node_update(NUpdArgs A, float *chi, int step, int sde, const float *noise, int
     nf4 ev[4] = {tailv, tailv, tailv, tailv};
     const int erow = tid & 15, ern = n0 + erow < N ? n0 + erow : N - 1;
     const bool e_bb = MODE == PP_NU_STEP && tid >= 128 && tid < 144, e_te = MODE == PP_NU_STEP && tid >= 192 && tid < 208;
-    if (tid < 48) {
-        const int row = tid / 3, rn = n0 + row < N ? n0 + row : N - 1;
-        tailv = *reinterpret_cast<const nf4 *>(A.frames + (size_t)rn * 12 + 4 * (tid - 3 * row));
-    } else if (e_bb) {
-        if (embed_next) {
-            const nf2 *bp = reinterpret_cast<const nf2 *>(A.bb_sincos + (size_t)ern * 6);
-            const nf2 b0 = bp[0], b1 = bp[1], b2 = bp[2];
-            ev[0] = nf4{b0[0], b0[1], b1[0], b1[1]};
-            ev[1] = nf4{b2[0], b2[1], 0.f, 0.f};
-        }
-    } else if (e_te) {
-        if (embed_next) {
-#pragma unroll
-            for (int k = 0; k < 16; k++) ev[k >> 2][k & 3] = te_next.v[k];
-        }
+    {       // frames of the tile: threads 0..47 need them, every thread reads (thread t the quad t mod 48 reads)
+        const int t48 = tid % 48, row = t48 / 3, rn = n0 + row < N ? n0 + row : N - 1;
+        tailv = *reinterpret_cast<const nf4 *>(A.frames + (size_t)rn * 12 + 4 * (t48 - 3 * row));
+    }
+    nf2 bb0 = {0.f, 0.f}, bb1 = bb0, bb2 = bb0;      // backbone sin / cos of row `ern` (threads 128..143 use them, after the stream start)
+    if constexpr (MODE == PP_NU_STEP) {
+        const nf2 *bp = reinterpret_cast<const nf2 *>(A.bb_sincos + (size_t)ern * 6);
+        bb0 = bp[0]; bb1 = bp[1]; bb2 = bp[2];
     }
     constexpr int NPV = (NPAR / 4 + 511) / 512;
     nf4 pv[NPV];
@@ -601,7 +597,14 @@ k_node_update(NUpdArgs A, float *chi, int step, int sde, const float *noise, int
     // next step's embedding: the one-hot column is fetched now, used at the very end
     nf4 oh4 = {0.f, 0.f, 0.f, 0.f};
     if constexpr (MODE == PP_NU_STEP) {
-        if (embed_next) oh4 = *reinterpret_cast<const nf4 *>(A.embT + (size_t)rt * 128 + fc);
+        oh4 = *reinterpret_cast<const nf4 *>(A.embT + (size_t)rt * 128 + fc);      // (unconditional, as rt above)
+    }
+    if (e_te) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) ev[k >> 2][k & 3] = te_next.v[k];
+    } else {
+        ev[0] = nf4{bb0[0], bb0[1], bb1[0], bb1[1]};
+        ev[1] = nf4{bb2[0], bb2[1], 0.f, 0.f};
     }
     if (tid < 48) reinterpret_cast<nf4 *>(&sm.fr[0][0])[tid] = tailv;
     else if (e_bb) {                       // features 0..5 (6, 7 are rewritten with chi_0's sin / cos later)
@@ -764,10 +767,10 @@ k_node_update(NUpdArgs A, float *chi, int step, int sde, const float *noise, int
                 const float sw = sg * sp_w;
                 float yk = chi1;
                 if (!sde) {
-                    if (p1 || p2) yk = chi1 + sp_c_ode * sw;
+                    if (m1raw != 0 || m2raw != 0) yk = chi1 + sp_c_ode * sw;
                 } else {
-                    if (p1) yk = chi1 + (sp_c_drift * sw + sp_c_diff * nz1);
-                    if (p2) yk = yk + (sp_c_drift * sw + sp_c_diff * nz2);
+                    if (m1raw != 0) yk = chi1 + (sp_c_drift * sw + sp_c_diff * nz1);
+                    if (m2raw != 0) yk = yk + (sp_c_drift * sw + sp_c_diff * nz2);
                 }
                 const float y = wrap_pi(yk) * scm1;
                 if (live) chi[(size_t)n * 4 + g] = y;
