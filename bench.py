@@ -174,6 +174,10 @@ def l2_requests(kernel):
     return max(hits, key=lambda v: v["launches"]) if hits else None
 
 
+RENDEZVOUS_ENV = ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID", "GROUP_RANK",
+                  "LOCAL_WORLD_SIZE", "ROLE_RANK", "ROLE_WORLD_SIZE")
+
+
 def spawn_ranks(n):
     """python bench.py --gpus N by hand: start N ranks (one per GPU) through torch.distributed.run as a CHILD process.
     Nothing in this process has touched the GPU yet (import torch does not), so no initialised process is replaced."""
@@ -209,7 +213,10 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: one rank per GPU (torch.distributed.run --nproc-per-node {args.gpus})")
     dist = None
-    if world > 1:
+    backend = None
+    # a rank started by torch.distributed.run joins a process group even when it is the only one: `--nproc-per-node 1` runs the
+    # barriers, the max-over-ranks and the metric all-gather through RCCL on a one-GPU box (tests/test_hip_cli.py)
+    if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -223,7 +230,8 @@ def main():
     # configs[1] once more on the exact-fp32 library (libpackppi_hip.f32.so: fp32-MFMA edge kernels, fp32 VALU node update) in a
     # child process of its own, started and finished BEFORE this process touches the GPU (the library is chosen at load time)
     f32_entry = None
-    if world == 1 and args.workload == "t1124" and not args.proximal and not args.no_secondary and not os.environ.get("PACKPPI_LIB"):
+    if (world == 1 and dist is None and args.workload == "t1124" and not args.proximal and not args.no_secondary
+            and not os.environ.get("PACKPPI_LIB")):
         f32_entry = run_f32_child()
 
     dev = torch.device("cuda", local_rank)
@@ -497,7 +505,7 @@ def main():
             "config": {"workload": name, "diffusion_steps": N_DIFFUSION_STEPS, "proximal": bool(args.proximal),
                        "residues_per_gpu": residues, "residues_rank0": residues, "mode": "ode"},
             "parity": {"max_abs_dchi_vs_reference_rad": max_dchi, "atom_rmsd": atom_rmsd},
-            "ranks_seen": ranks_seen, "metrics_rows_gathered": rows_gathered,
+            "ranks_seen": ranks_seen, "metrics_rows_gathered": rows_gathered, "dist_backend": backend,
         }
         if complexes is not None:
             out["config"]["complexes_total"] = 256
@@ -527,7 +535,8 @@ def run_f32_child():
         return entry
     cmd = [sys.executable, os.path.abspath(__file__), "--steps", "5", "--warmup", "2", "--cpu-steps", "0", "--no-secondary", "--no-roofline"]
     try:
-        r = subprocess.run(cmd, env=dict(os.environ, PACKPPI_LIB=lib), capture_output=True, text=True, timeout=300)
+        env = {k: v for k, v in os.environ.items() if k not in RENDEZVOUS_ENV}
+        r = subprocess.run(cmd, env=dict(env, PACKPPI_LIB=lib), capture_output=True, text=True, timeout=300)
         line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
         o = json.loads(line)
         entry.update({"value": o["value"], "unit": o["unit"], "ms_per_step": o["ms_per_step"], "residues": o["config"]["residues_per_gpu"],

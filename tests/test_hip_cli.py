@@ -195,3 +195,32 @@ def test_bench_two_ranks_as_the_driver_launches_it(workload, rows):
     assert out["value"] > 0 and out["scaling"] == ("strong" if workload == "c5" else "weak")
     if workload == "t1124":
         assert out["parity"]["max_abs_dchi_vs_reference_rad"] < 1e-4
+
+
+def test_bench_one_rank_through_rccl():
+    """The collectives of the multi-GPU path on the backend the driver's runs use: `torch.distributed.run --nproc-per-node 1
+    bench.py --gpus 1 --workload c5` gives the rank a process group of one with backend "nccl" (= RCCL), so the communicator
+    is created on this GPU and the fences' barriers, the max-over-ranks all-reduce and the metric all-gather of
+    parallel.gather_metric_rows (int64 id block + float32 rows, device tensors) run as RCCL kernels.  A fresh child process;
+    what a second GPU adds is the transport, not the calls."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "PACKPPI_LIB", "BENCH_DIST_BACKEND", "TORCHELASTIC_RUN_ID"):
+        env.pop(k, None)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0",
+                        "--cpu-steps", "0", "--no-secondary", "--workload", "c5"],
+                       env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-2500:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["dist_backend"] == "nccl" and out["n_gpus"] == 1 and out["ranks_seen"] == 1
+    assert out["metrics_rows_gathered"] == 256 and out["value"] > 0
