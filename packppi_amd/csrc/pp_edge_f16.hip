@@ -979,6 +979,7 @@ __device__ __forceinline__ void edge_update_body(const EdgeArgs &A, const int re
     TS(17)
     if (A.dbg && tid == 0)
         for (int q = 0; q < 18; q++) A.dbg[(size_t)n[0] * 24 + q] = (float)tsv[q];
+    if (A.dbg && tid == 0) A.dbg[(size_t)n[0] * 24 + 18] = (float)((ts0 >> 6) & 0xFFFFF);      // when the workgroup started, units of 64 cycles
 #ifdef PP_X_TS_FINE
     if (A.dbg && tid == 0)
         for (int q = 0; q < 16; q++) A.dbg[(size_t)n[0] * 24 + q] = (float)tsf[q];
