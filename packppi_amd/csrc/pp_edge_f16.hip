@@ -172,15 +172,6 @@ enum { P_BMID = 0, P_BOUT = 128, P_FOB = 256, P_G2 = 384, P_BE2 = 512, P_FIB = 6
 #ifndef PP_WGS2
 #define PP_WGS2 2          // same for the two-residue instances
 #endif
-// -DPP_LAB -DPP_X_UNI: ONE code stream in the mixed launch (experiment).  The one-residue workgroups run the two-residue
-// instance with the second slot switched off by a wave-uniform flag `two`: its MFMAs, LDS traffic and VALU work are branched
-// over (its loads mirror slot 0's addresses), so both workgroups of a CU -- and both CUs of an instruction cache -- fetch the
-// same lines.  RL(r): does slot r do work?
-#ifdef PP_X_UNI
-#define RL(r) ((r) == 0 || two)
-#else
-#define RL(r) true
-#endif
 #ifndef PP_WGS
 #define PP_WGS 3           // register budget = 512 / PP_WGS per lane: three workgroups per CU (the kernels need ~140 VGPRs, 38.4 KB of LDS)
 #endif
@@ -238,23 +229,7 @@ __device__ __forceinline__ void mfma_x(const AOp &a, const HT (&x)[R][4], f32x16
 }
 // one k-step S of a stage (3 R MFMAs) on one tile per residue; a stage = k-steps 0 and 1 of its weight chunk
 template <int R, bool SWAP, int S>
-__device__ __forceinline__ void mfma_hs(const AOp &a, const HT (&x)[R], f32x16 (&acc)[R], const bool two = true) {
-#ifdef PP_X_UNI
-#pragma unroll
-    for (int r = 0; r < R; r++)
-        if (RL(r)) {          // same three products per residue, same order
-            if (SWAP) {
-                acc[r] = MFMA16(x[r].hi[S], a.r[2 * S], acc[r]);
-                acc[r] = MFMA16(x[r].lo[S], a.r[2 * S], acc[r]);
-                acc[r] = MFMA16(x[r].hi[S], a.r[2 * S + 1], acc[r]);
-            } else {
-                acc[r] = MFMA16(a.r[2 * S], x[r].hi[S], acc[r]);
-                acc[r] = MFMA16(a.r[2 * S], x[r].lo[S], acc[r]);
-                acc[r] = MFMA16(a.r[2 * S + 1], x[r].hi[S], acc[r]);
-            }
-        }
-    return;
-#endif
+__device__ __forceinline__ void mfma_hs(const AOp &a, const HT (&x)[R], f32x16 (&acc)[R]) {
     if (SWAP) {
 #pragma unroll
         for (int r = 0; r < R; r++) acc[r] = MFMA16(x[r].hi[S], a.r[2 * S], acc[r]);
@@ -276,23 +251,7 @@ __device__ __forceinline__ void mfma_hs(const AOp &a, const HT (&x)[R], f32x16 (
 // (the last one is all padding and skipped).  The operands live in a 10 KB LDS block per residue, [k-step][hi | lo][lane] h8.
 #define GBUF_FLOATS (5 * 2 * 64 * 4)
 template <int R, int C>
-__device__ __forceinline__ void mfma_geo(const AOp &a, const float *gbuf, int lane, f32x16 (&acc)[R], const bool two = true) {
-#ifdef PP_X_UNI
-#pragma unroll
-    for (int r = 0; r < R; r++)
-        if (RL(r)) {
-#pragma unroll
-            for (int s = 0; s < 2; s++)
-                if (2 * C + s < 5) {
-                    const h8 *gp = reinterpret_cast<const h8 *>(gbuf + r * GBUF_FLOATS) + (2 * (2 * C + s)) * 64 + lane;
-                    const h8 ghi = gp[0], glo = gp[64];
-                    acc[r] = MFMA16(a.r[2 * s], ghi, acc[r]);
-                    acc[r] = MFMA16(a.r[2 * s], glo, acc[r]);
-                    acc[r] = MFMA16(a.r[2 * s + 1], ghi, acc[r]);
-                }
-        }
-    return;
-#endif
+__device__ __forceinline__ void mfma_geo(const AOp &a, const float *gbuf, int lane, f32x16 (&acc)[R]) {
 #pragma unroll
     for (int s = 0; s < 2; s++) {
         if (2 * C + s < 5) {
@@ -532,7 +491,7 @@ __device__ __forceinline__ void geometry_put(const GeoI &g, const float (&pj)[3]
 #endif
 #define ROT(p) ((wave + (p)) & 3)        // input tile at position p of a rotated layer (wave-uniform)
 #define BT_FETCH(BUF, t, set)                                                     \
-    _Pragma("unroll") for (int r = 0; r < R; r++) if (RL(r)) xbuf_get_h((BUF) + r * XBUF_FLOATS, t, lane, bt[set][r]);
+    _Pragma("unroll") for (int r = 0; r < R; r++) xbuf_get_h((BUF) + r * XBUF_FLOATS, t, lane, bt[set][r]);
 // every accumulator chain reaches this point before anything behind it is issued (MFMAs are pure: without a use the
 // instruction selection would let them sink past a barrier)
 #define ACC_FENCE(ACC) _Pragma("unroll") for (int r_ = 0; r_ < R; r_++) asm volatile("" ::"v"(ACC[r_][0]));
@@ -542,10 +501,10 @@ __device__ __forceinline__ void geometry_put(const GeoI &g, const float (&pj)[3]
 #define RSTAGE(k, NCH, ACC, BUF, P, SWAP, BAR, FETCH_LATE)                                                  \
     WSTAGE(k, NCH, ACC, {                                                                                   \
         if constexpr ((P) < 3 && !(FETCH_LATE) && !PP_X_NOBT_) { BT_FETCH(BUF, ROT((P) + 1), ((P) + 1) & 1) }   \
-        (mfma_hs<R, SWAP, 0>(AK, bt[(P) & 1], ACC, two));                                                        \
+        (mfma_hs<R, SWAP, 0>(AK, bt[(P) & 1], ACC));                                                        \
         if constexpr (BAR) { ACC_FENCE(ACC) __syncthreads(); }                                              \
         if constexpr ((P) < 3 && (FETCH_LATE) && !PP_X_NOBT_) { BT_FETCH(BUF, ROT((P) + 1), ((P) + 1) & 1) }    \
-        (mfma_hs<R, SWAP, 1>(AK, bt[(P) & 1], ACC, two));                                                        \
+        (mfma_hs<R, SWAP, 1>(AK, bt[(P) & 1], ACC));                                                        \
     })
 // a layer whose first B operands (the wave's own tile) are in bt[0] already -- PUBLISH_OWN() put them there and into BUF.
 // BAR_A: barrier A in position 3 (the next publication overwrites BUF and no other barrier lies in between).
@@ -567,7 +526,7 @@ __device__ __forceinline__ void geometry_put(const GeoI &g, const float (&pj)[3]
 // barrier here: B follows inside position 0 of the consuming layer, A was passed inside an earlier stage.
 #define PUBLISH_OWN(RELU, SRC, BUF)                                               \
     MF_END()                                                                      \
-    _Pragma("unroll") for (int r = 0; r < R; r++) if (RL(r)) {                    \
+    _Pragma("unroll") for (int r = 0; r < R; r++) {                               \
         split_tile<RELU>(SRC[r], bt[0][r], sat);                                  \
         xbuf_put_h((BUF) + r * XBUF_FLOATS, wave, lane, bt[0][r]);                \
     }
@@ -582,10 +541,10 @@ __device__ __forceinline__ void geometry_put(const GeoI &g, const float (&pj)[3]
         RLAYER_OWN((K0) + 0, NCH, acc, xbuf, false, false)                        \
     }                                                                             \
     MF_BEGIN()                                                                    \
-    WSTAGE((K0) + C0 + 0, NCH, acc, (mfma_geo<R, 0>(AK, gbuf, lane, acc, two)))        \
-    WSTAGE((K0) + C0 + 1, NCH, acc, (mfma_geo<R, 1>(AK, gbuf, lane, acc, two)))        \
+    WSTAGE((K0) + C0 + 0, NCH, acc, (mfma_geo<R, 0>(AK, gbuf, lane, acc)))        \
+    WSTAGE((K0) + C0 + 1, NCH, acc, (mfma_geo<R, 1>(AK, gbuf, lane, acc)))        \
     if constexpr (!ST0) { __syncthreads(); }                                      \
-    WSTAGE((K0) + C0 + 2, NCH, acc, (mfma_geo<R, 2>(AK, gbuf, lane, acc, two)))        \
+    WSTAGE((K0) + C0 + 2, NCH, acc, (mfma_geo<R, 2>(AK, gbuf, lane, acc)))        \
     PUBLISH_OWN(true, acc, xbuf)
 
 #define PROLOGUE_PIPE(NCH)                                                                                     \
@@ -602,7 +561,7 @@ __device__ __forceinline__ void geometry_put(const GeoI &g, const float (&pj)[3]
     int first = -1;                                                                            \
     _Pragma("unroll") for (int r = 0; r < R; r++) {                                            \
         const int nr = res0 + r;                                                               \
-        inr[r] = nr < A.N && RL(r);                                                            \
+        inr[r] = nr < A.N;                                                                     \
         n[r] = inr[r] ? nr : A.N - 1;                                                          \
         rm_[r] = A.rmask[n[r]];                                                                \
     }                                                                                          \
@@ -660,7 +619,6 @@ __device__ __forceinline__ void node_message_body(const EdgeArgs &A, const int r
     const int j = lane & 31, h = lane >> 5;
     const int K = A.K;
     unsigned sat = 0;
-    constexpr bool two = true;
     GROUP_SETUP()
 #pragma unroll
     for (int r = 0; r < R; r++)
@@ -790,7 +748,7 @@ k_node_message(EdgeArgs A) {
 // holds; the node-level inputs PA2 / PC2 / pts2 were written by the node update that ran before this kernel): one
 // launch, one prologue and one read of h_E less per layer.
 template <int R, bool ST0, bool FUSE>
-__device__ __forceinline__ void edge_update_body(const EdgeArgs &A, const int res0, float *smem, const bool two = true) {
+__device__ __forceinline__ void edge_update_body(const EdgeArgs &A, const int res0, float *smem) {
     float *const xbuf = smem, *const x1buf = smem + R * XBUF_FLOATS, *const stat = x1buf + R * XBUF_FLOATS,
                  *const prm = stat + R * STAT_FLOATS;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -870,10 +828,10 @@ __device__ __forceinline__ void edge_update_body(const EdgeArgs &A, const int re
     for (int it = 0; it < PRM_IT; it++) *reinterpret_cast<f32x4v *>(prm + 4 * min(tid + it * ET, PARAM_LDS / 4 - 1)) = prv[it];
     if (tid < 64) *reinterpret_cast<f32x4v *>(prm + PARAM_LDS + 4 * tid) = prg;
 #pragma unroll
-    for (int r = 0; r < R; r++) if (RL(r)) geometry_put(gi0[r], pj[r], wave, lane, gbuf + r * GBUF_FLOATS);
+    for (int r = 0; r < R; r++) geometry_put(gi0[r], pj[r], wave, lane, gbuf + r * GBUF_FLOATS);
     if constexpr (!ST0) { PUBLISH_OWN(false, out, xbuf) }
 #pragma unroll
-    for (int r = 0; r < R; r++) if (RL(r)) {
+    for (int r = 0; r < R; r++) {
         add_tile_q(pc[r], acc[r]);
         if constexpr (ST0) add_tile_q(zt[r], acc[r]);
     }
@@ -883,14 +841,14 @@ __device__ __forceinline__ void edge_update_body(const EdgeArgs &A, const int re
     TS(1)
     // ---- second layer (chunks C0 + 3 ..): barrier A in its last position, the third layer's input overwrites xbuf --------
 #pragma unroll
-    for (int r = 0; r < R; r++) if (RL(r)) load_tile(prm + P_BMID + 32 * wave, h, acc[r]);
+    for (int r = 0; r < R; r++) load_tile(prm + P_BMID + 32 * wave, h, acc[r]);
     RLAYER_OWN(C0 + 3, NCH, acc, xbuf, false, true)
     TS(2)
     PUBLISH_OWN(true, acc, xbuf)
     TS(3)
     // ---- third layer (chunks C0 + 7 ..) -----------------------------------------------------------
 #pragma unroll
-    for (int r = 0; r < R; r++) if (RL(r)) load_tile(prm + P_BOUT + 32 * wave, h, acc[r]);
+    for (int r = 0; r < R; r++) load_tile(prm + P_BOUT + 32 * wave, h, acc[r]);
     RLAYER_OWN(C0 + 7, NCH, acc, xbuf, false, false)
     TS(4)
     // ---- x1 = LN2(h_E + mask * m): own tile only, statistics merged across the four waves ---------------
@@ -898,7 +856,7 @@ __device__ __forceinline__ void edge_update_body(const EdgeArgs &A, const int re
     f32x16 fib;
     FFN_BIAS_FETCH(0)
 #pragma unroll
-    for (int r = 0; r < R; r++) if (RL(r)) {
+    for (int r = 0; r < R; r++) {
 #pragma unroll
         for (int q = 0; q < 16; q++) out[r][q] = fmaf(acc[r][q], me[r], out[r][q]);
         ln_partial(out[r], stat + r * STAT_FLOATS, wave, j, h);
@@ -906,7 +864,7 @@ __device__ __forceinline__ void edge_update_body(const EdgeArgs &A, const int re
     __syncthreads();
     TS(5)
 #pragma unroll
-    for (int r = 0; r < R; r++) if (RL(r)) {
+    for (int r = 0; r < R; r++) {
         float mean;
         const float rstd = ln_merge(stat + r * STAT_FLOATS, j, mean);
 #pragma unroll
@@ -917,7 +875,7 @@ __device__ __forceinline__ void edge_update_body(const EdgeArgs &A, const int re
     // `out` keeps x1 (this wave's tile, fp32) as the residual of the second LayerNorm and collects the FFN output
     // on top of it: out = x1 + b + W2 relu(W1 x1 + b1)
 #pragma unroll
-    for (int r = 0; r < R; r++) if (RL(r)) add_tile(prm + P_FOB + 32 * wave, h, out[r]);
+    for (int r = 0; r < R; r++) add_tile(prm + P_FOB + 32 * wave, h, out[r]);
     TS(6)
     // ---- FFN 128 -> 512 -> 128 in four hidden blocks of 128 ------------------------------------------
     FFN_BLOCK(0)
@@ -931,11 +889,11 @@ __device__ __forceinline__ void edge_update_body(const EdgeArgs &A, const int re
     // ---- h_E = mask * LN3(x1 + ffn) ---------------------------------------------------------------------
     MF_END()
 #pragma unroll
-    for (int r = 0; r < R; r++) if (RL(r)) ln_partial(out[r], stat + r * STAT_FLOATS, wave, j, h);
+    for (int r = 0; r < R; r++) ln_partial(out[r], stat + r * STAT_FLOATS, wave, j, h);
     __syncthreads();
     TS(11)
 #pragma unroll
-    for (int r = 0; r < R; r++) if (RL(r)) {
+    for (int r = 0; r < R; r++) {
         float mean3;
         const float rstd = ln_merge(stat + r * STAT_FLOATS, j, mean3);
 #pragma unroll
@@ -967,17 +925,17 @@ __device__ __forceinline__ void edge_update_body(const EdgeArgs &A, const int re
 #pragma unroll
         for (int r = 0; r < R; r++) load_tile_q(A.PC2 + (size_t)nbr[r] * 128 + 32 * wave, h, pc2[r]);
 #pragma unroll
-        for (int r = 0; r < R; r++) if (RL(r)) geometry_put(gi_[r], pj2[r], wave, lane, gbuf + r * GBUF_FLOATS);
+        for (int r = 0; r < R; r++) geometry_put(gi_[r], pj2[r], wave, lane, gbuf + r * GBUF_FLOATS);
         const float bmid = A.b_mid2[32 * wave + j];           // SWAP form: feature on the lane
         TS(13)
         // the next message's first layer always has its W_B stages (the edges are fresh)
         RLAYER_OWN(NEU + 0, NCH, acc, xbuf, false, false)
-        WSTAGE(NEU + 4, NCH, acc, (mfma_geo<R, 0>(AK, gbuf, lane, acc, two)))
-        WSTAGE(NEU + 5, NCH, acc, (mfma_geo<R, 1>(AK, gbuf, lane, acc, two)))
+        WSTAGE(NEU + 4, NCH, acc, (mfma_geo<R, 0>(AK, gbuf, lane, acc)))
+        WSTAGE(NEU + 5, NCH, acc, (mfma_geo<R, 1>(AK, gbuf, lane, acc)))
         __syncthreads();                  // barrier A of the publication below
-        WSTAGE(NEU + 6, NCH, acc, (mfma_geo<R, 2>(AK, gbuf, lane, acc, two)))
+        WSTAGE(NEU + 6, NCH, acc, (mfma_geo<R, 2>(AK, gbuf, lane, acc)))
 #pragma unroll
-        for (int r = 0; r < R; r++) if (RL(r)) add_tile_q(pc2[r], acc[r]);
+        for (int r = 0; r < R; r++) add_tile_q(pc2[r], acc[r]);
         TS(14)
         PUBLISH_OWN(true, acc, xbuf)
         f32x4v mmv[R][4];          // edge masks of the final reduction, requested a layer ahead (as in node_message_body)
@@ -996,7 +954,7 @@ __device__ __forceinline__ void edge_update_body(const EdgeArgs &A, const int re
         TS(16)
         MF_END()
 #pragma unroll
-        for (int r = 0; r < R; r++) if (RL(r)) {
+        for (int r = 0; r < R; r++) {
             // rows (registers) are edges e = 8 (r>>2) + 4 h + (r&3); mask and reduce over them
             float sacc = 0.f, ms = 0.f;
 #pragma unroll
@@ -1064,12 +1022,8 @@ k_edge_update_mix(EdgeArgs A) {
 #elif PP_X_PRIO == 2
     if (pair >= 0) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1);
 #endif
-#ifdef PP_X_UNI
-    edge_update_body<2, ST0, FUSE>(A, pair >= 0 ? 2 * pair : 2 * A.n_pairs + single, smem, pair >= 0);
-#else
     if (pair >= 0) edge_update_body<2, ST0, FUSE>(A, 2 * pair, smem);
     else edge_update_body<1, ST0, FUSE>(A, 2 * A.n_pairs + single, smem);
-#endif
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -23,7 +23,7 @@
 #endif
 #if !defined(PP_LAB) &&                                                                                                       \
     (defined(PP_X_NU_STOP) || defined(PP_X_TS) || defined(PP_X_TS_FINE) || defined(PP_X_PRIO) || defined(PP_X_NOWLOAD) ||        \
-     defined(PP_X_NOBT) || defined(PP_X_UNI) || defined(PP_X_PRM_ALIAS) || defined(PP_X_PIPE) || defined(PP_X_NU_EMBED_LAUNCH) ||                     \
+     defined(PP_X_NOBT) || defined(PP_X_PRM_ALIAS) || defined(PP_X_PIPE) || defined(PP_X_NU_EMBED_LAUNCH) ||                     \
      defined(PP_X_CVT_SCALAR) || defined(PP_X_CVT_PK) || defined(PP_X_NU_NOMFMA) || defined(PP_X_NU_NOLOAD) ||                   \
      defined(PP_X_NOSAT) || defined(PP_X_NOMFMA) || defined(PP_X_NOACT) || defined(PP_X_E_NOMFMA) || defined(PP_X_CL_NOSCAN) ||  \
      defined(PP_X_CL_NOPAIR) || defined(PP_WDEPTH) || defined(PP_WDEPTH_R1) || defined(PP_NXB_R1) || defined(PP_WGS2) || defined(PP_WGS) ||               \
