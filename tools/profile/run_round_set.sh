@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU box: the whole committed measurement set of a build (rocprofv3 stats + PMC passes, L2 counters, SQ counters, per-workload
 # stats, the bench lines); summaries land in profiles/ on the box and are copied to gpurun_out/ for the trip home.
-#   GRAFT_ROUND=r04 PROFILE_TAG=r04_v1 bash tools/profile/run_round_set.sh
+#   GRAFT_ROUND=r04 PROFILE_TAG=r04_v2 bash tools/profile/run_round_set.sh
 set -e
 export GRAFT_ROUND=${GRAFT_ROUND:-r04}
 export PROFILE_TAG=${PROFILE_TAG:-${GRAFT_ROUND}_v1}
