@@ -472,11 +472,8 @@ def main():
                 "whole_pass_algorithmic_tflops": whole,
                 "whole_pass_frac_of_peak": whole / FP32_MFMA_PEAK_TFLOPS,
                 "kernel_launches_timed": insitu["k_edge_update"][1],
-                # (no separate node-message launch when layer 0 runs as one fused launch, k_nm_nu0: it is then part of the
-                #  first of the three node-update launches timed below)
-                "node_message_kernel_ms": t_node * 1e3 if insitu["k_node_message"][1] else None,
-                "node_message_layer0_tflops": NODE_MSG_FLOP_PER_EDGE * n_edges / t_node / 1e12 if insitu["k_node_message"][1] else None,
-                "layer0_fused_launch": insitu["k_node_message"][1] == 0,
+                "node_message_kernel_ms": t_node * 1e3,
+                "node_message_layer0_tflops": NODE_MSG_FLOP_PER_EDGE * n_edges / t_node / 1e12,
                 # second kernel: the node update (mean over its three launches per evaluation)
                 "node_update": {
                     "kernel": "k_node_update", "kernel_ms": t_nu * 1e3, "launches_timed": insitu["k_node_update"][1],

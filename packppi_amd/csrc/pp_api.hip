@@ -864,9 +864,8 @@ bool pp_prof_take(pp_ctx *c, hipEvent_t *e0, hipEvent_t *e1) {
 static pp_status run_network(pp_ctx *c, hipStream_t s, int step, int last_mode, float *chi, int mode, const float *noise,
                              const StepParams *cur, const StepParams *next) {
     pp_status st;
-    const bool fused0 = pp_layer0_fused(c);     // layer 0's node message and node update as one launch (k_nm_nu0)
     for (int l = 0; l < 3; l++) {
-        if ((l == 0 && !fused0) || (l > 0 && !pp_edge_fused())) {   // fused build: layers 1 and 2 come from the tail of the previous edge update
+        if (l == 0 || !pp_edge_fused()) {   // fused build: layers 1 and 2 come from the tail of the previous edge update
             prof_arm(c, 0);
             st = pp_launch_node_message(c, l, s);
             prof_disarm(c);
@@ -874,8 +873,7 @@ static pp_status run_network(pp_ctx *c, hipStream_t s, int step, int last_mode, 
         }
         if (l < 2) {
             prof_arm(c, 2);
-            st = (l == 0 && fused0) ? pp_launch_layer0_fused(c, s)
-                                    : pp_launch_node_update(c, l, PP_NU_MID, chi, step, mode, noise, nullptr, nullptr, s);
+            st = pp_launch_node_update(c, l, PP_NU_MID, chi, step, mode, noise, nullptr, nullptr, s);
             prof_disarm(c);
             if (st != PP_OK) return st;
             prof_arm(c, 1);

@@ -686,8 +686,6 @@ void pp_edge_occupancy(int *node_msg, int *edge_upd) {
 
 extern "C" int pp_edge_variant(void) { return 0; }
 bool pp_edge_fused() { return true; }
-bool pp_layer0_fused(const pp_ctx *) { return false; }      // the exact-fp32 library keeps the two launches
-pp_status pp_launch_layer0_fused(pp_ctx *, hipStream_t) { pp_set_error("pp_launch_layer0_fused: not in this build"); return PP_ERR_UNSUPPORTED; }
 
 pp_status pp_launch_edge_static(pp_ctx *c, hipStream_t s) {
     EDGE_ATTR_CHECK()

@@ -18,7 +18,6 @@
 #include "pp_internal.h"
 
 PP_RANGE_COUNTER
-#include "pp_node_update.h"     // node_update_body: the fused layer-0 launch below runs it behind the node message
 PP_RANGE_READER(pp_edge_range_hits)
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -612,13 +611,10 @@ __device__ __forceinline__ float ln_merge(const float *st, int j, float &mean_ou
 // ---------------------------------------------------------------------------------------------
 // node message: S[i] = (1/K) sum_j mask_ij relu(W_mid relu(W_in [..]) + b), msum[i] = (1/K) sum_j mask_ij
 // ---------------------------------------------------------------------------------------------
-// TEAMS = 2 (the fused layer-0 launch, k_nm_nu0): two four-wave teams of a 512-thread workgroup run this body side by side,
-// each on its own residues and its own LDS block; the barriers are the whole workgroup's, so a team never leaves early -- a
-// team without a live residue computes on a row that exists and stores nothing.
-template <int R, bool ST0, int TEAMS = 1>
+template <int R, bool ST0>
 __device__ __forceinline__ void node_message_body(const EdgeArgs &A, const int res0, float *smem) {
     float *const xbuf = smem;
-    const int tid = TEAMS == 1 ? threadIdx.x : (threadIdx.x & (ET - 1)), lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, h = lane >> 5;
     const int K = A.K;
@@ -630,11 +626,7 @@ __device__ __forceinline__ void node_message_body(const EdgeArgs &A, const int r
             if (tid < 128) A.S[(size_t)n[r] * 128 + tid] = 0.f;
             if (tid == 0) A.msum[n[r]] = 0.f;
         }
-    const bool any_live = first >= 0;
-    if (first < 0) {
-        if constexpr (TEAMS == 1) return;
-        first = res0 < A.N ? res0 : A.N - 1;
-    }
+    if (first < 0) return;
 #pragma unroll
     for (int r = 0; r < R; r++)
         if (!live[r]) n[r] = first;
@@ -715,7 +707,7 @@ __device__ __forceinline__ void node_message_body(const EdgeArgs &A, const int r
             if (tid == 0) A.msum[n[r]] = ms * A.inv_K;
         }
     }
-    if (any_live && pp_sat_hit(sat)) atomicOr(A.sat, 1u);
+    if (pp_sat_hit(sat)) atomicOr(A.sat, 1u);
 }
 
 template <int R, bool ST0>
@@ -723,37 +715,6 @@ __global__ void __launch_bounds__(ET, R == 1 ? PP_WGS : PP_WGS2)
 k_node_message(EdgeArgs A) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     node_message_body<R, ST0>(A, blockIdx.x * R, smem);
-}
-
-// ---------------------------------------------------------------------------------------------
-// FUSED layer-0 launch (one complex that fills the chip once): node message AND node update of layer 0 in one kernel.
-// The node update is node-local -- a residue's update needs its own message sum and nothing of its neighbours' -- and its
-// launch lasts as long as one CU needs for the 0.9 MB weight stream whatever the tile size.  So a 512-thread workgroup owns
-// FOUR residues: its two four-wave teams first run the layer-0 node message of two residues each (the two-residue instance of
-// node_message_body, own LDS block per team; S and msum go to global memory as always), then the whole workgroup runs the
-// node update on a four-row tile (rows 4..15 of the operand images mirror row 0).  One launch, one dispatch gap and one cold
-// start less per evaluation; every residue's arithmetic is what the two separate launches do: same bits.
-// ---------------------------------------------------------------------------------------------
-#define NMNU_TILE 4
-#define NMNU_DEPTH 7        // weight stages of the node update in flight across the node message (8: 254 registers + scratch)
-#define NM_TEAM_FLOATS (2 * XBUF_FLOATS + 2 * GBUF_FLOATS)
-template <int NU_ND>
-__global__ void __launch_bounds__(512)
-k_nm_nu0(EdgeArgs E, NUpdArgs U) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const StepScalars sp0 = {0.f, 0.f, 0.f, 0.f};
-    const TimeEmb te0 = {};
-    // The node update asks for its S-independent inputs and its first weight stages, THEN the node message runs (those loads land
-    // under it: the update's cold start is hidden), then the update reads what the message wrote.
-    auto message = [&]() {
-        const int team = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8);
-        node_message_body<2, true, 2>(E, (int)blockIdx.x * NMNU_TILE + 2 * team, smem + team * NM_TEAM_FLOATS);
-        // the tile's S / msum were written by this workgroup: stores complete, every wave past its last LDS access of the message
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __syncthreads();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    };
-    node_update_body<PP_NU_MID, NU_ND, 1, NMNU_TILE>(U, nullptr, 0, 0, nullptr, 0, sp0, te0, reinterpret_cast<char *>(smem), (int)blockIdx.x, message);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1345,7 +1306,6 @@ static bool edge_attrs() {
                      set(reinterpret_cast<const void *>(eu_kernel_r(R, st0)), MAX_SMEM);
         ok = ok && set(reinterpret_cast<const void *>(k_edge_update_mix<true, PP_FUSED>), MAX_SMEM) &&
              set(reinterpret_cast<const void *>(k_edge_update_mix<false, PP_FUSED>), MAX_SMEM);
-        ok = ok && set(reinterpret_cast<const void *>(k_nm_nu0<NMNU_DEPTH>), MAX_SMEM);
         int dev = 0;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
@@ -1413,30 +1373,6 @@ pp_status pp_launch_node_message(pp_ctx *c, int layer, hipStream_t s) {
     static const int nm_R = nm_env ? atoi(nm_env) : 0;       // measurement aid: residues per workgroup of this kernel only
     const int R = (nm_R >= 1 && nm_R <= PP_RMAX) ? nm_R : pick_R(c->N);
     PP_LAUNCH(c, nm_kernel_r(R, layer == 0), dim3((c->N + R - 1) / R), dim3(ET), nm_smem(R), s, A);
-    PP_HIP_CHECK(hipGetLastError());
-    return PP_OK;
-}
-
-// Layer 0 as ONE launch (k_nm_nu0) when four-residue tiles fill the chip at most once.  The range-check build keeps the two
-// launches (its counters are per kernel family); -DPP_DIAG builds read PP_FUSE0=0 to switch it off (A/B runs).
-bool pp_layer0_fused(const pp_ctx *c) {
-#ifdef PP_CHECK_RANGE
-    return false;
-#else
-    static const char *e = PP_GETENV("PP_FUSE0");
-    static const bool on = !(e && atoi(e) == 0);
-    if (!on || !PP_FUSED || g_forced_R >= 1) return false;
-    edge_attrs();
-    return (c->N + NMNU_TILE - 1) / NMNU_TILE <= g_num_cu;
-#endif
-}
-pp_status pp_launch_layer0_fused(pp_ctx *c, hipStream_t s) {
-    EDGE_ATTR_CHECK()
-    EdgeArgs E = edge_args(c, 0, false);
-    NUpdArgs U = pp_node_update_args(c, 0);
-    const size_t nm = 2 * NM_TEAM_FLOATS * sizeof(float);
-    const size_t smem = pad_smem(nm > sizeof(SmemU) ? nm : sizeof(SmemU));
-    PP_LAUNCH(c, k_nm_nu0<NMNU_DEPTH>, dim3((c->N + NMNU_TILE - 1) / NMNU_TILE), dim3(512), smem, s, E, U);
     PP_HIP_CHECK(hipGetLastError());
     return PP_OK;
 }

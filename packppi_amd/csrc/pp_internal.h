@@ -297,8 +297,6 @@ pp_status pp_launch_edge_embed_f16(pp_ctx *c, hipStream_t s);   // pp_edge_f16.h
 #endif
 pp_status pp_launch_node_message(pp_ctx *c, int layer, hipStream_t s);
 bool pp_edge_fused();            // does pp_launch_edge_update also compute the next layer's node message?
-bool pp_layer0_fused(const pp_ctx *c);      // layer 0 (node message + node update) as one launch for this context? (split-f16 build, small N)
-pp_status pp_launch_layer0_fused(pp_ctx *c, hipStream_t s);
 pp_status pp_launch_edge_update(pp_ctx *c, int layer, hipStream_t s);   // + node message of layer + 1
 pp_status pp_launch_atom14(pp_ctx *c, const float *chi, float *xyz, hipStream_t s);
 pp_status pp_launch_clash(pp_ctx *c, const float *xyz, float *per_res, float *dchi, hipStream_t s);
