@@ -1026,6 +1026,17 @@ k_edge_update_mix(EdgeArgs A) {
     else edge_update_body<1, ST0, FUSE>(A, 2 * A.n_pairs + single, smem);
 }
 
+// the stand-alone node message (layer 0) with the same split of a CU's three residues: two weight passes instead of three
+template <bool ST0>
+__global__ void __launch_bounds__(ET, 2)
+k_node_message_mix(EdgeArgs A) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int b = blockIdx.x;
+    const int ns = gridDim.x - A.n_pairs;
+    if (b < ns) node_message_body<1, ST0>(A, 2 * A.n_pairs + b, smem);       // the one-residue workgroups first, as in k_edge_update_mix
+    else node_message_body<2, ST0>(A, 2 * (b - ns), smem);
+}
+
 // ---------------------------------------------------------------------------------------------
 // once per complex: Z_nm = W_B(node message, layer 0) h_E0 and Z_em = W_B(edge message, layer 0) h_E0.  h_E0 never
 // changes during sampling, so the layer-0 kernels skip four of their stages and start from these tiles.
@@ -1306,6 +1317,8 @@ static bool edge_attrs() {
                      set(reinterpret_cast<const void *>(eu_kernel_r(R, st0)), MAX_SMEM);
         ok = ok && set(reinterpret_cast<const void *>(k_edge_update_mix<true, PP_FUSED>), MAX_SMEM) &&
              set(reinterpret_cast<const void *>(k_edge_update_mix<false, PP_FUSED>), MAX_SMEM);
+        ok = ok && set(reinterpret_cast<const void *>(k_node_message_mix<true>), MAX_SMEM) &&
+             set(reinterpret_cast<const void *>(k_node_message_mix<false>), MAX_SMEM);
         int dev = 0;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
@@ -1372,6 +1385,16 @@ pp_status pp_launch_node_message(pp_ctx *c, int layer, hipStream_t s) {
     static const char *nm_env = PP_GETENV("PP_NM_R");
     static const int nm_R = nm_env ? atoi(nm_env) : 0;       // measurement aid: residues per workgroup of this kernel only
     const int R = (nm_R >= 1 && nm_R <= PP_RMAX) ? nm_R : pick_R(c->N);
+    static const char *nmix_env = PP_GETENV("PP_NM_MIX");
+    static const bool nmix = !(nmix_env && atoi(nmix_env) == 0);
+    if (nmix && !(nm_R >= 1 && nm_R <= PP_RMAX) && use_mix(c->N)) {
+        A.n_pairs = (c->N + 2) / 3;
+        const int singles = c->N - 2 * A.n_pairs > 0 ? c->N - 2 * A.n_pairs : 0;
+        PP_LAUNCH(c, (layer == 0 ? k_node_message_mix<true> : k_node_message_mix<false>), dim3(A.n_pairs + singles), dim3(ET),
+                  nm_smem(2), s, A);
+        PP_HIP_CHECK(hipGetLastError());
+        return PP_OK;
+    }
     PP_LAUNCH(c, nm_kernel_r(R, layer == 0), dim3((c->N + R - 1) / R), dim3(ET), nm_smem(R), s, A);
     PP_HIP_CHECK(hipGetLastError());
     return PP_OK;

@@ -17,10 +17,10 @@ echo sq done
 bash tools/profile/run_stats_workload.sh $V s1500 > gpurun_out/set_stats_s1500.log 2>&1
 bash tools/profile/run_stats_workload.sh $V c5 > gpurun_out/set_stats_c5.log 2>&1
 echo stats done
+cp profiles/${PROFILE_TAG}_* gpurun_out/ 2>/dev/null || true      # (before the bench lines: a committed older line in profiles/ must not overwrite a fresh one)
 python bench.py --steps 20 --warmup 5 > gpurun_out/${PROFILE_TAG}_bench_t1124.json 2> gpurun_out/set_bench.err
 python bench.py --proximal > gpurun_out/${PROFILE_TAG}_bench_t1124_prox.json 2>> gpurun_out/set_bench.err
 python bench.py --workload s1500 > gpurun_out/${PROFILE_TAG}_bench_s1500.json 2>> gpurun_out/set_bench.err
 python bench.py --workload s1500 --proximal > gpurun_out/${PROFILE_TAG}_bench_s1500_prox.json 2>> gpurun_out/set_bench.err
 python bench.py --workload c5 > gpurun_out/${PROFILE_TAG}_bench_c5.json 2>> gpurun_out/set_bench.err
 echo bench done
-cp profiles/${PROFILE_TAG}_* gpurun_out/ 2>/dev/null || true
