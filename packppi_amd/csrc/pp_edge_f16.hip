@@ -747,14 +747,11 @@ k_node_message(EdgeArgs A) {
 // FUSE: the workgroup goes straight on to the NEXT layer's node message of its residues (same edges, whose new h_E it
 // holds; the node-level inputs PA2 / PC2 / pts2 were written by the node update that ran before this kernel): one
 // launch, one prologue and one read of h_E less per layer.
-// TEAMS = 2 (k_edge_update_trio): this body is one of two four-wave teams of a 512-thread workgroup; the barriers are the whole
-// workgroup's (both teams pass the same sequence of them), so a team must never leave early: the kernel hands a team without a
-// live residue a live one of the other team as a stand-in (`mute`: same control flow, no stores).
-template <int R, bool ST0, bool FUSE, int TEAMS = 1>
-__device__ __forceinline__ void edge_update_body(const EdgeArgs &A, const int res0, float *smem, const bool mute = false) {
+template <int R, bool ST0, bool FUSE>
+__device__ __forceinline__ void edge_update_body(const EdgeArgs &A, const int res0, float *smem) {
     float *const xbuf = smem, *const x1buf = smem + R * XBUF_FLOATS, *const stat = x1buf + R * XBUF_FLOATS,
                  *const prm = stat + R * STAT_FLOATS;
-    const int tid = TEAMS == 1 ? threadIdx.x : (threadIdx.x & (ET - 1)), lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, h = lane >> 5;
     const int K = A.K;
@@ -763,7 +760,7 @@ __device__ __forceinline__ void edge_update_body(const EdgeArgs &A, const int re
     GROUP_SETUP()
 #pragma unroll
     for (int r = 0; r < R; r++)
-        if (inr[r] && !live[r] && !mute) {         // masked / padded residue: its edges are zero
+        if (inr[r] && !live[r]) {         // masked / padded residue: its edges are zero
             if (j < K) {
                 f32x4v z = {0.f, 0.f, 0.f, 0.f};
                 float *orow = A.hE_out + ((size_t)n[r] * K + j) * 128 + 32 * wave;
@@ -775,14 +772,10 @@ __device__ __forceinline__ void edge_update_body(const EdgeArgs &A, const int re
                 if (tid == 0) A.msum[n[r]] = 0.f;
             }
         }
-    if (first < 0) return;            // (TEAMS = 2: the caller never hands a team a group without a live residue)
+    if (first < 0) return;
 #pragma unroll
     for (int r = 0; r < R; r++)
         if (!live[r]) n[r] = first;
-    if (mute) {
-#pragma unroll
-        for (int r = 0; r < R; r++) live[r] = false;       // a stand-in run: same control flow and barriers, no stores
-    }
     // chunks: [W_B x4,] W_G x3, W_mid x4, W_out x4, then per hidden block c: W1 x4, W2 x4
     constexpr int C0 = ST0 ? 0 : 4;
     constexpr int NEU = C0 + 43;                       // chunks of the edge update itself
@@ -1031,41 +1024,6 @@ k_edge_update_mix(EdgeArgs A) {
 #endif
     if (pair >= 0) edge_update_body<2, ST0, FUSE>(A, 2 * pair, smem);
     else edge_update_body<1, ST0, FUSE>(A, 2 * A.n_pairs + single, smem);
-}
-
-// TRIO launch (experiment): the CU's three residues in ONE 512-thread workgroup -- team 0 (waves 0-3) runs the two-residue
-// instance on residues 3b, 3b + 1, team 1 (waves 4-7) the one-residue instance on 3b + 2, each in its own LDS block, in
-// lockstep through the workgroup's barriers.  Wave w of both teams asks for the same quarter of every weight chunk within a
-// stage of each other: the second request hits in the L1 (or merges with the miss in flight), so the CU pulls the layer's
-// weight set through its L2 -> L1 fill path ONCE (0.93 instead of 1.86 MB per launch).
-#define EU_TEAM0_FLOATS (2 * 2 * XBUF_FLOATS + 2 * STAT_FLOATS + PARAM_LDS + 256)
-template <bool ST0, bool FUSE>
-__global__ void __launch_bounds__(2 * ET)
-k_edge_update_trio(EdgeArgs A) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int b = blockIdx.x, N = A.N;
-    const int r0 = 3 * b, r1 = r0 + 1, r2 = r0 + 2;
-    const bool l0 = r0 < N && A.rmask[r0 < N ? r0 : N - 1] != 0.f, l1 = r1 < N && A.rmask[r1 < N ? r1 : N - 1] != 0.f,
-               l2 = r2 < N && A.rmask[r2 < N ? r2 : N - 1] != 0.f;
-    const bool team1 = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8) != 0;
-    if ((l0 || l1) && l2) {           // the regular case
-        if (!team1) edge_update_body<2, ST0, FUSE, 2>(A, r0, smem);
-        else edge_update_body<1, ST0, FUSE, 2>(A, r2, smem + EU_TEAM0_FLOATS);
-    } else if (l0 || l1) {            // team 1 has nothing of its own: it zeroes its residue's rows (if it has one) and stands in
-        if (!team1) edge_update_body<2, ST0, FUSE, 2>(A, r0, smem);
-        else {
-            if (r2 < N) edge_update_body<1, ST0, FUSE, 2>(A, r2, smem + EU_TEAM0_FLOATS);       // masked: zero rows, returns before any barrier
-            edge_update_body<1, ST0, FUSE, 2>(A, l0 ? r0 : r1, smem + EU_TEAM0_FLOATS, true);
-        }
-    } else if (l2) {                  // team 0 has nothing of its own
-        if (!team1) {
-            edge_update_body<2, ST0, FUSE, 2>(A, r0, smem);        // zero rows of the masked / padded pair, returns before any barrier
-            edge_update_body<2, ST0, FUSE, 2>(A, r2, smem, true);  // stand-in on (r2, r2 + 1)
-        } else edge_update_body<1, ST0, FUSE, 2>(A, r2, smem + EU_TEAM0_FLOATS);
-    } else {                          // nothing live: every wave zeroes its rows and leaves (no barrier was entered)
-        if (!team1) edge_update_body<2, ST0, FUSE, 2>(A, r0, smem);
-        else if (r2 < N) edge_update_body<1, ST0, FUSE, 2>(A, r2, smem + EU_TEAM0_FLOATS);
-    }
 }
 
 // the stand-alone node message (layer 0) with the same split of a CU's three residues: two weight passes instead of three
@@ -1359,8 +1317,6 @@ static bool edge_attrs() {
                      set(reinterpret_cast<const void *>(eu_kernel_r(R, st0)), MAX_SMEM);
         ok = ok && set(reinterpret_cast<const void *>(k_edge_update_mix<true, PP_FUSED>), MAX_SMEM) &&
              set(reinterpret_cast<const void *>(k_edge_update_mix<false, PP_FUSED>), MAX_SMEM);
-        ok = ok && set(reinterpret_cast<const void *>(k_edge_update_trio<true, PP_FUSED>), MAX_SMEM) &&
-             set(reinterpret_cast<const void *>(k_edge_update_trio<false, PP_FUSED>), MAX_SMEM);
         ok = ok && set(reinterpret_cast<const void *>(k_node_message_mix<true>), MAX_SMEM) &&
              set(reinterpret_cast<const void *>(k_node_message_mix<false>), MAX_SMEM);
         int dev = 0;
@@ -1454,14 +1410,6 @@ pp_status pp_launch_edge_update(pp_ctx *c, int layer, hipStream_t s) {
     if (layer < 0 || layer > 1) { pp_set_error("pp_launch_edge_update: layer must be 0 or 1"); return PP_ERR_INVALID; }
     EdgeArgs A = edge_args(c, layer, true);
     const int R = pick_R(c->N);
-    static const char *trio_env = PP_GETENV("PP_EDGE_TRIO");
-    static const bool trio = trio_env && atoi(trio_env) == 1;
-    if (trio && use_mix(c->N)) {
-        PP_LAUNCH(c, (layer == 0 ? k_edge_update_trio<true, PP_FUSED> : k_edge_update_trio<false, PP_FUSED>), dim3((c->N + 2) / 3),
-                  dim3(2 * ET), (EU_TEAM0_FLOATS * sizeof(float)) + eu_smem(1), s, A);
-        PP_HIP_CHECK(hipGetLastError());
-        return PP_OK;
-    }
     if (use_mix(c->N)) {
         // three residues per CU as one two-residue and one one-residue workgroup
         A.n_pairs = (c->N + 2) / 3;
