@@ -14,7 +14,7 @@
 // RESULTS (no weight fetches, no matrix instructions, stop points ...).  None of them may reach a shipped library:
 //   -DPP_LAB   is required by every PP_X_* switch (tools/debug, tools/profile build tagged libraries with it);
 //   -DPP_DIAG  (implied by PP_LAB; the libpackppi_hip.dbg.so build) compiles the pp_debug_* exports and the getenv switches
-//              of the launchers (PP_NU_SPLIT, PP_EDGE_MIX, PP_EDGE_R, PP_NM_R, PP_NODE_F16, PP_DEBUG): same kernels, same
+//              of the launchers (PP_NU_SPLIT, PP_EDGE_MIX, PP_EDGE_R, PP_NM_R, PP_NM_MIX, PP_NODE_F16, PP_DEBUG): same kernels, same
 //              results, forced launch shapes -- the default / .f32 / .chk libraries have neither.
 // packppi_amd/build.py refuses these flags for the three product libraries and lib.load() refuses a library whose flag
 // stamp is not one of the known sets.
