@@ -108,7 +108,8 @@ pp_status pp_plan_set_knn_ties(pp_plan *plan, int mode);
 
 /* Replaces sample_cfg.annealed_temp as TDiffusionModule.__init__ hands it to both SO2VESchedule instances
  * (TorsionalDiffusion.py:70-75; configs/model/sample_cfg/Sampling.yaml:4, default 3): the T of the annealed weight
- * w = T / (alpha + (1 - alpha) T) in SO2VESchedule.step (schedule.py:205-208).  Applies to later pp_score / pp_sample calls. */
+ * w = T / (alpha + (1 - alpha) T) in SO2VESchedule.step (schedule.py:216-217); 0 = no annealing, w = 1 (the reference's
+ * `if self.annealed_temp`: a Sampling.yaml with `annealed_temp: 0` or `null`).  Applies to later pp_score / pp_sample calls. */
 pp_status pp_plan_set_annealed_temp(pp_plan *plan, float annealed_temp);
 
 /* No reference counterpart.  The split-f16 build rebalances every ReLU chain of the edge-level MLPs by powers of two when the
@@ -192,8 +193,9 @@ pp_status pp_proximal(pp_ctx *ctx, const float *chi, float lamda, int num_steps,
 pp_status pp_time_kernel(pp_ctx *ctx, int which, int iters, float *avg_ms, void *stream);
 
 /* Measurement aid, no reference counterpart: in-situ duration of a hot kernel.  After
- * pp_profile_kernel(ctx, which) (0 node message, 1 edge update, 2 node update) every launch of that
- * kernel made by pp_score / pp_sample carries a start / stop HIP event pair on the launch stream
+ * pp_profile_kernel(ctx, which) (0 node message, 1 edge update, 2 node update; 3 clash loss + gradient and
+ * 4 Adam step + reconstruction of the Adam loop inside pp_proximal) every launch of that
+ * kernel made by pp_score / pp_sample / pp_proximal carries a start / stop HIP event pair on the launch stream
  * (hipExtLaunchKernelGGL: the dispatch's own begin and end, the interval rocprofv3's kernel trace reports);
  * pp_profile_read waits for the last one, returns the summed intervals (ms) and the number of
  * launches, and switches profiling off again. */

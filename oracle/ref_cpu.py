@@ -326,7 +326,7 @@ def reverse_step(x, score, time, dt, mask, mode="ode", noise=None):
     sigma = t_to_sigma(time)
     g = sigma * np.sqrt(2 * np.log(SIGMA_MAX / SIGMA_MIN))
     alpha = 1 - (sigma / np.exp(np.log(SIGMA_MAX))) ** 2
-    w = ANNEALED_TEMP / (alpha + (1 - alpha) * ANNEALED_TEMP)
+    w = ANNEALED_TEMP / (alpha + (1 - alpha) * ANNEALED_TEMP) if ANNEALED_TEMP else 1      # schedule.py:216-217
     if mode == "ode":
         new = x + 0.5 * g ** 2 * dt * (score * w)
     else:

@@ -70,7 +70,9 @@ def _compile_and_link(lib_path, sources, flags, tag, verbose, only=()):
     objs, jobs = [], []
     for src in sources:
         obj = os.path.join(CSRC, src.replace(".hip", f".{tag}.o" if tag else ".o"))
-        if tag and only and src not in only:
+        # pp_api.hip carries the build stamp (flags included): a tagged build always recompiles it, so that a laboratory library
+        # can never link the product object and pass lib.load()'s flag-stamp check
+        if tag and only and src not in only and src != "pp_api.hip":
             objs.append(os.path.join(CSRC, src.replace(".hip", ".o")))
             continue
         extra = [f'-DPP_BUILD_ID="{stamp}"'] if src == "pp_api.hip" else []

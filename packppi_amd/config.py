@@ -17,8 +17,6 @@ import os
 from types import SimpleNamespace
 from typing import Any, Dict, Optional
 
-import yaml
-
 ENCODER_YAML = os.path.join("model", "encoder_cfg", "ProteinEncoder.yaml")
 MODEL_YAML = os.path.join("model", "model_cfg", "MpnnNet.yaml")
 SAMPLE_YAML = os.path.join("model", "sample_cfg", "Sampling.yaml")
@@ -43,6 +41,7 @@ def _as_dict(cfg) -> Dict[str, Any]:
 
 
 def read_yaml(path) -> Dict[str, Any]:
+    import yaml          # only a configuration TREE needs PyYAML: constructing a model from dicts / namespaces does not
     with open(path) as fh:
         data = yaml.safe_load(fh)
     if data is None:
@@ -54,7 +53,10 @@ def read_yaml(path) -> Dict[str, Any]:
 
 def load_hot_path_configs(config_dir) -> SimpleNamespace:
     """``config_dir`` = the reference checkout's ``configs/`` (or a directory laid out like it).  Returns a namespace with
-    ``encoder_cfg``, ``model_cfg``, ``sample_cfg`` (dicts; a missing file gives ``None``), ``ckpt_path`` and ``seed``."""
+    ``encoder_cfg``, ``model_cfg``, ``sample_cfg`` (dicts; a missing file gives ``None``), ``ckpt_path`` and ``seed``.
+    ``seed`` is reported, not applied: the reference's eval_diffusion.py never reads ``cfg.seed`` (only train_diffusion.py:21-22 and
+    train_affinity.py:21-22 call ``pl.seed_everything``), so its sampling draws are unseeded; ``cli.eval_diffusion --seed`` is this
+    package's own switch."""
     config_dir = os.fspath(config_dir)
     if not os.path.isdir(config_dir):
         raise RuntimeError(f"config directory '{config_dir}' does not exist")

@@ -35,38 +35,6 @@ extern "C" const char *pp_build_id(void) { return g_build_id + 12; }
     } while (0)
 
 // ---------------------------------------------------------------------------------------------
-WeightOff pp_weight_offsets() {
-    WeightOff o;
-    size_t p = 0;
-    auto take = [&](size_t n) { size_t r = p; p += n; return r; };
-    o.node_emb_w = take(128 * 51); o.node_emb_b = take(128);
-    o.norm_nodes_g = take(128); o.norm_nodes_b = take(128);
-    o.edge_emb_w = take(128 * 468); o.edge_emb_b = take(128);
-    o.norm_edges_g = take(128); o.norm_edges_b = take(128);
-    for (int l = 0; l < 3; l++) {
-        LayerOff &L = o.layer[l];
-        L.pts_node_w = take(24 * 128); L.pts_node_b = take(24);
-        L.pts_edge_w = take(24 * 128); L.pts_edge_b = take(24);
-        L.nm_in_w = take(128 * 456); L.nm_in_b = take(128);
-        L.nm_mid_w = take(128 * 128); L.nm_mid_b = take(128);
-        L.nm_out_w = take(128 * 128); L.nm_out_b = take(128);
-        L.em_in_w = take(128 * 456); L.em_in_b = take(128);
-        L.em_mid_w = take(128 * 128); L.em_mid_b = take(128);
-        L.em_out_w = take(128 * 128); L.em_out_b = take(128);
-        for (int k = 0; k < 4; k++) { L.norm_g[k] = take(128); L.norm_b[k] = take(128); }
-        L.nd_in_w = take(512 * 128); L.nd_in_b = take(512);
-        L.nd_out_w = take(128 * 512); L.nd_out_b = take(128);
-        L.ed_in_w = take(512 * 128); L.ed_in_b = take(512);
-        L.ed_out_w = take(128 * 512); L.ed_out_b = take(128);
-    }
-    o.d0_in_w = take(64 * 128); o.d0_in_b = take(64);
-    o.d0_out_w = take(32 * 64); o.d0_out_b = take(32);
-    o.d2_in_w = take(16 * 32); o.d2_in_b = take(16);
-    o.d2_out_w = take(4 * 16); o.d2_out_b = take(4);
-    o.total = p;
-    return o;
-}
-
 // host-side transpose of W[rows][ld] columns [c0, c0+cols) into dst[cols][rows]
 static size_t put_T(std::vector<float> &arena, const float *W, int rows, int ld, int c0, int cols) {
     size_t at = arena.size();
@@ -327,75 +295,7 @@ static size_t put_edge_params(std::vector<float> &arena, const float *w, const L
 }
 
 #ifdef PP_EDGE_F16
-// ---- power-of-two rebalancing of the ReLU chains (split-f16 build) ---------------------------------------------------------
-// The edge kernels carry an activation as hi + lo with an UNSCALED low part: below |x| = 2^-4 the low part is a subnormal f16
-// number and carries an absolute error of 2^-25 instead of a relative 2^-22.  LayerNorm outputs and geometry are O(1); a HIDDEN
-// activation is as large as the checkpoint happens to make it -- a network that computes relu(W2 relu(W1 x + b1) + b2) with
-// W1 a thousand times smaller and W2 a thousand times larger is the same function, and its hidden operands sit at 1e-3, where
-// 15 bits are left (measured: T1124, 100 steps, 1.9e-4 rad from the reference against 8e-6 for the balanced network;
-// tests/test_hip_parity.py::test_weight_range_envelope_T1124, "tiny operands").  ReLU commutes with a positive scale, so the
-// chain is rebalanced here, once, exactly: W1, b1 times s, W2 divided by s, s a power of two chosen so that the rows of the
-// producing layer have a median norm of about 1 (nothing is touched while that norm is within [1/8, 8]: the seeded fixtures
-// keep their bits).  In fp32 the rebalanced network is the same function to the last bit (no overflow / underflow at these
-// magnitudes); every consumer -- the edge kernels, the node update's projections and its W_out of the node message, the
-// first node embedding, the static layer-0 products -- is packed from the rebalanced vector.  Cost at run time: none.
-static float row_norm_median(const float *W, int rows, int cols, int ld, const float *bias, float col_scale) {
-    std::vector<float> nrm((size_t)rows);
-    for (int i = 0; i < rows; i++) {
-        double a = bias ? (double)bias[i] * bias[i] : 0.0;
-        for (int c = 0; c < cols; c++) { const double w = (double)W[(size_t)i * ld + c] * col_scale; a += w * w; }
-        nrm[i] = (float)std::sqrt(a);
-    }
-    std::nth_element(nrm.begin(), nrm.begin() + rows / 2, nrm.end());
-    return nrm[rows / 2];
-}
-static float pow2_rebalance(float norm) {
-    if (!(norm > 0.f) || !std::isfinite(norm) || (norm >= 0.125f && norm <= 8.f)) return 1.f;
-    int e = (int)std::lround(-std::log2((double)norm));
-    e = e < -24 ? -24 : (e > 24 ? 24 : e);
-    return std::ldexp(1.f, e);
-}
-static float max_abs(const float *w, size_t n) {
-    float m = 0.f;
-    for (size_t i = 0; i < n; i++) m = std::max(m, std::fabs(w[i]));
-    return m;
-}
-// the smallest power of two >= x (x <= 0: the smallest scale there is, i.e. no constraint)
-static float pow2_at_least(float x) {
-    if (!(x > 0.f) || !std::isfinite(x)) return std::ldexp(1.f, -60);
-    return std::ldexp(1.f, (int)std::ceil(std::log2((double)x)));
-}
-static void scale_block(float *w, size_t n, float s) {
-    if (s != 1.f) for (size_t i = 0; i < n; i++) w[i] *= s;
-}
-// in place on a host copy of the weight vector; returns how many chains were rescaled
-static int rebalance_relu_chains(float *w, const WeightOff &off) {
-    int changed = 0;
-    for (int l = 0; l < 3; l++) {
-        const LayerOff &L = off.layer[l];
-        const size_t in_w[2] = {L.nm_in_w, L.em_in_w}, in_b[2] = {L.nm_in_b, L.em_in_b}, mid_w[2] = {L.nm_mid_w, L.em_mid_w},
-                     mid_b[2] = {L.nm_mid_b, L.em_mid_b}, out_w[2] = {L.nm_out_w, L.em_out_w};
-        for (int f = 0; f < 2; f++) {      // node message, edge message: hidden 1 after W_in, hidden 2 after W_inter.0
-            float s1 = pow2_rebalance(row_norm_median(w + in_w[f], 128, 456, 456, w + in_b[f], 1.f));
-            // W_inter.0 sees hidden 1, which is O(1) once multiplied by s1: its pre-activation has the size of the rows of W / s1
-            float s2 = pow2_rebalance(row_norm_median(w + mid_w[f], 128, 128, 128, w + mid_b[f], 1.f / s1));
-            // the consuming layers are divided by the scale: they must stay inside the f16 range themselves (a hidden layer that
-            // really is huge keeps part of its size -- and saturates, flagged, if that is beyond 65504)
-            s2 = std::max(s2, pow2_at_least(max_abs(w + out_w[f], (size_t)128 * 128) / 32768.f));
-            s1 = std::max(s1, pow2_at_least(max_abs(w + mid_w[f], (size_t)128 * 128) * s2 / 32768.f));
-            scale_block(w + in_w[f], (size_t)128 * 456, s1); scale_block(w + in_b[f], 128, s1);
-            scale_block(w + mid_w[f], (size_t)128 * 128, s2 / s1); scale_block(w + mid_b[f], 128, s2);
-            scale_block(w + out_w[f], (size_t)128 * 128, 1.f / s2);
-            changed += (s1 != 1.f) + (s2 != 1.f);
-        }
-        float sf = pow2_rebalance(row_norm_median(w + L.ed_in_w, 512, 128, 128, w + L.ed_in_b, 1.f));      // edge FFN hidden
-        sf = std::max(sf, pow2_at_least(max_abs(w + L.ed_out_w, (size_t)128 * 512) / 32768.f));
-        scale_block(w + L.ed_in_w, (size_t)512 * 128, sf); scale_block(w + L.ed_in_b, 512, sf);
-        scale_block(w + L.ed_out_w, (size_t)128 * 512, 1.f / sf);
-        changed += sf != 1.f;
-    }
-    return changed;
-}
+#include "pp_rebalance.h"      // rebalance_relu_chains(): power-of-two rebalancing of the ReLU chains (host-only header)
 #endif
 
 template <typename T>
@@ -610,7 +510,8 @@ extern "C" pp_status pp_rebalance_weights_host(const float *weights, size_t n_we
 // sample_cfg.annealed_temp (TorsionalDiffusion.py:70-75 -> SO2VESchedule(annealed_temp=...), schedule.py:205-208)
 extern "C" pp_status pp_plan_set_annealed_temp(pp_plan *p, float T) {
     if (!p) FAIL(PP_ERR_INVALID, "pp_plan_set_annealed_temp: null plan");
-    if (!(T > 0.f) || !std::isfinite(T)) FAIL(PP_ERR_INVALID, "pp_plan_set_annealed_temp: annealed_temp must be a positive number");
+    // schedule.py:216-217 tests `if self.annealed_temp`: 0 (and None, which the host side maps to 0) switch the annealing off
+    if (!std::isfinite(T)) FAIL(PP_ERR_INVALID, "pp_plan_set_annealed_temp: annealed_temp must be finite (0 = no annealing)");
     p->annealed_temp = T;
     return PP_OK;
 }
@@ -840,7 +741,7 @@ static void fill_step(StepParams *sp, float t, float dt, float T) {
     float g = sigma * (float)sqrt(2.0 * log(PI_D / (0.01 * PI_D)));
     float ratio = sigma / (float)exp(hi);
     float alpha = 1.0f - ratio * ratio;
-    sp->w = T / (alpha + (1.0f - alpha) * T);
+    sp->w = T != 0.f ? T / (alpha + (1.0f - alpha) * T) : 1.0f;      // schedule.py:216-217: a falsy annealed_temp means weight 1
     sp->c_ode = (0.5f * (g * g)) * dt;
     sp->c_drift = (g * g) * dt;
     sp->c_diff = g * sqrtf(dt);
@@ -1050,7 +951,8 @@ extern "C" pp_status pp_debug_score_prefix(pp_ctx *c, const float *chi, float t,
 // dispatch's own begin and end timestamps);
 // pp_profile_read synchronises, sums the pair intervals, reports (total ms, launches) and switches profiling off.
 extern "C" pp_status pp_profile_kernel(pp_ctx *c, int which) {
-    if (!c || which < 0 || which > 2) FAIL(PP_ERR_INVALID, "pp_profile_kernel: which must be 0 (node message), 1 (edge update) or 2 (node update)");
+    if (!c || which < 0 || which > 4)
+        FAIL(PP_ERR_INVALID, "pp_profile_kernel: which must be 0 (node message), 1 (edge update), 2 (node update), 3 (clash, inside pp_proximal) or 4 (Adam step + atom14, inside pp_proximal)");
     c->prof_which = which;
     c->prof_n = 0;
     return PP_OK;

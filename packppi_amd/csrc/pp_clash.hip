@@ -503,10 +503,10 @@ pp_status pp_launch_atom14(pp_ctx *c, const float *chi, float *xyz, hipStream_t 
 
 pp_status pp_launch_clash(pp_ctx *c, const float *xyz, float *per_res, float *dchi, hipStream_t s) {
     const pp_plan *p = c->plan;
-    hipLaunchKernelGGL(k_clash, dim3(c->N), dim3(64 * CL_WAVES), 0, s, c->N, c->seg, xyz,
-                       reinterpret_cast<const float4 *>(c->rec), c->b.atom_mask,
-                       p->bounds_lower, p->bounds_upper, p->atom14_to_group, c->axes, p->clash_tol,
-                       1.0f / (float)c->N, per_res, dchi);
+    PP_LAUNCH(c, k_clash, dim3(c->N), dim3(64 * CL_WAVES), 0, s, c->N, c->seg, xyz,
+              reinterpret_cast<const float4 *>(c->rec), c->b.atom_mask,
+              p->bounds_lower, p->bounds_upper, p->atom14_to_group, c->axes, p->clash_tol,
+              1.0f / (float)c->N, per_res, dchi);
     PP_HIP_CHECK(hipGetLastError());
     return PP_OK;
 }
@@ -537,13 +537,20 @@ pp_status pp_launch_proximal(pp_ctx *c, const float *chi, float lamda, int nstep
         U.t = t % PP_PROX_CHUNK;
         float *traj_t = traj ? traj + (size_t)(t - U.t) * c->N * 4 : nullptr;     // U.t indexes within the chunk
         U.traj = traj_t;
-        hipLaunchKernelGGL(k_atom14<true>, dim3(nblocks), dim3(256), 0, s, c->N, c->b.X, c->b.residue_type, c->b.BB_D, c->pxeff,
-                           p->default_frames, p->atom14_to_group, p->atom14_mask, p->lit_positions, c->b.atom_mask,
-                           p->between_radius, c->b.residue_index, c->xyz, c->axes, c->brad, rec, U);
+        c->prof_armed = c->prof_which == 4;          // pp_profile_kernel(4): the fused Adam step + reconstruction
+        PP_LAUNCH(c, k_atom14<true>, dim3(nblocks), dim3(256), 0, s, c->N, c->b.X, c->b.residue_type, c->b.BB_D, c->pxeff,
+                  p->default_frames, p->atom14_to_group, p->atom14_mask, p->lit_positions, c->b.atom_mask,
+                  p->between_radius, c->b.residue_index, c->xyz, c->axes, c->brad, rec, U);
+        c->prof_armed = false;
         const bool chunk_end = U.t == PP_PROX_CHUNK - 1 || t == nsteps - 1;
         if (chunk_end)
             hipLaunchKernelGGL(k_prox_losses, dim3(1), dim3(64), 0, s, U.t + 1, nblocks, U.inv_n, c->prox_part, losses + (t - U.t));
-        if (t + 1 < nsteps && (st = pp_launch_clash(c, c->xyz, c->per_res, c->dchi, s)) != PP_OK) return st;
+        if (t + 1 < nsteps) {
+            c->prof_armed = c->prof_which == 3;      // pp_profile_kernel(3): the clash loss + gradient of the Adam loop
+            st = pp_launch_clash(c, c->xyz, c->per_res, c->dchi, s);
+            c->prof_armed = false;
+            if (st != PP_OK) return st;
+        }
     }
     PP_HIP_CHECK(hipGetLastError());
     return PP_OK;

@@ -41,25 +41,7 @@
 #define PP_NPTS 8         // invariant points per node
 #define PP_PROX_CHUNK 64   // proximal steps whose loss terms are parked before one reduction
 
-// ---------------------------------------------------------------------------------------------
-// Offsets (in floats) into the concatenated weight buffer, order of weights.py::weight_spec().
-// ---------------------------------------------------------------------------------------------
-struct LayerOff {
-    size_t pts_node_w, pts_node_b, pts_edge_w, pts_edge_b;
-    size_t nm_in_w, nm_in_b, nm_mid_w, nm_mid_b, nm_out_w, nm_out_b;   // node_message_fn
-    size_t em_in_w, em_in_b, em_mid_w, em_mid_b, em_out_w, em_out_b;   // edge_message_fn
-    size_t norm_g[4], norm_b[4];
-    size_t nd_in_w, nd_in_b, nd_out_w, nd_out_b;                       // node_dense
-    size_t ed_in_w, ed_in_b, ed_out_w, ed_out_b;                       // edge_dense
-};
-struct WeightOff {
-    size_t node_emb_w, node_emb_b, norm_nodes_g, norm_nodes_b;
-    size_t edge_emb_w, edge_emb_b, norm_edges_g, norm_edges_b;
-    LayerOff layer[3];
-    size_t d0_in_w, d0_in_b, d0_out_w, d0_out_b, d2_in_w, d2_in_b, d2_out_w, d2_out_b;
-    size_t total;
-};
-WeightOff pp_weight_offsets();
+#include "pp_weights.h"      // LayerOff / WeightOff / pp_weight_offsets(): offsets into the concatenated weight buffer
 
 // Transposed ([in][out]) copies used by the node-level (VALU) kernels, per layer.
 struct LayerT {

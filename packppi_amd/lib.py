@@ -222,10 +222,16 @@ class BatchKey:
 
     @staticmethod
     def _meta(ts):
-        return [None if t is None else (t._version, tuple(t.shape), t.dtype) for t in ts]
+        # tensors made under torch.inference_mode() (Lightning's test / predict loops) track no version counter: reading
+        # `_version` raises.  They get no version in the key -- and never match (below)
+        return [None if t is None else ((None if t.is_inference() else t._version), tuple(t.shape), t.dtype) for t in ts]
 
     def matches(self, batch) -> bool:
         ts = [t if isinstance(t, torch.Tensor) else None for t in (_get(batch, k) for k in self.KEYS)]
+        if any(t is not None and t.is_inference() for t in ts):
+            # an in-place edit of an inference tensor cannot be seen (no version counter, same data_ptr): the context is
+            # rebuilt on every call, as the reference recomputes graph and embedding on every call (encoder.py:198-246)
+            return False
         return all(a is b for a, b in zip(ts, self.tensors)) and self._meta(ts) == self.meta
 
 
@@ -355,7 +361,8 @@ class Context:
         return float(ms.value)
 
     def profile_kernel(self, which: int):
-        """Bracket every later launch of kernel `which` (0 node message, 1 edge update, 2 node update) with HIP events."""
+        """Bracket every later launch of kernel `which` (0 node message, 1 edge update, 2 node update; inside proximal(): 3 clash
+        loss + gradient, 4 Adam step + reconstruction) with HIP events."""
         _check(load().pp_profile_kernel(self.handle, int(which)), "pp_profile_kernel")
 
     def profile_read(self):

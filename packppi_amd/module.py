@@ -96,8 +96,11 @@ class TDiffusionModule:
                                        model_cfg=model_cfg)
         if self.hparams.sample_cfg.mode not in ("ode", "sde"):
             raise NotImplementedError(self.hparams.sample_cfg.mode)
-        if not float(self.hparams.sample_cfg.annealed_temp) > 0:
-            raise RuntimeError(f"sample_cfg.annealed_temp = {self.hparams.sample_cfg.annealed_temp!r}: must be a positive number")
+        # schedule.py:216-217 tests `if self.annealed_temp`: 0 and None (Sampling.yaml `annealed_temp: null`) mean weight 1
+        if not self.hparams.sample_cfg.annealed_temp:
+            self.hparams.sample_cfg.annealed_temp = 0.0
+        if not np.isfinite(float(self.hparams.sample_cfg.annealed_temp)):
+            raise RuntimeError(f"sample_cfg.annealed_temp = {self.hparams.sample_cfg.annealed_temp!r}: must be a finite number, 0 or null")
         self.schedule = torch.linspace(1, 0, 31)              # schedule.py:286-288
         self.device = torch.device("cpu")
         self._plan: Optional[Plan] = None

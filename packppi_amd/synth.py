@@ -139,3 +139,19 @@ def make_complex(n_res: int, seed: int, n_chains: int = 2) -> Dict:
 def c5_lengths(n_complexes: int = 256) -> List[int]:
     """Residue counts of benchmark config C5: L_i ~ U{270..330}, default_rng(256)."""
     return [int(x) for x in np.random.default_rng(256).integers(270, 331, size=n_complexes)]
+
+
+def _make_one(spec):
+    return make_complex(*spec)
+
+
+def make_complexes(specs, workers: int = 1) -> List[Dict]:
+    """``[make_complex(n_res, seed) for n_res, seed in specs]``, on ``workers`` forked processes when that is more than one
+    (0.25 s of numpy per ~300-residue complex: the 256 complexes of config C5 take a minute on one core).  Call it BEFORE the
+    process touches the GPU: a forked child must not inherit an initialised HIP runtime."""
+    specs = [tuple(s) for s in specs]
+    if workers <= 1 or len(specs) < 4:
+        return [make_complex(*s) for s in specs]
+    import multiprocessing as mp
+    with mp.get_context("fork").Pool(min(workers, len(specs))) as pool:
+        return pool.map(_make_one, specs, chunksize=max(1, len(specs) // (4 * workers)))

@@ -171,12 +171,14 @@ def test_get_metric_matches_reference(tmp_path):
         assert abs(float(m[k]) - float(z["metric." + k])) < 2e-5 * max(1.0, abs(float(z["metric." + k]))), (k, float(m[k]))
 
 
-@pytest.mark.parametrize("workload,rows", [("t1124", 2), ("c5", 256)])
+@pytest.mark.parametrize("workload,rows", [(None, 256), ("t1124", 2)])
 def test_bench_two_ranks_as_the_driver_launches_it(workload, rows):
-    """The driver's multi-GPU command line, rehearsed: `python bench.py --gpus 2 ...` started as a FRESH child process (it
-    spawns torch.distributed.run itself before anything touches the GPU), two ranks sharing this box's one GPU over gloo
-    (BENCH_DIST_BACKEND; on a multi-GPU node the backend is "nccl" = RCCL and nothing else differs).  One JSON line, both ranks
-    seen, every metric row gathered, exit code 0."""
+    """The driver's multi-GPU command line, rehearsed: `python bench.py --gpus 2 --steps K --warmup W` -- NO --workload, as the
+    driver starts it -- as a FRESH child process (it spawns torch.distributed.run itself before anything touches the GPU), two
+    ranks sharing this box's one GPU over gloo (BENCH_DIST_BACKEND; on a multi-GPU node the backend is "nccl" = RCCL and nothing
+    else differs).  The default at N > 1 is BASELINE configs[4]: the 256 complexes sharded over the ranks, metric rows gathered
+    inside the timed pass, "strong" scaling, one T1124 replica per rank as `secondary`; `--workload t1124` stays available.  One
+    JSON line whose last key is `summary`, both ranks seen, every metric row gathered, exit code 0."""
     import json
     import subprocess
     import sys
@@ -184,17 +186,24 @@ def test_bench_two_ranks_as_the_driver_launches_it(workload, rows):
     env = dict(os.environ, BENCH_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "PACKPPI_LIB"):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
-                        "--cpu-steps", "0", "--no-secondary", "--workload", workload],
-                       env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"]
+                       + (["--workload", workload, "--no-secondary"] if workload else []),
+                       env=env, cwd=root, capture_output=True, text=True, timeout=1100)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-2500:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["metrics_rows_gathered"] == rows
-    assert out["value"] > 0 and out["scaling"] == ("strong" if workload == "c5" else "weak")
+    assert out["value"] > 0 and out["scaling"] == ("weak" if workload == "t1124" else "strong")
+    assert list(out)[-1] == "summary" and len(json.dumps(out["summary"])) < 1500
     if workload == "t1124":
         assert out["parity"]["max_abs_dchi_vs_reference_rad"] < 1e-4
+    else:
+        assert out["config"]["complexes_total"] == 256
+        assert "configs[4]" in out["config"]["workload"]
+        rep = [e for e in out["secondary"] if e["config"] == "configs[1] replicas"]
+        assert len(rep) == 1 and rep[0]["scaling"] == "weak" and rep[0]["max_abs_dchi_vs_reference_rad"] < 1e-4
+        assert "c4_sharded" in out["summary"]["cfg"] and "c1_replicas" in out["summary"]["cfg"]
 
 
 def test_bench_one_rank_through_rccl():

@@ -525,6 +525,45 @@ def test_context_workspace_reuse(weights):
         assert torch.equal(o, ref[L]), (L, float((o - ref[L]).abs().max()))
 
 
+def test_inference_mode_batch_and_annealing_switched_off(weights):
+    """(a) A batch built under torch.inference_mode() -- how Lightning's test / predict loops drive the reference module -- goes
+    through sampling, atom14 and the proximal stage (lib.BatchKey read `_version`, which such tensors do not have: advisor, round 4);
+    (b) sample_cfg.annealed_temp 0 / None mean weight 1 (schedule.py:216-217), held to the oracle."""
+    from oracle import ref_cpu as O
+    from packppi_amd import synth
+    from packppi_amd.featurize import protein_to_batch
+    from packppi_amd.functional import proximal_optimizer
+    from packppi_amd.module import TDiffusionModule
+    p = synth.make_complex(56, 31)
+    cpu = protein_to_batch(p)
+    g = torch.Generator().manual_seed(9)
+    init = (torch.rand(1, 56, 4, generator=g) * 2 - 1) * 3.0 * cpu.SC_D_mask
+    sched = torch.linspace(1, 0, 9)
+    m = TDiffusionModule(weights, device=DEV)
+    m.schedule = sched
+    plain = m.sample_from(cpu.to(DEV), init.to(DEV))
+    with torch.inference_mode():
+        b = protein_to_batch(p).to(DEV)
+        assert b.X.is_inference()
+        got = m.sample_from(b, init.to(DEV))
+        again = m.sample_from(b, init.to(DEV))                # a second call on the same inference batch: rebuilt, same bits
+        xyz = m.get_atom14_coords(b, got)
+        chis, losses = proximal_optimizer(b, got, 12.0, 0.5, 1.0, 3)
+    assert torch.equal(got, plain) and torch.equal(again, plain) and torch.isfinite(xyz).all() and len(losses) == 3
+    for off in (0, None):
+        mo = TDiffusionModule(weights, sample_cfg={"annealed_temp": off}, device=DEV)
+        mo.schedule = sched
+        out = mo.sample_from(cpu.to(DEV), init.to(DEV)).cpu()
+        old = O.ANNEALED_TEMP
+        try:
+            O.ANNEALED_TEMP = 0
+            ref = O.sampling(weights, cpu, init, sched)
+        finally:
+            O.ANNEALED_TEMP = old
+        assert wrapped_absdiff(out, ref)[cpu.SC_D_mask.bool()].max() < 1e-4
+        assert wrapped_absdiff(out, plain.cpu())[cpu.SC_D_mask.bool()].max() > 1e-3        # and it is not the annealed result
+
+
 def test_in_place_edit_of_the_batch_rebuilds_the_context(weights):
     """The module caches the context of the last batch (graph, frames, edge embedding).  The reference recomputes all of it
     on every call (encoder.py:198-246), so an IN-PLACE edit of the batch between two calls must be seen: the cache is keyed on

@@ -172,8 +172,8 @@ def test_hot_path_configs_are_read_and_checked(tmp_path, weights):
     config.check_compiled_dims({"num_positional_embeddings": 99}, {"dropout": 0.5, "k_neighbors": 7})       # not read by the path
     with pytest.raises(RuntimeError, match="does not exist"):
         config.load_hot_path_configs(tmp_path / "nowhere")
-    with pytest.raises(RuntimeError, match="annealed_temp"):
-        TDiffusionModule(weights, sample_cfg={"annealed_temp": 0}, device="cuda")
+    with pytest.raises(RuntimeError, match="annealed_temp"):         # not a number at all; 0 and null are the reference's "no annealing"
+        TDiffusionModule(weights, sample_cfg={"annealed_temp": float("nan")}, device="cuda")
     ref = "/root/reference/configs"
     if os.path.isdir(ref):                                           # the reference's own tree (absent on the GPU box)
         r = config.load_hot_path_configs(ref)
@@ -386,3 +386,64 @@ def test_interface_mask_matches_reference(tmp_path):
     hit = ((d <= 10.0) & (chain_of[:, None] != chain_of[None])).any(1)
     want = {c: sorted(set(prot["residue_index"][owner[hit & (chain_of == c)]].tolist())) for c in np.unique(prot["chain_id"])}
     assert interface_residues(str(pdb)) == want
+
+
+def test_batch_key_accepts_inference_tensors():
+    """Lightning's test / predict loops build their batches under torch.inference_mode(): such tensors have no version counter
+    (reading ``_version`` raises).  lib.BatchKey must take them, and -- since an in-place edit of one cannot be seen -- must never
+    report a match, so that the context is rebuilt per call (advisor, round 4)."""
+    from packppi_amd import synth
+    from packppi_amd.featurize import protein_to_batch
+    from packppi_amd.lib import BatchKey
+    p = synth.make_complex(40, 3)
+    with torch.inference_mode():
+        b = protein_to_batch(p)
+        assert b.X.is_inference()
+        key = BatchKey(b)                       # used to raise "Inference tensors do not track version counter"
+        assert not key.matches(b)
+    b2 = protein_to_batch(p)
+    k2 = BatchKey(b2)
+    assert k2.matches(b2)
+    b2.X[0, 3] += 1.0
+    assert not k2.matches(b2)
+
+
+def test_oracle_annealed_temp_falsy_means_weight_one():
+    """schedule.py:216-217: ``annealed_temp`` 0 / None switch the annealed weight off (w = 1)."""
+    from oracle import ref_cpu as O
+    x = torch.zeros(1, 3, 4)
+    sc = torch.ones(1, 3, 4)
+    mask = torch.ones(1, 3, 4, dtype=torch.bool)
+    old = O.ANNEALED_TEMP
+    try:
+        O.ANNEALED_TEMP = 0
+        a = O.reverse_step(x, sc, torch.tensor(0.5), torch.tensor(0.1), mask)
+    finally:
+        O.ANNEALED_TEMP = old
+    if True:
+        sigma = np.exp(np.log(O.SIGMA_MIN) + (np.log(O.SIGMA_MAX) - np.log(O.SIGMA_MIN)) * 0.5)
+        g = sigma * np.sqrt(2 * np.log(O.SIGMA_MAX / O.SIGMA_MIN))
+        assert torch.allclose(a, torch.full_like(a, float(0.5 * g ** 2 * 0.1)), rtol=1e-6)
+
+
+def test_bench_summary_is_small_and_last():
+    """bench.py's `summary` digest: flat, under 1.5 KB even with every secondary entry and regime present."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    prox = {"k_clash": {"kernel_us": 14.61234, "frac": 0.0123456, "culled_fraction_of_residue_pairs": 0.98765},
+            "k_atom14<true>": {"kernel_us": 10.21234, "frac": 0.0081234}}
+    out = {"value": 60967.123456, "ms_per_step": 12.105123, "scaling": "weak", "n_gpus": 1,
+           "config": {"workload": "data/T1124_lig.pdb"}, "parity": {"max_abs_dchi_vs_reference_rad": 4.812345e-6},
+           "secondary": [{"config": c, "value": 53812.123, "ms_per_step": 13.7123, "max_abs_dchi_vs_reference_rad": 4.8e-6,
+                          "proximal": {"end_state_vs_reference_fp32_rad": 3.4e-3} if "prox" in c or c in ("configs[2]", "configs[3]") else False}
+                         for c in ("configs[2]", "S1500", "configs[3]", "configs[4] share", "configs[4] whole, one GPU",
+                                   "configs[1], exact-fp32 library")],
+           "roofline": {"regimes": {k: {"frac": 0.151234, "mfma_busy": 0.391234, "l2_over_algorithmic": 22.8123} for k in ("t1124", "s1500", "c5")},
+                        "proximal": {"T1124": prox, "S1500": prox}},
+           "cpu_baseline": {"value": 24.991234, "cores": 16, "kind": "port"}}
+    s = bench.make_summary(out)
+    assert len(json.dumps(s)) < 1500, len(json.dumps(s))
+    assert s["cfg"]["c1_t1124"][0] == 60970.0 and "c4_whole_1gpu" in s["cfg"] and set(s["roof"]) == {"t1124", "s1500", "c5"}
