@@ -171,89 +171,6 @@ static void put_chunk_rot(std::vector<float> &arena, const float *W, int ld, int
     put_chunk(arena, W, ld, row0, col_base + 32 * p, 32);
 }
 #endif
-#ifdef PP_EDGE_F16
-// ---- slot streams of the throughput-regime edge kernels (pp_edge_w.inc: a wave owns residues and all 128 features) ----------
-// A slot = the operand of ONE 16-deep k-step of v_mfma_f32_32x32x16_f16 for 32 weight rows: [hi 1 KB | lo 1 KB], each
-// [lane 64][8 halves], lane = (row & 31, half h) holding W[row0 + row][col(h, i)].  Layers run tile-major (all k-steps of output
-// tile t, then t + 1), so a stream is: for every output tile, the k-steps of its whole input.  Streams are padded to chunks of
-// 4 slots (8 KB), the unit in which a workgroup moves them into its LDS ring.
-template <typename ColMap>
-static void put_slot_w(std::vector<float> &arena, const float *W, int ld, int row0, ColMap colmap) {
-    size_t at = arena.size();
-    arena.resize(at + 512, 0.f);
-    uint16_t *d = reinterpret_cast<uint16_t *>(arena.data() + at);
-    for (int lane = 0; lane < 64; lane++)
-        for (int i = 0; i < 8; i++) {
-            const int row = row0 + (lane & 31), h = lane >> 5;
-            const int col = colmap(h, i);
-            const float w = col >= 0 ? W[(size_t)row * ld + col] : 0.f;
-            const uint16_t hi = f2h(w);
-            d[lane * 8 + i] = hi;
-            d[512 + lane * 8 + i] = f2h(w - h2f(hi));
-        }
-}
-// k-step ks (0..7) of a 128-wide input that arrives as accumulator tiles: feature 32 (ks >> 1) + 8 (2 (ks & 1) + (i >> 2)) + 4 h + (i & 3)
-static void put_kstep_w(std::vector<float> &arena, const float *W, int ld, int row0, int col0, int ks) {
-    put_slot_w(arena, W, ld, row0, [=](int h, int i) { return col0 + 32 * (ks >> 1) + 8 * (2 * (ks & 1) + (i >> 2)) + 4 * h + (i & 3); });
-}
-// geometry k-step S5 (0..4) of a message MLP's first layer (same feature order as put_geo_chunk)
-static void put_geo_kstep_w(std::vector<float> &arena, const float *W, int row0, int S5) {
-    put_slot_w(arena, W, 456, row0, [=](int h, int i) {
-        int f;
-        if (S5 < 4) {
-            const int pt = 4 * h + S5;
-            if (i < 3) f = 3 * pt + i;
-            else if (i == 3) f = 24 + pt;
-            else if (i < 7) f = 32 + 3 * pt + (i - 4);
-            else f = 56 + pt;
-        } else if (i < 4) {
-            f = 64 + 4 * h + i;
-        } else {
-            return -1;
-        }
-        return 384 + f;
-    });
-}
-// first layer of a message MLP: W_B on the 8 k-steps of h_E for the four output tiles (unless `skip_wb`), THEN W_G on the 5 geometry
-// k-steps for the four tiles (the kernel overwrites its h_E operands with the geometry operands in between)
-static void put_first_layer_w(std::vector<float> &arena, const float *win, bool skip_wb) {
-    if (!skip_wb)
-        for (int t = 0; t < 4; t++)
-            for (int ks = 0; ks < 8; ks++) put_kstep_w(arena, win, 456, 32 * t, 128, ks);
-    for (int t = 0; t < 4; t++)
-        for (int S5 = 0; S5 < 5; S5++) put_geo_kstep_w(arena, win, 32 * t, S5);
-}
-static void put_square_w(std::vector<float> &arena, const float *W) {
-    for (int t = 0; t < 4; t++)
-        for (int ks = 0; ks < 8; ks++) put_kstep_w(arena, W, 128, 32 * t, 0, ks);
-}
-// edge update of layer l + node message of layer l + 1 (Ln): first layer, W_mid, W_out, the FFN software-pipelined over its 16 hidden
-// tiles (W1(0), then W1(ht + 1), W2(ht) for every ht), the next message's first layer and W_mid
-static size_t put_edge_stream_w(std::vector<float> &arena, const float *w, const LayerOff &L, const LayerOff *Ln, bool st0) {
-    size_t at = (arena.size() + 3) & ~size_t(3);
-    arena.resize(at);
-    put_first_layer_w(arena, w + L.em_in_w, st0);
-    put_square_w(arena, w + L.em_mid_w);
-    put_square_w(arena, w + L.em_out_w);
-    auto put_w1 = [&](int ht) { for (int ks = 0; ks < 8; ks++) put_kstep_w(arena, w + L.ed_in_w, 128, 32 * ht, 0, ks); };
-    put_w1(0);
-    for (int ht = 0; ht < 16; ht++) {
-        if (ht + 1 < 16) put_w1(ht + 1);
-        for (int t = 0; t < 4; t++)
-            for (int s2 = 0; s2 < 2; s2++)
-                put_slot_w(arena, w + L.ed_out_w, 512, 32 * t,
-                           [=](int h, int i) { return 32 * ht + 8 * (2 * s2 + (i >> 2)) + 4 * h + (i & 3); });
-    }
-    if (Ln) {
-        put_first_layer_w(arena, w + Ln->nm_in_w, false);
-        put_square_w(arena, w + Ln->nm_mid_w);
-    }
-    const size_t chunk = 4 * 512;           // pp_edge_w.inc W_CHUNK_FLOATS: the unit in which a workgroup moves the stream into its LDS ring
-    arena.resize(at + ((arena.size() - at + chunk - 1) / chunk) * chunk, 0.f);
-    return at;
-}
-#endif
-
 // chunk stream of one message MLP: [W_in[:,128:256] x4 unless `skip_wb`,] W_in[:,384:456] x3 (24 cols), W_mid x4
 // [, W_out x4, FFN blocks].  Layer 0 skips the W_B chunks: its W_B h_E0 is precomputed once per complex (k_edge_static).
 static size_t put_stream(std::vector<float> &arena, const float *w, const LayerOff &L, bool edge, bool skip_wb) {
@@ -504,10 +421,7 @@ extern "C" pp_status pp_plan_create(const float *weights, size_t n_weights, cons
         o_l[l][13] = put_node_params(arena, weights, off, l);
     }
     size_t o_static = put_static_stream(arena, weights, off.layer[0]);
-#ifdef PP_EDGE_F16
-    size_t o_em_w[2];
-    for (int l = 0; l < 2; l++) o_em_w[l] = put_edge_stream_w(arena, weights, off.layer[l], &off.layer[l + 1], l == 0);
-#endif
+
 
 #ifdef PP_EDGE_F16
     // edge embedding, RBF block (input columns 65..464 of encoder.edge_embedding.weight): 13 chunks of two 16-deep k-steps,
@@ -539,9 +453,7 @@ extern "C" pp_status pp_plan_create(const float *weights, size_t n_weights, cons
         t.nu_stream = p->wT + o_l[l][12]; t.nu_params = p->wT + o_l[l][13];
     }
     p->static_stream = p->wT + o_static;
-#ifdef PP_EDGE_F16
-    for (int l = 0; l < 2; l++) p->lt[l].em_stream_w = p->wT + o_em_w[l];
-#endif
+
 
 #ifdef PP_EDGE_F16
     p->embed_stream = p->wT + o_embed;

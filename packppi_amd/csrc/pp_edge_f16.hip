@@ -1237,8 +1237,6 @@ static float *g_dbg = nullptr;
 #ifdef PP_DIAG
 extern "C" void pp_debug_set_dbg(float *p) { g_dbg = p; }
 #endif
-#include "pp_edge_w.inc"      // k_edge_update_w: the throughput-regime form (a wave owns residues, one weight pass per CU)
-
 static EdgeArgs edge_args(pp_ctx *c, int layer, bool edge) {
     const pp_plan *p = c->plan;
     const LayerOff &o = p->off.layer[layer];
@@ -1321,8 +1319,6 @@ static bool edge_attrs() {
              set(reinterpret_cast<const void *>(k_edge_update_mix<false, PP_FUSED>), MAX_SMEM);
         ok = ok && set(reinterpret_cast<const void *>(k_node_message_mix<true>), MAX_SMEM) &&
              set(reinterpret_cast<const void *>(k_node_message_mix<false>), MAX_SMEM);
-        ok = ok && set(reinterpret_cast<const void *>(k_edge_update_w<2, true, PP_FUSED>), MAX_SMEM) &&
-             set(reinterpret_cast<const void *>(k_edge_update_w<2, false, PP_FUSED>), MAX_SMEM);
         int dev = 0;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
@@ -1359,26 +1355,6 @@ static bool use_mix(int N) {
     }
     if (g_forced_R >= 1 || !g_mix) return false;
     return N > 2 * g_num_cu && N <= 3 * g_num_cu;
-}
-
-// throughput-regime launch (k_edge_update_w, pp_edge_w.inc): a workgroup of four lone waves carries eight residues through the layer
-// on ONE pass of the weight stream; it needs eight residues per CU to fill the chip once, and pays for itself from about
-// PP_W_MIN_PER_CU residues per CU on (measured: profiles/r05_edge_w_ab.txt).  Below that the feature-split kernels above run.
-#ifndef PP_W_MIN_PER_CU
-#define PP_W_MIN_PER_CU 5
-#endif
-static int g_w = -1;           // -1 automatic, 0 never, 1 always (diagnostic builds: PP_EDGE_W / pp_debug_set_edge_w)
-#ifdef PP_DIAG
-extern "C" void pp_debug_set_edge_w(int mode) { g_w = mode < 0 ? -2 : mode; }
-#endif
-static bool use_w(int N) {
-    if (g_w == -1) {
-        const char *e = PP_GETENV("PP_EDGE_W");
-        g_w = e ? atoi(e) : -2;
-    }
-    if (g_w == 0 || g_forced_R >= 1) return false;
-    if (g_w == 1) return true;
-    return N >= PP_W_MIN_PER_CU * g_num_cu;
 }
 
 // resident workgroups per CU the runtime predicts for the two kernels (measurement aid)
@@ -1434,13 +1410,6 @@ pp_status pp_launch_edge_update(pp_ctx *c, int layer, hipStream_t s) {
     if (layer < 0 || layer > 1) { pp_set_error("pp_launch_edge_update: layer must be 0 or 1"); return PP_ERR_INVALID; }
     EdgeArgs A = edge_args(c, layer, true);
     const int R = pick_R(c->N);
-    if (PP_FUSED && use_w(c->N)) {
-        A.wstream = c->plan->lt[layer].em_stream_w;
-        PP_LAUNCH(c, (layer == 0 ? k_edge_update_w<2, true, PP_FUSED> : k_edge_update_w<2, false, PP_FUSED>), dim3((c->N + 7) / 8), dim3(ET),
-                  WSmem<2>::total_floats * sizeof(float), s, A);
-        PP_HIP_CHECK(hipGetLastError());
-        return PP_OK;
-    }
     if (use_mix(c->N)) {
         // three residues per CU as one two-residue and one one-residue workgroup
         A.n_pairs = (c->N + 2) / 3;

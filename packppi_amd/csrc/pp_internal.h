@@ -27,7 +27,7 @@
      defined(PP_X_CVT_SCALAR) || defined(PP_X_CVT_PK) || defined(PP_X_NU_NOMFMA) || defined(PP_X_NU_NOLOAD) ||                   \
      defined(PP_X_NOSAT) || defined(PP_X_NOMFMA) || defined(PP_X_NOACT) || defined(PP_X_E_NOMFMA) || defined(PP_X_CL_NOSCAN) ||  \
      defined(PP_X_CL_NOPAIR) || defined(PP_WDEPTH) || defined(PP_WDEPTH_R1) || defined(PP_NXB_R1) || defined(PP_WGS2) || defined(PP_WGS) ||               \
-     defined(PP_LDS_PAD) || defined(PP_NO_FUSE_NM) || defined(PP_NU_DEPTH) || defined(PP_X_W_NOBAR) || defined(W_PIN_MASK))
+     defined(PP_LDS_PAD) || defined(PP_NO_FUSE_NM) || defined(PP_NU_DEPTH))
 #error "PP_X_* / tuning switches compile laboratory variants (most give wrong results): add -DPP_LAB and build a TAGGED library (python -m packppi_amd.build --tag NAME -DPP_LAB -DPP_X_...)"
 #endif
 #ifdef PP_DIAG
@@ -51,7 +51,6 @@ struct LayerT {
     const float *nd_in_T;                            // [128][512]
     const float *nd_out_T;                           // [512][128]
     const float *nm_stream, *em_stream;              // MFMA weight chunks packed in consumption order (pp_edge.hip)
-    const float *em_stream_w = nullptr;              // slot stream of the throughput-regime edge kernel (pp_edge_w.inc), layers 0 and 1
     const float *em_params;                          // edge kernel small vectors, one block
     const float *nu_stream;                          // k_node_update: split-f16 weight slots, [wave][slot] (pp_api.hip put_node_stream)
     const float *nu_params;                          // k_node_update: small per-layer vectors, one block (NU_P_* offsets)

@@ -498,59 +498,6 @@ def test_residues_per_workgroup_agree(weights):
         l.pp_debug_set_edge_R(0)          # back to the automatic choice
 
 
-def test_throughput_edge_kernel_agrees(weights):
-    """The throughput-regime edge kernel (pp_edge_w.inc: a wave owns two residues and all 128 features, one weight pass per CU) is
-    the same arithmetic per residue as the feature-split kernels: forced onto small shapes -- a residue count that is no multiple
-    of eight (dead slots, a wave without a live residue), K < 32, a padded batch, a packed batch with a residue masked mid-chain --
-    it must agree with the default launch to fp32 rounding and with the oracle to the tolerance, and be bit-reproducible."""
-    import ctypes as C
-    from oracle import ref_cpu as O
-    from packppi_amd import lib as L, synth
-    from packppi_amd.batch import collate, pack
-    from packppi_amd.featurize import protein_to_batch, protein_to_data
-    from packppi_amd.module import TDiffusionModule
-    l = L.load()
-    if l.pp_edge_variant() != 1:
-        pytest.skip("exact-fp32 edge kernels are built")
-    if not hasattr(l, "pp_debug_set_edge_w"):
-        pytest.skip("forcing the launch shape needs libpackppi_hip.dbg.so (tests/test_hip_layers.py runs this test on it)")
-    l.pp_debug_set_edge_w.argtypes = [C.c_int]
-    l.pp_debug_set_edge_w.restype = None
-    m = TDiffusionModule(weights, device=DEV)
-    sched = torch.linspace(1, 0, 9)
-    masked = protein_to_batch(synth.make_complex(77, 41))
-    masked["residue_mask"][0, 30] = 0.0
-    masked["X"][0, 30] = 0.0
-    cases = {"single 301": protein_to_batch(synth.make_complex(301, 5)),
-             "single 20 (K < 32)": protein_to_batch(synth.make_complex(20, 6)),
-             "single 61": protein_to_batch(synth.make_complex(61, 8)),
-             "padded 40/52/33": collate([protein_to_data(synth.make_complex(n, 90 + n)) for n in (40, 52, 33)]),
-             "packed 77 (one masked) + 45": pack([masked, protein_to_batch(synth.make_complex(45, 43))])}
-    try:
-        for name, b in cases.items():
-            gb = b.to(DEV)
-            B, Lmax = b["SC_D"].shape[:2]
-            g = torch.Generator().manual_seed(7)
-            init = (torch.rand(B, Lmax, 4, generator=g) * 2 - 1) * 3.0 * b["SC_D_mask"]
-            ctx = m._context(gb)
-            l.pp_debug_set_edge_w(0)
-            base = ctx.sample(init.to(DEV), sched).cpu()
-            l.pp_debug_set_edge_w(1)
-            got = ctx.sample(init.to(DEV), sched)
-            assert torch.equal(ctx.sample(init.to(DEV), sched), got), name
-            got = got.cpu()
-            msk = b["SC_D_mask"].bool()
-            assert torch.isfinite(got).all(), name
-            d = float(wrapped_absdiff(got, base)[msk].max())
-            assert d < 2e-5, (name, d)
-            assert m.saturated() == 0
-            if "seg_offsets" not in b and B == 1:
-                ref = O.sampling(weights, b, init, sched)
-                assert float(wrapped_absdiff(got, ref)[msk].max()) < 1e-4, name
-    finally:
-        l.pp_debug_set_edge_w(-1)          # back to the automatic choice
-
-
 def test_context_workspace_reuse(weights):
     """Contexts hand their device workspace back to the plan's pool (no hipMalloc / hipFree on the sampling path): a
     smaller, an equal and a larger complex after a destroyed context must give what a fresh module gives."""
