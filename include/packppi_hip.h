@@ -123,6 +123,17 @@ int pp_plan_rebalanced_chains(const pp_plan *plan);
  * rebalanced network must be the original function (tests/test_host.py runs both through the CPU oracle). */
 pp_status pp_rebalance_weights_host(const float *weights, size_t n_weights, float *out, int *chains);
 
+/* No reference counterpart.  Three LayerNorm outputs become f16 operands of the edge-level dense layers: h_E0 (encoder.norm_edges,
+ * encoder.py:243-244), the h_E a layer writes and x1 (norm[3], norm[2]: layers.py:128-146).  Where a feature's gain and bias are
+ * both far from 1 (a checkpoint that keeps the scale in the consuming weights) the split-f16 build multiplies that operand feature
+ * by a power of two before the split and divides the consuming weight column by it when the plan is created -- exact, and only then
+ * are the kernel instances with that multiply launched (csrc/pp_rebalance.h ln_operand_scales).  Returns how many of the 5 x 128
+ * operand features carry a scale other than 1 (0 for the seeded fixtures; always 0 in libpackppi_hip.f32.so), -1 for a null plan. */
+int pp_plan_ln_scaled_features(const pp_plan *plan);
+/* HOST helper, no device call: `out` [5][128] = the operand scales pp_plan_create would choose for these weights, in the order
+ * h_E0 | h_E after layer 0 | after layer 1 | x1 of layer 0 | of layer 1; `n_scaled` (may be NULL) = how many differ from 1. */
+pp_status pp_ln_operand_scales_host(const float *weights, size_t n_weights, float *out, int *n_scaled);
+
 /* HOST helper, no device call: idx_out[0..k-1] = torch.topk(values[0..n-1], k, largest=False) indices as ATen's CPU kernel
  * returns them -- the same code the neighbour search runs on the device for rows with ties.  Returns PP_OK / PP_ERR_INVALID. */
 pp_status pp_topk_aten_host(const float *values, int n, int k, int32_t *idx_out);

@@ -394,6 +394,22 @@ extern "C" pp_status pp_plan_create(const float *weights, size_t n_weights, cons
         weights = rebalanced.data();       // everything below -- device copy, packed streams, transposed copies -- is made from it
     }
 #endif
+    const float *wpack = weights;          // what the edge-level MFMA streams are packed from
+#ifdef PP_EDGE_F16
+    std::vector<float> ln_packed;
+    p->ln_scale = nullptr;
+    p->ln_scaled_features = 0;
+    if (has_net) {
+        const LnScales sc = ln_operand_scales(weights, off);
+        p->ln_scaled_features = sc.n_scaled;
+        if (sc.n_scaled > 0) {
+            ln_packed.assign(weights, weights + off.total);
+            apply_ln_scales(ln_packed.data(), off, sc);
+            wpack = ln_packed.data();
+            if ((st = upload(&p->ln_scale, &sc.v[0][0], (size_t)5 * 128)) != PP_OK) return st;
+        }
+    }
+#endif
     if (has_net) {
     if ((st = upload(&p->w, weights, off.total)) != PP_OK) return st;
 
@@ -413,14 +429,14 @@ extern "C" pp_status pp_plan_create(const float *weights, size_t n_weights, cons
         o_l[l][6] = put_T4(arena, weights + L.nm_out_w, 128, 128, 0, 128);
         o_l[l][7] = put_T4(arena, weights + L.nd_in_w, 512, 128, 0, 128);
         o_l[l][8] = put_T4(arena, weights + L.nd_out_w, 128, 512, 0, 512);
-        o_l[l][9] = put_stream(arena, weights, L, false, l == 0);
-        o_l[l][10] = put_stream(arena, weights, L, true, l == 0);
-        if (l < 2) put_stream(arena, weights, off.layer[l + 1], false, false);   // fused kernel: next layer's node message follows
+        o_l[l][9] = put_stream(arena, wpack, L, false, l == 0);
+        o_l[l][10] = put_stream(arena, wpack, L, true, l == 0);
+        if (l < 2) put_stream(arena, wpack, off.layer[l + 1], false, false);   // fused kernel: next layer's node message follows
         o_l[l][11] = put_edge_params(arena, weights, L);
         o_l[l][12] = put_node_stream(arena, weights, off, l);
         o_l[l][13] = put_node_params(arena, weights, off, l);
     }
-    size_t o_static = put_static_stream(arena, weights, off.layer[0]);
+    size_t o_static = put_static_stream(arena, wpack, off.layer[0]);
 
 
 #ifdef PP_EDGE_F16
@@ -477,7 +493,7 @@ extern "C" pp_status pp_plan_create(const float *weights, size_t n_weights, cons
 extern "C" void pp_plan_destroy(pp_plan *p) {
     if (!p) return;
     void *ptrs[] = {p->w, p->wT, p->default_frames, p->atom14_to_group, p->atom14_mask, p->lit_positions,
-                    p->between_radius, p->bounds_lower, p->bounds_upper};
+                    p->between_radius, p->bounds_lower, p->bounds_upper, p->ln_scale};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     for (const ArenaSlot &sl : p->arena_pool) {
         (void)hipFree(sl.p);
@@ -494,6 +510,25 @@ extern "C" pp_status pp_plan_set_knn_ties(pp_plan *p, int mode) {
 }
 
 extern "C" int pp_plan_rebalanced_chains(const pp_plan *p) { return p ? p->rebalanced_chains : -1; }
+extern "C" int pp_plan_ln_scaled_features(const pp_plan *p) { return p ? p->ln_scaled_features : -1; }
+// HOST helper, no device call: the five operand-scale vectors pp_plan_create would choose for these weights (after the ReLU-chain
+// rebalancing), [h_E0 | h_E after layer 0 | after layer 1 | x1 of layer 0 | of layer 1] x 128; the exact-fp32 build returns ones
+extern "C" pp_status pp_ln_operand_scales_host(const float *weights, size_t n_weights, float *out, int *n_scaled) {
+    const WeightOff off = pp_weight_offsets();
+    if (!weights || !out || n_weights != off.total) FAIL(PP_ERR_INVALID, "pp_ln_operand_scales_host: bad argument");
+    int n = 0;
+#ifdef PP_EDGE_F16
+    std::vector<float> w(weights, weights + n_weights);
+    rebalance_relu_chains(w.data(), off);
+    const LnScales sc = ln_operand_scales(w.data(), off);
+    std::memcpy(out, &sc.v[0][0], sizeof(sc.v));
+    n = sc.n_scaled;
+#else
+    for (int i = 0; i < 5 * 128; i++) out[i] = 1.f;
+#endif
+    if (n_scaled) *n_scaled = n;
+    return PP_OK;
+}
 
 // HOST helper, no device call: the weight vector as pp_plan_create packs it (split-f16 build: ReLU chains rebalanced by powers of
 // two; exact-fp32 build: a copy).  Lets a CPU test hold the rebalanced network to the original one through the oracle.

@@ -88,6 +88,8 @@ struct pp_plan {
     int knn_ties;             // PP_KNN_TIES_*: what the neighbour search does on exactly equal distances
     float annealed_temp;      // sample_cfg.annealed_temp (the T of schedule.py:205-208), default 3
     int rebalanced_chains;    // split-f16 build: ReLU chains whose layers were rescaled by a power of two (pp_api.hip rebalance_relu_chains)
+    float *ln_scale = nullptr;       // split-f16 build: [5][128] power-of-two operand scales behind small LayerNorm gains (pp_rebalance.h), or null
+    int ln_scaled_features = 0;      // ... how many of them differ from 1
     float *w;                 // device copy of all weights, original layouts
     WeightOff off;
     float *wT;                // device arena of transposed copies

@@ -3,6 +3,11 @@
 #pragma once
 #include <stddef.h>
 
+// the five power-of-two operand-scale vectors behind small LayerNorm gains (pp_rebalance.h ln_operand_scales, plan->ln_scale)
+#define PP_LN_E0 0        /* h_E0 -> layer 0's two W_B blocks (k_edge_static) */
+#define PP_LN_E(l) (1 + (l))      /* h_E after layer l -> layer l + 1's W_B blocks */
+#define PP_LN_X1(l) (3 + (l))     /* x1 of layer l -> its edge FFN's W_in */
+
 // ---------------------------------------------------------------------------------------------
 // Offsets (in floats) into the concatenated weight buffer, order of weights.py::weight_spec().
 // ---------------------------------------------------------------------------------------------

@@ -15,7 +15,7 @@ from .weights import check_state_dict
 _LIB_PATH = os.environ.get("PACKPPI_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libpackppi_hip.so")     # PACKPPI_LIB: A/B runs of build variants
 _lib = None
 
-SYMBOLS = ("pp_version", "pp_last_error", "pp_build_id", "pp_plan_set_knn_ties", "pp_plan_set_annealed_temp", "pp_plan_rebalanced_chains", "pp_rebalance_weights_host", "pp_topk_aten_host", "pp_plan_create", "pp_plan_destroy", "pp_plan_set_clash_params",
+SYMBOLS = ("pp_version", "pp_last_error", "pp_build_id", "pp_plan_set_knn_ties", "pp_plan_set_annealed_temp", "pp_plan_rebalanced_chains", "pp_rebalance_weights_host", "pp_plan_ln_scaled_features", "pp_ln_operand_scales_host", "pp_topk_aten_host", "pp_plan_create", "pp_plan_destroy", "pp_plan_set_clash_params",
            "pp_complex_prepare", "pp_complex_prepare_packed", "pp_ctx_destroy", "pp_ctx_get_graph", "pp_ctx_set_graph", "pp_score", "pp_sample", "pp_atom14",
            "pp_clash", "pp_proximal", "pp_time_kernel", "pp_profile_kernel", "pp_profile_read", "pp_edge_variant", "pp_has_range_check", "pp_range_check", "pp_range_check_parts", "pp_ctx_saturated")
 
@@ -70,6 +70,9 @@ def load():
     lib.pp_plan_rebalanced_chains.argtypes = [vp]
     lib.pp_rebalance_weights_host.argtypes = [vp, C.c_size_t, vp, C.POINTER(C.c_int)]
     lib.pp_plan_rebalanced_chains.restype = C.c_int
+    lib.pp_plan_ln_scaled_features.argtypes = [vp]
+    lib.pp_plan_ln_scaled_features.restype = C.c_int
+    lib.pp_ln_operand_scales_host.argtypes = [vp, C.c_size_t, vp, C.POINTER(C.c_int)]
     lib.pp_topk_aten_host.argtypes = [vp, i, i, vp]
     lib.pp_version.restype = C.c_int
     lib.pp_last_error.restype = C.c_char_p
@@ -114,6 +117,18 @@ def _stream(device):
 
 def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def ln_operand_scales(state_dict):
+    """([5, 128] operand scales pp_plan_create would choose behind the edge-level LayerNorms -- rows: h_E0, h_E after layer 0,
+    after layer 1, x1 of layer 0, of layer 1 --, how many differ from 1): host only, no device call."""
+    lib = load()
+    sd = check_state_dict(state_dict)
+    flat = np.ascontiguousarray(torch.cat([v.reshape(-1) for v in sd.values()]).numpy(), dtype=np.float32)
+    out = np.empty((5, 128), np.float32)
+    n = C.c_int(0)
+    _check(lib.pp_ln_operand_scales_host(flat.ctypes.data, flat.size, out.ctypes.data, C.byref(n)), "pp_ln_operand_scales_host")
+    return torch.from_numpy(out), int(n.value)
 
 
 def rebalanced_state_dict(state_dict):
@@ -174,6 +189,11 @@ class Plan:
     def rebalanced_chains(self) -> int:
         """How many ReLU chains of the edge-level MLPs the split-f16 build rescaled by a power of two at plan creation."""
         return int(load().pp_plan_rebalanced_chains(self.handle))
+
+    def ln_scaled_features(self) -> int:
+        """How many of the 5 x 128 LayerNorm-output operand features of the edge kernels carry a power-of-two scale (split-f16 build;
+        0 for weights whose LayerNorm gains and biases are of ordinary size)."""
+        return int(load().pp_plan_ln_scaled_features(self.handle))
 
     def set_annealed_temp(self, T):
         """sample_cfg.annealed_temp (Sampling.yaml:4): the T of the annealed score weight in SO2VESchedule.step."""

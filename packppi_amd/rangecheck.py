@@ -24,9 +24,29 @@ import sys
 
 # LayerNorms whose OUTPUT is an f16-split operand of the edge kernels (h_E0, x1 = LN2 output, h_E = LN3 output): a gain vector
 # far below 1 makes those operand vectors small, and below 2^-4 the unscaled low part of the split loses resolution (DESIGN.md
-# section 4.1).  ReLU chains are rebalanced when the plan is made; a LayerNorm gain is not (it is not an exact reparametrisation).
+# section 4.1).  ReLU chains are rebalanced when the plan is made, and since round 5 so are these operands: the plan multiplies a
+# small (or huge) operand feature by a power of two before the split and divides the consuming weight column by it
+# (csrc/pp_rebalance.h ln_operand_scales; `ln_scaled_features` in the report).  `small_gain_layernorms` names the LayerNorms
+# concerned; `uncovered_small_operands` lists what the scales could NOT bring within [2^-4, 2^4] (a consuming column that would
+# leave the f16 range): only that makes the check fail.
 SMALL_GAIN = 1.0 / 16.0
 EDGE_OPERAND_NORMS = ["encoder.norm_edges.weight"] + [f"mpnn.mpnn_layers.{l}.norm.{k}.weight" for l in range(3) for k in (2, 3)]
+SCALE_ROWS = {"encoder.norm_edges": 0, "mpnn.mpnn_layers.0.norm.3": 1, "mpnn.mpnn_layers.1.norm.3": 2,
+              "mpnn.mpnn_layers.0.norm.2": 3, "mpnn.mpnn_layers.1.norm.2": 4}
+
+
+def uncovered_small_operands(state_dict):
+    """[(LayerNorm, features still below 2^-4 after the plan's operand scales)] -- host only (lib.ln_operand_scales)."""
+    import torch
+    from .lib import ln_operand_scales
+    sc, _ = ln_operand_scales(state_dict)
+    out = []
+    for site, row in SCALE_ROWS.items():
+        mag = torch.sqrt(torch.as_tensor(state_dict[site + ".weight"]).float() ** 2 + torch.as_tensor(state_dict[site + ".bias"]).float() ** 2) * sc[row]
+        bad = int(((mag > 0) & (mag < SMALL_GAIN)).sum())
+        if bad:
+            out.append((site, bad))
+    return out
 
 
 def small_gain_layernorms(state_dict):
@@ -91,6 +111,8 @@ def _run(args):
     report["sticky_flag"] = model._ctx.saturated() if model._ctx is not None else 0
     report["rebalanced_relu_chains"] = model._plan.rebalanced_chains()
     report["small_gain_layernorms"] = small_gain_layernorms(model.state_dict())
+    report["ln_scaled_features"] = model._plan.ln_scaled_features()
+    report["uncovered_small_operands"] = uncovered_small_operands(model.state_dict())
     print("RANGECHECK " + json.dumps(report))
     return report
 
@@ -128,7 +150,12 @@ def main(argv=None):
         print(f"{k:24s} {v}")
     if rep.get("small_gain_layernorms"):
         print("NOTE: LayerNorm gains with a median below 2^-4 in front of split-f16 operands: " + ", ".join(f"{n} ({m:.3g})" for n, m in rep["small_gain_layernorms"])
-              + " -- the operand resolution of the default library drops below fp32 level there: prefer libpackppi_hip.f32.so")
+              + f" -- the plan carries power-of-two operand scales for {rep.get('ln_scaled_features', 0)} features (exact; csrc/pp_rebalance.h)")
+    uncovered = rep.get("uncovered_small_operands") or []
+    if uncovered:
+        print("f16 operand RESOLUTION not covered: " + ", ".join(f"{n}: {k} features" for n, k in uncovered) + " stay below 2^-4 after the "
+              "operand scales (a consuming weight column would leave the f16 range): run this checkpoint with PACKPPI_LIB=.../libpackppi_hip.f32.so")
+        return 3
     if rep["total"] == 0:
         print("f16 operand range: OK")
     else:

@@ -223,6 +223,33 @@ def test_rebalanced_relu_chains_are_the_same_network(weights):
     assert 0.25 <= float(reb[k].abs().max() / weights[k].abs().max()) <= 4.0
 
 
+def test_layernorm_operand_scales(weights):
+    """The power-of-two operand scales behind small LayerNorm gains (csrc/pp_rebalance.h ln_operand_scales): ones for the seeded
+    weights (they keep their bits and their kernels); for gains / biases of 1e-3 .. 1e-2 every scaled operand feature lands within
+    [1/16, 16] of unit size, the scale is an exact power of two and the consuming weight column divided by it stays in range."""
+    from packppi_amd import lib as L
+    from tools.oracle.envelope_weights import small_ln_gain_variants
+    if L.load().pp_edge_variant() != 1:
+        pytest.skip("exact-fp32 edge kernels are built: no operand scales")
+    s0, n0 = L.ln_operand_scales(weights)
+    assert n0 == 0 and bool((s0 == 1).all())
+    sites = ["encoder.norm_edges", "mpnn.mpnn_layers.0.norm.3", "mpnn.mpnn_layers.1.norm.3", "mpnn.mpnn_layers.0.norm.2", "mpnn.mpnn_layers.1.norm.2"]
+    for name, sd in small_ln_gain_variants(weights).items():
+        sc, n = L.ln_operand_scales(sd)
+        assert n > (500 if "bias too" in name else 100), (name, n)       # ("bias kept": most features are bias-sized, i.e. already O(1))
+        assert bool((torch.log2(sc) == torch.log2(sc).round()).all())                       # exact powers of two
+        for row, site in enumerate(sites):
+            mag = torch.sqrt(sd[site + ".weight"] ** 2 + sd[site + ".bias"] ** 2) * sc[row]
+            assert float(mag.min()) > 1 / 16 and float(mag.max()) < 16, (name, site, float(mag.min()), float(mag.max()))
+        w = sd["mpnn.mpnn_layers.1.edge_dense.W_in.weight"] / sc[4][None, :]
+        assert float(w.abs().max()) < 32768
+    # one LayerNorm with a HUGE gain is scaled the other way
+    big = dict(weights)
+    big["mpnn.mpnn_layers.0.norm.2.weight"] = weights["mpnn.mpnn_layers.0.norm.2.weight"] * 300.0
+    sc, n = L.ln_operand_scales(big)
+    assert n == 128 and float(sc[3].max()) < 1.0 and bool((sc[[0, 1, 2, 4]] == 1).all())
+
+
 def test_rangecheck_names_small_layernorm_gains(weights):
     """What the plan-time rebalancing does not cover (a LayerNorm gain is not an exact reparametrisation): gains with a median
     below 2^-4 in front of edge-kernel operands are named by the range-check tool."""

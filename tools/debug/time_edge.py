@@ -1,6 +1,6 @@
-"""GPU box: in-situ time of the edge-update launches for the throughput workloads (S1500, the configs[4] share), with the
-throughput-regime kernel (pp_edge_w.inc) forced on and off when the loaded library is the diagnostic one.
-    python tools/debug/time_edge.py [s1500] [c5] [steps]"""
+"""GPU box: in-situ time of the edge-update launches (T1124, S1500, the configs[4] share), with the duo launch (k_edge_update_duo)
+forced off and on when the loaded library is the diagnostic one (PACKPPI_LIB=.../libpackppi_hip.dbg.so).
+    python tools/debug/time_edge.py [t1124] [s1500] [c5] [steps]"""
 import ctypes as C
 import os
 import sys
@@ -17,7 +17,7 @@ from packppi_amd.weights import make_random_state_dict  # noqa: E402
 
 dev = torch.device("cuda", 0)
 l = lib.load()
-force = getattr(l, "pp_debug_set_edge_w", None)      # only libraries built from the experiment commit export it
+force = getattr(l, "pp_debug_set_edge_duo", None)
 if force is not None:
     force.argtypes = [C.c_int]
     force.restype = None
@@ -50,6 +50,6 @@ for wl in wls:
         ctx.sample(x0, sched)
         torch.cuda.synchronize()
         dt = time.time() - t0
-        print(f"{wl:6s} edge_w={mode}  edge launch {ms * 1e3:8.1f} us x {n}   pass {dt / steps * 1e3:7.3f} ms/eval   finite {bool(torch.isfinite(out).all())}", flush=True)
+        print(f"{wl:6s} duo={mode}  edge launch {ms * 1e3:8.1f} us x {n}   pass {dt / steps * 1e3:7.3f} ms/eval   finite {bool(torch.isfinite(out).all())}", flush=True)
 if force is not None:
     force(-1)

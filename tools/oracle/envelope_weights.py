@@ -63,3 +63,38 @@ def tiny_operand_variants(sd0):
         v[b + ".weight"] = sd0[b + ".weight"] * 1024.0
         out[name] = v
     return out
+
+
+def small_ln_gain_variants(sd0):
+    """Edge-level LayerNorms whose GAIN is tiny, with the scale put back into the weights that consume their output: the operand
+    vectors h_E (encoder.norm_edges, norm.3 of a layer -> the W_B columns 128:256 of the next layer's two message MLPs) and x1
+    (norm.2 -> the edge FFN's W_in) then sit at 1e-3 .. 1e-2 -- below 2^-4, where the edge kernels' unscaled f16 low part is
+    subnormal -- while the dense products stay O(1).  (The residual paths see the small tensors as they are: another network than
+    the seeded one, a valid one; the reference's fp32 / fp64 runs are the truth.)  "bias too": the LayerNorm biases shrink with the
+    gains; "bias kept": they keep their size, so an operand feature is bias-dominated."""
+    out = {}
+    for name, shrink_bias in (("bias too", True), ("bias kept", False)):
+        g = torch.Generator().manual_seed(3)
+        v = dict(sd0)
+        # a per-feature LayerNorm bias as well (the seeded draw has zeros): without one "bias kept" would be the same variant
+        def gains():
+            import math as _m
+            return torch.exp(_m.log(1e-3) + torch.rand(128, generator=g) * (_m.log(1e-2) - _m.log(1e-3)))
+
+        def apply(norm, consumers):
+            gf = gains()
+            b0 = (torch.rand(128, generator=g) * 2 - 1) * 0.5
+            v[norm + ".weight"] = sd0[norm + ".weight"] * gf
+            v[norm + ".bias"] = (sd0[norm + ".bias"] + b0) * (gf if shrink_bias else 1.0)
+            for key, c0 in consumers:
+                w = v[key].clone()
+                w[:, c0:c0 + 128] = w[:, c0:c0 + 128] / gf
+                v[key] = w
+        apply("encoder.norm_edges", [("mpnn.mpnn_layers.0.node_message_fn.W_in.weight", 128),
+                                     ("mpnn.mpnn_layers.0.edge_message_fn.W_in.weight", 128)])
+        for l in (0, 1):
+            apply(f"mpnn.mpnn_layers.{l}.norm.3", [(f"mpnn.mpnn_layers.{l + 1}.node_message_fn.W_in.weight", 128)]
+                  + ([(f"mpnn.mpnn_layers.{l + 1}.edge_message_fn.W_in.weight", 128)] if l + 1 < 2 else []))
+            apply(f"mpnn.mpnn_layers.{l}.norm.2", [(f"mpnn.mpnn_layers.{l}.edge_dense.W_in.weight", 0)])
+        out["small LN gains, " + name] = v
+    return out

@@ -21,7 +21,7 @@ sys.path.insert(0, HERE)
 sys.path.insert(0, ROOT)
 
 import refshim  # noqa: E402
-from envelope_weights import envelope_variants, tiny_operand_variants  # noqa: E402
+from envelope_weights import envelope_variants, small_ln_gain_variants, tiny_operand_variants  # noqa: E402
 from make_golden_prox import load_fixture, ref_batch, wrapped  # noqa: E402
 from packppi_amd.weights import make_random_state_dict  # noqa: E402
 
@@ -39,6 +39,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--threads", type=int, default=8)
     ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--append", action="store_true", help="keep the variants the fixture already holds, run only the missing ones")
     args = ap.parse_args()
     torch.set_num_threads(args.threads)
     z, b = load_fixture("g4_T1124")
@@ -47,8 +48,19 @@ def main():
     out = {"variants": [], "steps": np.int64(args.steps)}
     variants = dict(envelope_variants(sd0))
     variants.update({"tiny operands: " + k: v for k, v in tiny_operand_variants(sd0).items()})
+    variants.update(small_ln_gain_variants(sd0))
+    path = os.path.join(GOLD, "g10_envelope_T1124.npz")
+    old = dict(np.load(path)) if args.append and os.path.exists(path) else {}
+    if old:
+        assert int(old["steps"]) == args.steps
     for name, sd in variants.items():
         key = name.replace(" ", "_").replace(",", "").replace("/", "_").replace(":", "").replace("+-", "pm")
+        if "chi64." + key in old:
+            out["variants"].append(name)
+            for pre in ("chi32.", "chi64.", "cond."):
+                out[pre + key] = old[pre + key]
+            print(f"{name}: kept (|ref32 - ref64| = {float(old['cond.' + key]):.2e} rad)", flush=True)
+            continue
         res = {}
         for prec, dt in (("32", torch.float32), ("64", torch.float64)):
             model = refshim.build_reference_module(0)
@@ -65,7 +77,6 @@ def main():
         out["chi64." + key] = res["64"].numpy()
         out["cond." + key] = np.float64(cond)
     out["variants"] = np.array(out["variants"])
-    path = os.path.join(GOLD, "g10_envelope_T1124.npz")
     np.savez_compressed(path, **out)
     print(f"wrote {path} {os.path.getsize(path) / 1e6:.2f} MB")
 
