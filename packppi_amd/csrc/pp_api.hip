@@ -380,34 +380,24 @@ extern "C" pp_status pp_plan_create(const float *weights, size_t n_weights, cons
     p->annealed_temp = 3.0f;      // configs/model/sample_cfg/Sampling.yaml:4
     p->rebalanced_chains = 0;
     pp_status st;
+    const float *wpack = weights;          // what the edge-level MFMA streams are packed from
 #ifdef PP_EDGE_F16
-    std::vector<float> rebalanced;
+    std::vector<float> rebalanced, ln_packed;
+    p->ln_scale = nullptr;
+    p->ln_scaled_features = 0;
     if (has_net) {
-        rebalanced.assign(weights, weights + off.total);
-        p->rebalanced_chains = rebalance_relu_chains(rebalanced.data(), off);
+        LnScales sc;
+        p->rebalanced_chains = rewrite_checkpoint(weights, off, rebalanced, ln_packed, sc);
+        p->ln_scaled_features = sc.n_scaled;
         for (size_t i = 0; i < off.total; i++)
-            if (!(std::fabs(rebalanced[i]) < 65504.f)) {
+            if (!(std::fabs(rebalanced[i]) < 65504.f) || !(std::fabs(ln_packed[i]) < 65504.f)) {
                 delete p;
                 FAIL(PP_ERR_INVALID, "pp_plan_create: weight " + std::to_string(i) + " leaves the f16 range when its ReLU chain is "
                                      "rebalanced (run this checkpoint on libpackppi_hip.f32.so)");
             }
-        weights = rebalanced.data();       // everything below -- device copy, packed streams, transposed copies -- is made from it
-    }
-#endif
-    const float *wpack = weights;          // what the edge-level MFMA streams are packed from
-#ifdef PP_EDGE_F16
-    std::vector<float> ln_packed;
-    p->ln_scale = nullptr;
-    p->ln_scaled_features = 0;
-    if (has_net) {
-        const LnScales sc = ln_operand_scales(weights, off);
-        p->ln_scaled_features = sc.n_scaled;
-        if (sc.n_scaled > 0) {
-            ln_packed.assign(weights, weights + off.total);
-            apply_ln_scales(ln_packed.data(), off, sc);
-            wpack = ln_packed.data();
-            if ((st = upload(&p->ln_scale, &sc.v[0][0], (size_t)5 * 128)) != PP_OK) return st;
-        }
+        weights = rebalanced.data();       // everything below -- device copy, node-level streams, transposed copies -- is made from it
+        wpack = ln_packed.data();          // ... and the edge-level streams from the copy with the operand scales in its columns
+        if (sc.n_scaled > 0 && (st = upload(&p->ln_scale, &sc.v[0][0], (size_t)5 * 128)) != PP_OK) return st;
     }
 #endif
     if (has_net) {
@@ -518,9 +508,7 @@ extern "C" pp_status pp_ln_operand_scales_host(const float *weights, size_t n_we
     if (!weights || !out || n_weights != off.total) FAIL(PP_ERR_INVALID, "pp_ln_operand_scales_host: bad argument");
     int n = 0;
 #ifdef PP_EDGE_F16
-    std::vector<float> w(weights, weights + n_weights);
-    rebalance_relu_chains(w.data(), off);
-    const LnScales sc = ln_operand_scales(w.data(), off);
+    const LnScales sc = ln_operand_scales(weights, off);
     std::memcpy(out, &sc.v[0][0], sizeof(sc.v));
     n = sc.n_scaled;
 #else
@@ -538,7 +526,12 @@ extern "C" pp_status pp_rebalance_weights_host(const float *weights, size_t n_we
     memcpy(out, weights, n_weights * sizeof(float));
     int c = 0;
 #ifdef PP_EDGE_F16
-    c = rebalance_relu_chains(out, off);
+    {
+        std::vector<float> plain, packed;
+        LnScales sc;
+        c = rewrite_checkpoint(weights, off, plain, packed, sc);      // (`plain`: the rebalanced network with the operand scales multiplied back)
+        memcpy(out, plain.data(), n_weights * sizeof(float));
+    }
 #endif
     if (chains) *chains = c;
     return PP_OK;

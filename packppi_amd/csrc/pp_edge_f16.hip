@@ -145,29 +145,6 @@ struct EdgeArgs {
 };
 enum { P_BMID = 0, P_BOUT = 128, P_FOB = 256, P_G2 = 384, P_BE2 = 512, P_FIB = 640 };
 
-// ---- barriers of a four-wave TEAM ------------------------------------------------------------------------------------------
-// The bodies below synchronise their four waves through `tbar.sync(lane)`.  In the ordinary kernels the team IS the workgroup and
-// that is `__syncthreads()`.  In k_edge_update_duo (round 5) a 512-thread workgroup holds TWO teams that must not meet at each
-// other's barriers (the lockstep of the round-3 / round-4 "duo" and "trio" experiments exposed every exchange of one team to the
-// other): there a team's barrier is a monotonic counter in LDS -- every wave, once its own LDS writes are complete, adds one and
-// polls until the count reaches four times the barrier's number.  ~150 cycles where s_barrier takes ~30; twenty per launch.
-template <bool DUO> struct TeamBar;
-template <> struct TeamBar<false> {
-    __device__ __forceinline__ void sync(int) { __syncthreads(); }
-};
-template <> struct TeamBar<true> {
-    unsigned *cnt;           // this team's counter (LDS, zero when the teams start)
-    unsigned target = 0;
-    __device__ __forceinline__ void sync(int lane) {
-        target += 4;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");           // s_waitcnt lgkmcnt(0): this wave's LDS writes are done
-        if (lane == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        while ((unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < target)
-            __builtin_amdgcn_s_sleep(1);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    }
-};
-
 // ---- weight pipeline: global memory -> registers, private to each wave -------------------------------------------
 // Wave w only ever needs rows 32w..32w+31 of a weight chunk (its output tile), so its quarter of every chunk is packed
 // (pp_plan_create, put_chunk_f16) as [quad q][lane][8 halves] = exactly the A-operand registers of the stage's MFMAs
@@ -544,7 +521,7 @@ __device__ __forceinline__ void geometry_put(const GeoI &g, const float (&pj)[3]
     WSTAGE(k, NCH, ACC, {                                                                                   \
         if constexpr ((P) < 3 && !(FETCH_LATE) && !PP_X_NOBT_) { BT_FETCH(BUF, ROT((P) + 1), ((P) + 1) & 1) }   \
         (mfma_hs<R, SWAP, 0>(AK, bt[(P) & 1], ACC));                                                        \
-        if constexpr (BAR) { ACC_FENCE(ACC) tbar.sync(lane); }                                              \
+        if constexpr (BAR) { ACC_FENCE(ACC) __syncthreads(); }                                              \
         if constexpr ((P) < 3 && (FETCH_LATE) && !PP_X_NOBT_) { BT_FETCH(BUF, ROT((P) + 1), ((P) + 1) & 1) }    \
         (mfma_hs<R, SWAP, 1>(AK, bt[(P) & 1], ACC));                                                        \
     })
@@ -585,7 +562,7 @@ __device__ __forceinline__ void geometry_put(const GeoI &g, const float (&pj)[3]
     MF_BEGIN()                                                                    \
     WSTAGE((K0) + C0 + 0, NCH, acc, (mfma_geo<R, 0>(AK, gbuf, lane, acc)))        \
     WSTAGE((K0) + C0 + 1, NCH, acc, (mfma_geo<R, 1>(AK, gbuf, lane, acc)))        \
-    if constexpr (!ST0) { tbar.sync(lane); }                                      \
+    if constexpr (!ST0) { __syncthreads(); }                                      \
     WSTAGE((K0) + C0 + 2, NCH, acc, (mfma_geo<R, 2>(AK, gbuf, lane, acc)))        \
     PUBLISH_OWN(true, acc, xbuf)
 
@@ -655,7 +632,6 @@ __device__ __forceinline__ float ln_merge(const float *st, int j, float &mean_ou
 // ---------------------------------------------------------------------------------------------
 template <int R, bool ST0>
 __device__ __forceinline__ void node_message_body(const EdgeArgs &A, const int res0, float *smem) {
-    TeamBar<false> tbar;
     float *const xbuf = smem;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -713,7 +689,7 @@ __device__ __forceinline__ void node_message_body(const EdgeArgs &A, const int r
         add_tile_q(pc[r], acc[r]);
         if constexpr (ST0) add_tile_q(zt[r], acc[r]);
     }
-    if constexpr (ST0) tbar.sync(lane);   // geometry operands are in LDS (otherwise the first W_B stage's barrier says so)
+    if constexpr (ST0) __syncthreads();   // geometry operands are in LDS (otherwise the first W_B stage's barrier says so)
     FIRST_LAYER(0, NCH)
     // the edge masks of the final reduction are requested before the last layer (read where they are used, their round trip
     // followed the last MFMA)
@@ -790,16 +766,13 @@ k_node_message(EdgeArgs A) {
 // FUSE: the workgroup goes straight on to the NEXT layer's node message of its residues (same edges, whose new h_E it
 // holds; the node-level inputs PA2 / PC2 / pts2 were written by the node update that ran before this kernel): one
 // launch, one prologue and one read of h_E less per layer.
-// DUO: the body runs as one of the two four-wave TEAMS of a 512-thread workgroup (k_edge_update_duo): thread ids are team-local,
-// the team's barriers are `tbar`'s LDS counter, and a team whose residues are all masked or out of range does not leave early (the
-// other team throttles on its progress): it computes on a valid row and stores nothing.
 // LNS: the plan carries operand scales behind small LayerNorm gains (A.ls_*): the three LayerNorm outputs that become f16 operands
 // are multiplied by their power-of-two scale vector before the split (the default instances contain none of it).
-template <int R, bool ST0, bool FUSE, bool DUO = false, bool LNS = false>
-__device__ __forceinline__ void edge_update_body(const EdgeArgs &A, const int res0, float *smem, TeamBar<DUO> tbar = TeamBar<DUO>()) {
+template <int R, bool ST0, bool FUSE, bool LNS = false>
+__device__ __forceinline__ void edge_update_body(const EdgeArgs &A, const int res0, float *smem) {
     float *const xbuf = smem, *const x1buf = smem + R * XBUF_FLOATS, *const stat = x1buf + R * XBUF_FLOATS,
                  *const prm = stat + R * STAT_FLOATS;
-    const int tid = DUO ? (int)(threadIdx.x & (ET - 1)) : (int)threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, h = lane >> 5;
     const int K = A.K;
@@ -820,11 +793,7 @@ __device__ __forceinline__ void edge_update_body(const EdgeArgs &A, const int re
                 if (tid == 0) A.msum[n[r]] = 0.f;
             }
         }
-    const bool any_live = first >= 0;
-    if (first < 0) {
-        if constexpr (DUO) first = 0;          // (row 0 of the batch: valid loads, nothing of it is stored)
-        else return;
-    }
+    if (first < 0) return;
 #pragma unroll
     for (int r = 0; r < R; r++)
         if (!live[r]) n[r] = first;
@@ -887,7 +856,7 @@ __device__ __forceinline__ void edge_update_body(const EdgeArgs &A, const int re
         add_tile_q(pc[r], acc[r]);
         if constexpr (ST0) add_tile_q(zt[r], acc[r]);
     }
-    if constexpr (ST0) tbar.sync(lane);   // geometry operands and parameters are in LDS (otherwise the first W_B stage's barrier says so)
+    if constexpr (ST0) __syncthreads();   // geometry operands and parameters are in LDS (otherwise the first W_B stage's barrier says so)
     TS(0)
     FIRST_LAYER(0, NCH)
     TS(1)
@@ -913,7 +882,7 @@ __device__ __forceinline__ void edge_update_body(const EdgeArgs &A, const int re
         for (int q = 0; q < 16; q++) out[r][q] = fmaf(acc[r][q], me[r], out[r][q]);
         ln_partial(out[r], stat + r * STAT_FLOATS, wave, j, h);
     }
-    tbar.sync(lane);
+    __syncthreads();
     TS(5)
 #pragma unroll
     for (int r = 0; r < R; r++) {
@@ -942,7 +911,7 @@ __device__ __forceinline__ void edge_update_body(const EdgeArgs &A, const int re
     MF_END()
 #pragma unroll
     for (int r = 0; r < R; r++) ln_partial(out[r], stat + r * STAT_FLOATS, wave, j, h);
-    tbar.sync(lane);
+    __syncthreads();
     TS(11)
 #pragma unroll
     for (int r = 0; r < R; r++) {
@@ -984,7 +953,7 @@ __device__ __forceinline__ void edge_update_body(const EdgeArgs &A, const int re
         RLAYER_OWN(NEU + 0, NCH, acc, xbuf, false, false)
         WSTAGE(NEU + 4, NCH, acc, (mfma_geo<R, 0>(AK, gbuf, lane, acc)))
         WSTAGE(NEU + 5, NCH, acc, (mfma_geo<R, 1>(AK, gbuf, lane, acc)))
-        tbar.sync(lane);                  // barrier A of the publication below
+        __syncthreads();                  // barrier A of the publication below
         WSTAGE(NEU + 6, NCH, acc, (mfma_geo<R, 2>(AK, gbuf, lane, acc)))
 #pragma unroll
         for (int r = 0; r < R; r++) add_tile_q(pc2[r], acc[r]);
@@ -1026,7 +995,7 @@ __device__ __forceinline__ void edge_update_body(const EdgeArgs &A, const int re
             }
         }
     }
-    if (any_live && pp_sat_hit(sat)) atomicOr(A.sat, 1u);
+    if (pp_sat_hit(sat)) atomicOr(A.sat, 1u);
 #ifdef PP_X_TS
     TS(17)
     if (A.dbg && tid == 0)
@@ -1043,7 +1012,7 @@ template <int R, bool ST0, bool FUSE, bool LNS = false>
 __global__ void __launch_bounds__(ET, R == 1 ? PP_WGS : PP_WGS2)
 k_edge_update(EdgeArgs A) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    edge_update_body<R, ST0, FUSE, false, LNS>(A, blockIdx.x * R, smem);
+    edge_update_body<R, ST0, FUSE, LNS>(A, blockIdx.x * R, smem);
 }
 
 // MIXED launch for one complex that fills the chip once (2 < residues per CU <= 3).  Every workgroup streams the layer's
@@ -1074,41 +1043,9 @@ k_edge_update_mix(EdgeArgs A) {
 #elif PP_X_PRIO == 2
     if (pair >= 0) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1);
 #endif
-    if (pair >= 0) edge_update_body<2, ST0, FUSE, false, LNS>(A, 2 * pair, smem);
-    else edge_update_body<1, ST0, FUSE, false, LNS>(A, 2 * A.n_pairs + single, smem);
+    if (pair >= 0) edge_update_body<2, ST0, FUSE, LNS>(A, 2 * pair, smem);
+    else edge_update_body<1, ST0, FUSE, LNS>(A, 2 * A.n_pairs + single, smem);
 }
-
-// DUO launch (round 5): ONE 512-thread workgroup per CU made of two four-wave TEAMS, each running the edge update of its own
-// residues in its own LDS block -- the two co-resident workgroups of the launches above, moved into one workgroup so that they START
-// TOGETHER and stream the layer's weights at (nearly) the same time: a weight line that one team's wave pulls into the CU's L1 is a
-// hit for the other team's wave a few hundred cycles later, i.e. ONE L2 -> L1 fill of the 0.93 MB stream per CU instead of two (the
-// binding resource of these launches: DESIGN.md 4.6).  Rounds 3 and 4 tried this with the workgroup's s_barrier ("duo": ping-pong
-// teams, "trio") and lost what the fill gained to the lockstep -- every exchange of one team exposed to the other.  Here the teams
-// are FREE-RUNNING: a team's barriers are its own LDS counter (TeamBar<true>), nothing couples the teams but the cache.
-//   A.n_pairs > 0 : team 0 = residues (2 b, 2 b + 1), team 1 = residue 2 n_pairs + b   (three residues per CU: one complex)
-//   A.n_pairs == 0: team t = residues (4 b + 2 t, 4 b + 2 t + 1)                        (four residues per workgroup)
-// Same arithmetic per residue as k_edge_update<R> (the bodies are the same code): results are bit-identical.
-#define DUO_TEAM_FLOATS (2 * 2 * XBUF_FLOATS + 2 * STAT_FLOATS + PARAM_LDS + 256)
-template <bool ST0, bool FUSE, bool LNS = false>
-__global__ void __launch_bounds__(2 * ET, 1)
-k_edge_update_duo(EdgeArgs A) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int team = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));
-    unsigned *bars = reinterpret_cast<unsigned *>(smem + 2 * DUO_TEAM_FLOATS);
-    if (threadIdx.x < 2) bars[threadIdx.x] = 0u;
-    __syncthreads();                                  // the only workgroup-wide barrier: the teams' counters start at zero
-    TeamBar<true> tb;
-    tb.cnt = bars + team;
-    float *tsm = smem + team * DUO_TEAM_FLOATS;
-    const int b = blockIdx.x;
-    if (A.n_pairs > 0) {
-        if (team == 0) edge_update_body<2, ST0, FUSE, true, LNS>(A, 2 * b, tsm, tb);
-        else edge_update_body<1, ST0, FUSE, true, LNS>(A, 2 * A.n_pairs + b, tsm, tb);
-    } else {
-        edge_update_body<2, ST0, FUSE, true, LNS>(A, 4 * b + 2 * team, tsm, tb);
-    }
-}
-#define DUO_SMEM ((2 * DUO_TEAM_FLOATS + 4) * sizeof(float))
 
 // the stand-alone node message (layer 0) with the same split of a CU's three residues: two weight passes instead of three
 template <bool ST0>
@@ -1395,17 +1332,14 @@ static edge_kernel_t mix_kernel(bool st0, bool lns) {
     if (lns) return st0 ? k_edge_update_mix<true, PP_FUSED, true> : k_edge_update_mix<false, PP_FUSED, true>;
     return st0 ? k_edge_update_mix<true, PP_FUSED> : k_edge_update_mix<false, PP_FUSED>;
 }
-static edge_kernel_t duo_kernel(bool st0, bool lns);
+
 static edge_kernel_t nm_kernel_r(int R, bool st0) {
     return R == 1 ? nm_kernel<1>(st0) : nm_kernel<2>(st0);
 }
 static edge_kernel_t eu_kernel_r(int R, bool st0, bool lns = false) {
     return R == 1 ? eu_kernel<1>(st0, lns) : eu_kernel<2>(st0, lns);
 }
-static edge_kernel_t duo_kernel(bool st0, bool lns) {
-    if (lns) return st0 ? k_edge_update_duo<true, PP_FUSED, true> : k_edge_update_duo<false, PP_FUSED, true>;
-    return st0 ? k_edge_update_duo<true, PP_FUSED> : k_edge_update_duo<false, PP_FUSED>;
-}
+
 
 static int g_num_cu = 0;
 static bool edge_attrs() {
@@ -1423,7 +1357,7 @@ static bool edge_attrs() {
                      set(reinterpret_cast<const void *>(eu_kernel_r(R, st0, true)), MAX_SMEM);
         for (int st0 = 0; st0 < 2 && ok; st0++)
             for (int lns = 0; lns < 2 && ok; lns++)
-                ok = set(reinterpret_cast<const void *>(mix_kernel(st0, lns)), MAX_SMEM) && set(reinterpret_cast<const void *>(duo_kernel(st0, lns)), MAX_SMEM);
+                ok = set(reinterpret_cast<const void *>(mix_kernel(st0, lns)), MAX_SMEM);
         ok = ok && set(reinterpret_cast<const void *>(k_node_message_mix<true>), MAX_SMEM) &&
              set(reinterpret_cast<const void *>(k_node_message_mix<false>), MAX_SMEM);
         int dev = 0;
@@ -1462,22 +1396,6 @@ static bool use_mix(int N) {
     }
     if (g_forced_R >= 1 || !g_mix) return false;
     return N > 2 * g_num_cu && N <= 3 * g_num_cu;
-}
-
-// duo launch (k_edge_update_duo): 0 never, 1 for every launch beyond two residues per CU (diagnostic builds: PP_EDGE_DUO /
-// pp_debug_set_edge_duo); -1 the default rule
-static int g_duo = -1;
-#ifdef PP_DIAG
-extern "C" void pp_debug_set_edge_duo(int mode) { g_duo = mode < 0 ? -2 : mode; }
-#endif
-static bool use_duo(int N) {
-    if (g_duo == -1) {
-        const char *e = PP_GETENV("PP_EDGE_DUO");
-        g_duo = e ? atoi(e) : -2;
-    }
-    if (g_forced_R >= 1 || N <= 2 * g_num_cu) return false;
-    if (g_duo >= 0) return g_duo == 1;
-    return false;
 }
 
 // resident workgroups per CU the runtime predicts for the two kernels (measurement aid)
@@ -1536,14 +1454,6 @@ pp_status pp_launch_edge_update(pp_ctx *c, int layer, hipStream_t s) {
     const int R = pick_R(c->N);
     const bool lns = c->plan->ln_scale != nullptr;      // operand scales behind small LayerNorm gains: the LNS instances
     if (lns && !PP_FUSED) { pp_set_error("pp_launch_edge_update: a plan with LayerNorm operand scales needs the fused build"); return PP_ERR_UNSUPPORTED; }
-    if (PP_FUSED && use_duo(c->N)) {
-        const bool three = c->N <= 3 * g_num_cu;           // one complex that fills the chip once: pair + single per workgroup
-        A.n_pairs = three ? (c->N + 2) / 3 : 0;
-        const int wgs = three ? A.n_pairs : (c->N + 3) / 4;
-        PP_LAUNCH(c, duo_kernel(layer == 0, lns), dim3(wgs), dim3(2 * ET), DUO_SMEM, s, A);
-        PP_HIP_CHECK(hipGetLastError());
-        return PP_OK;
-    }
     if (use_mix(c->N)) {
         // three residues per CU as one two-residue and one one-residue workgroup
         A.n_pairs = (c->N + 2) / 3;

@@ -179,11 +179,14 @@ static LnScales ln_operand_scales(const float *w, const WeightOff &off) {
     }
     return sc;
 }
-// the consuming columns divided by the operand scales, in place on the copy the edge-level streams are packed from
-static void apply_ln_scales(float *w, const WeightOff &off, const LnScales &sc) {
+// the consuming columns divided by the operand scales (`undo`: multiplied back), in place
+static void apply_ln_scales(float *w, const WeightOff &off, const LnScales &sc, bool undo = false) {
     auto div_cols = [&](size_t wofs, int rows, int ld, int col0, const float *s) {
         for (int r = 0; r < rows; r++)
-            for (int f = 0; f < 128; f++) w[wofs + (size_t)r * ld + col0 + f] /= s[f];
+            for (int f = 0; f < 128; f++) {
+                float &x = w[wofs + (size_t)r * ld + col0 + f];
+                x = undo ? x * s[f] : x / s[f];
+            }
     };
     div_cols(off.layer[0].nm_in_w, 128, 456, 128, sc.v[PP_LN_E0]);
     div_cols(off.layer[0].em_in_w, 128, 456, 128, sc.v[PP_LN_E0]);
@@ -192,4 +195,21 @@ static void apply_ln_scales(float *w, const WeightOff &off, const LnScales &sc) 
         if (l + 1 < 2) div_cols(off.layer[l + 1].em_in_w, 128, 456, 128, sc.v[PP_LN_E(l)]);
         div_cols(off.layer[l].ed_in_w, 512, 128, 0, sc.v[PP_LN_X1(l)]);
     }
+}
+
+// Both rewrites in the order that makes them meaningful: FIRST the operand scales (chosen from the LayerNorm gains and biases) go
+// into the consuming columns, so that every input of an edge-level layer is O(1) and a row norm says how large the layer's output
+// is -- a W_B block that carries 1 / gain in its columns would otherwise look 300x larger than it acts and the chain would be
+// "rebalanced" into the subnormal range (measured: small-LN-gain envelope variant, 5.5e-4 rad) --, THEN the ReLU chains are
+// rebalanced on that matrix.  `packed` = what the edge-level MFMA streams are packed from (columns divided by the operand scales);
+// `plain` = the same network with the columns multiplied back: what every other consumer (node kernels, biases, the device copy)
+// uses.  Row scaling and column scaling commute and are powers of two: both vectors describe the original function exactly.
+static int rewrite_checkpoint(const float *weights, const WeightOff &off, std::vector<float> &plain, std::vector<float> &packed, LnScales &sc) {
+    sc = ln_operand_scales(weights, off);
+    packed.assign(weights, weights + off.total);
+    if (sc.n_scaled > 0) apply_ln_scales(packed.data(), off, sc);
+    const int chains = rebalance_relu_chains(packed.data(), off);
+    plain = packed;
+    if (sc.n_scaled > 0) apply_ln_scales(plain.data(), off, sc, true);
+    return chains;
 }

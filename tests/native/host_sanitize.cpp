@@ -64,6 +64,17 @@ static int rebalance_cases(unsigned seed) {
         case 5: w[L.em_mid_w + 5] = 6.0e4f; scale(L.em_in_w, 128 * 456, 1e-5f); break;        // a consumer entry at the f16 edge
         case 6: scale(L.ed_in_w, 512 * 128, 1e-30f); break;                                   // denormal producer
         }
+        if (variant == 3 || variant == 5) {          // small LayerNorm gains as well: operand scales, then the chains
+            for (int f = 0; f < 128; f++) { w[L.norm_g[2] + f] = 1e-3f * (1.f + f % 7); w[L.norm_b[2] + f] = 2e-4f * (f % 5); }
+            std::vector<float> plain, packed;
+            LnScales sc;
+            chains += rewrite_checkpoint(w.data(), off, plain, packed, sc);
+            for (size_t i = 0; i < w.size(); i++)
+                if ((!(std::fabs(plain[i]) < 65504.f) || !(std::fabs(packed[i]) < 65504.f)) && std::fabs(w[i]) < 65504.f && variant != 5) {
+                    std::fprintf(stderr, "variant %d: rewritten weight %zu left the f16 range\n", variant, i);
+                    return -1;
+                }
+        }
         const std::vector<float> before = w;
         chains += rebalance_relu_chains(w.data(), off);
         for (size_t i = 0; i < w.size(); i++)

@@ -498,50 +498,6 @@ def test_residues_per_workgroup_agree(weights):
         l.pp_debug_set_edge_R(0)          # back to the automatic choice
 
 
-def test_duo_launch_is_bit_identical(weights):
-    """The duo launch (k_edge_update_duo: the two co-resident edge workgroups of a CU as the two free-running four-wave teams of ONE
-    512-thread workgroup, team barriers through an LDS counter) runs the same bodies on the same residues' data: forced on, it must
-    give the same BITS as the default launch -- in its three-residues-per-CU form (team 0 a pair, team 1 a single), in its
-    four-per-workgroup form with a ragged tail, and on a packed batch with a masked residue (a team without a live residue)."""
-    import ctypes as C
-    from packppi_amd import lib as L, synth
-    from packppi_amd.batch import pack
-    from packppi_amd.featurize import protein_to_batch
-    from packppi_amd.module import TDiffusionModule
-    l = L.load()
-    if l.pp_edge_variant() != 1:
-        pytest.skip("exact-fp32 edge kernels are built")
-    if not hasattr(l, "pp_debug_set_edge_duo"):
-        pytest.skip("forcing the launch shape needs libpackppi_hip.dbg.so (tests/test_hip_layers.py runs this test on it)")
-    l.pp_debug_set_edge_duo.argtypes = [C.c_int]
-    l.pp_debug_set_edge_duo.restype = None
-    m = TDiffusionModule(weights, device=DEV)
-    sched = torch.linspace(1, 0, 7)
-    masked = protein_to_batch(synth.make_complex(301, 41))
-    masked["residue_mask"][0, 130:134] = 0.0
-    masked["X"][0, 130:134] = 0.0
-    cases = {"single 700 (pair + single per workgroup)": protein_to_batch(synth.make_complex(700, 5)),
-             "single 1101 (four per workgroup, ragged tail)": protein_to_batch(synth.make_complex(1101, 6)),
-             "packed 301 (four masked in a row) + 280 + 333": pack([masked, protein_to_batch(synth.make_complex(280, 43)),
-                                                                    protein_to_batch(synth.make_complex(333, 44))])}
-    try:
-        for name, b in cases.items():
-            gb = b.to(DEV)
-            B, Lmax = b["SC_D"].shape[:2]
-            g = torch.Generator().manual_seed(7)
-            init = ((torch.rand(B, Lmax, 4, generator=g) * 2 - 1) * 3.0 * b["SC_D_mask"]).to(DEV)
-            ctx = m._context(gb)
-            l.pp_debug_set_edge_duo(0)
-            base = ctx.sample(init, sched)
-            l.pp_debug_set_edge_duo(1)
-            got = ctx.sample(init, sched)
-            assert torch.isfinite(got).all(), name
-            assert torch.equal(got, base), (name, float((got - base).abs().max()))
-            assert torch.equal(ctx.sample(init, sched), got), name
-    finally:
-        l.pp_debug_set_edge_duo(-1)          # back to the default rule
-
-
 def test_context_workspace_reuse(weights):
     """Contexts hand their device workspace back to the plan's pool (no hipMalloc / hipFree on the sampling path): a
     smaller, an equal and a larger complex after a destroyed context must give what a fresh module gives."""
@@ -1063,7 +1019,7 @@ def test_weight_range_envelope_T1124():
     from packppi_amd import lib as L
     from packppi_amd.module import TDiffusionModule
     from packppi_amd.weights import make_random_state_dict
-    from tools.oracle.envelope_weights import envelope_variants, tiny_operand_variants
+    from tools.oracle.envelope_weights import envelope_variants, small_ln_gain_variants, tiny_operand_variants
     z = np.load(os.path.join(GOLD, "g10_envelope_T1124.npz"))
     assert int(z["steps"]) == 100
     b, g = load_golden("g4_T1124")
@@ -1072,6 +1028,7 @@ def test_weight_range_envelope_T1124():
     sd0 = make_random_state_dict(20251003)
     variants = dict(envelope_variants(sd0))
     variants.update({"tiny operands: " + k: v for k, v in tiny_operand_variants(sd0).items()})
+    variants.update(small_ln_gain_variants(sd0))          # round 5: operand vectors made small by LayerNorm gains of 1e-3 .. 1e-2
     assert list(z["variants"]) == list(variants)
     libname = os.path.basename(os.environ.get("PACKPPI_LIB") or "libpackppi_hip.so")
     lines = []
@@ -1085,7 +1042,7 @@ def test_weight_range_envelope_T1124():
         d64 = float(wrapped_absdiff(out, ref64)[mask].max())
         d32 = float(wrapped_absdiff(out, ref32)[mask].max())
         lines.append(f"{libname:24s} {name:40s} |ref32 - ref64| {cond:.2e}   |this - ref64| {d64:.2e}   |this - ref32| {d32:.2e}   "
-                     f"saturated {m.saturated()}  rebalanced chains {m._plan.rebalanced_chains()}")
+                     f"saturated {m.saturated()}  rebalanced chains {m._plan.rebalanced_chains()}  scaled LN operand features {m._plan.ln_scaled_features()}")
         print(lines[-1])
         assert d64 < max(1e-4, 3 * cond), (name, d64, cond)
         assert d32 < max(1e-4, 3 * cond), (name, d32, cond)
@@ -1094,6 +1051,8 @@ def test_weight_range_envelope_T1124():
             # the chains whose hidden operands would sit at 1e-3 were rebalanced when the plan was made (pp_api.hip)
             if name.startswith(("tiny operands", "linear x1/32")):
                 assert m._plan.rebalanced_chains() > 0, name
+            # operand vectors made small by LayerNorm gains carry power-of-two scales (pp_rebalance.h); the seeded LayerNorms none
+            assert (m._plan.ln_scaled_features() > 100) == name.startswith("small LN gains"), (name, m._plan.ln_scaled_features())
     if os.environ.get("PACKPPI_ENVELOPE_REPORT"):
         with open(os.environ["PACKPPI_ENVELOPE_REPORT"], "a") as fh:
             fh.write("\n".join(lines) + "\n")

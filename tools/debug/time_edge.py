@@ -17,7 +17,7 @@ from packppi_amd.weights import make_random_state_dict  # noqa: E402
 
 dev = torch.device("cuda", 0)
 l = lib.load()
-force = getattr(l, "pp_debug_set_edge_duo", None)
+force = getattr(l, "pp_debug_set_edge_duo", None)      # only libraries built from the duo experiment commits export it
 if force is not None:
     force.argtypes = [C.c_int]
     force.restype = None
