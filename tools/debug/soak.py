@@ -10,8 +10,9 @@ from packppi_amd.module import TDiffusionModule
 from packppi_amd.weights import make_random_state_dict
 m = TDiffusionModule(make_random_state_dict(20251003), device="cuda:0")
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+sizes = [int(a) for a in sys.argv[2:]] or [300, 520, 739, 800, 1100, 1600, 2300]       # soak.py <reps> [sizes ...]
 bad = 0
-for L in (300, 520, 739, 800, 1100, 1600, 2300):
+for L in sizes:
     b = protein_to_batch(synth.make_complex(L, 11)).to("cuda:0")
     ctx = m._context(b)
     sched = torch.linspace(1, 0, 21)
