@@ -234,7 +234,10 @@ pp_status pp_range_check_parts(unsigned long long *edge_events, unsigned long lo
 /* Sticky saturation flag, every build (no reference counterpart).  The default kernels clamp hidden activations at the f16
  * maximum before splitting them; a context remembers that it happened: *flags bit 0 = in an edge-level kernel, bit 1 = in a
  * node-level kernel, 0 = never since pp_complex_prepare.  The call waits for `stream`.  A set bit means results of this
- * context are not fp32-equivalent for this checkpoint (run python -m packppi_amd.rangecheck for the details). */
+ * context are not fp32-equivalent for this checkpoint (run python -m packppi_amd.rangecheck for the details).
+ * Bit 2 (value 4): a NaN or infinity ENTERED with the caller's tensors (backbone coordinates of an unmasked row at
+ * pp_complex_prepare, an angle at pp_score / pp_sample).  The reference propagates it to its output (layers.py:22-33 has no
+ * clamp); these kernels' clamps turn it into finite numbers that mean nothing -- the flag is how a caller learns of it. */
 pp_status pp_ctx_saturated(pp_ctx *ctx, int *flags, void *stream);
 
 /* Diagnostics -- ONLY in libpackppi_hip.dbg.so (built with -DPP_DIAG; same kernels and results as the default library):

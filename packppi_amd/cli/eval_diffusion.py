@@ -48,7 +48,9 @@ def evaluate_model(model, args):
     if args.seed is not None:
         torch.manual_seed(args.seed)
     SC_D_sample = model.sampling(batch, use_proximal=args.use_proximal)
-    if model.saturated():
+    if model.saturated() & 4:
+        print("----- WARNING: NaN / infinity in the input coordinates or angles: the reference would return NaN here -----")
+    if model.saturated() & 3:
         # a hidden activation reached the f16 maximum in the split-f16 dense layers: not the reference's arithmetic any more
         print("----- WARNING: f16 saturation in the score network (flag %d); run `python -m packppi_amd.rangecheck` on this "
               "checkpoint -----" % model.saturated())

@@ -326,6 +326,25 @@ extern "C" pp_status pp_range_check_parts(unsigned long long *edge_events, unsig
                              "python -m packppi_amd.rangecheck)");
 #endif
 }
+// Non-finite INPUTS.  The kernels clamp hidden activations with v_med3 / v_max, which turn a NaN into a finite number: a NaN that
+// enters with the caller's tensors would come out as finite angles that mean nothing, where the reference returns NaN
+// (layers.py:22-33 has no such clamp).  From finite inputs no NaN can arise inside (every weight is checked finite at plan
+// creation, every LayerNorm has its eps, every hidden activation is bounded), so the inputs are what is checked: the backbone
+// coordinates of unmasked rows when a context is prepared, the angles at every pp_score / pp_sample.  Bit 2 of the sticky word.
+__global__ void k_flag_nonfinite(const float *__restrict__ v, int rows, int row_stride, int per_row, const float *__restrict__ rmask,
+                                 unsigned *__restrict__ sat) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * per_row) return;
+    const int r = i / per_row, k = i - r * per_row;
+    if (rmask && rmask[r] == 0.f) return;
+    const float x = v[(size_t)r * row_stride + k];
+    if (!(__builtin_fabsf(x) <= 3.402823466e38f)) atomicOr(sat, 4u);
+}
+static void flag_nonfinite(pp_ctx *c, const float *v, int row_stride, int per_row, hipStream_t s) {
+    const int n = c->N * per_row;
+    hipLaunchKernelGGL(k_flag_nonfinite, dim3((n + 255) / 256), dim3(256), 0, s, v, c->N, row_stride, per_row, c->b.residue_mask, c->sat);
+}
+
 // sticky saturation word of the context (every build): waits for `stream`
 extern "C" pp_status pp_ctx_saturated(pp_ctx *c, int *flags, void *stream) {
     if (!c || !flags) FAIL(PP_ERR_INVALID, "pp_ctx_saturated: null argument");
@@ -700,6 +719,7 @@ static pp_status prepare_impl(pp_plan *plan, const pp_batch *b, const int32_t *s
         pp_set_error("clearing the saturation word failed");
         st = PP_ERR_HIP;
     }
+    if (net && st == PP_OK) flag_nonfinite(c, c->b.X, 42, 12, static_cast<hipStream_t>(stream));      // N, CA, C, O of the unmasked rows
     if (net && st == PP_OK) st = pp_launch_prepare(c, static_cast<hipStream_t>(stream));
     if (net && st == PP_OK) st = pp_launch_edge_static(c, static_cast<hipStream_t>(stream));
     if (st != PP_OK) { pp_ctx_destroy(c); return st; }
@@ -830,6 +850,7 @@ extern "C" pp_status pp_score(pp_ctx *c, const float *chi, float t, float *score
     StepParams sp;
     fill_step(&sp, t, 0.f, c->plan->annealed_temp);
     pp_status st;
+    flag_nonfinite(c, chi, 4, 4, s);
     if ((st = pp_launch_node_embed(c, chi, sp, s)) != PP_OK) return st;
     if ((st = run_network(c, s, 0, PP_NU_SCORE, nullptr, PP_MODE_ODE, nullptr, &sp, nullptr)) != PP_OK) return st;
     PP_HIP_CHECK(hipMemcpyAsync(score, c->score, (size_t)c->N * 4 * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -855,6 +876,7 @@ extern "C" pp_status pp_sample(pp_ctx *c, float *chi, const float *schedule, int
     pp_status st;
     // (A hipGraph replay of the loop was measured and dropped: with no stray event records in the stream the kernel
     // trace shows back-to-back dispatches, and capture + replay was 2 % slower than plain launches.)
+    flag_nonfinite(c, chi, 4, 4, s);
     if ((st = pp_launch_node_embed(c, chi, steps[0], s)) != PP_OK) return st;
     static const bool dbg = PP_GETENV("PP_DEBUG") != nullptr;
     const auto h0 = std::chrono::steady_clock::now();

@@ -44,13 +44,14 @@ struct HT {
 typedef float f32x2v __attribute__((ext_vector_type(2)));
 typedef _Float16 h2v __attribute__((ext_vector_type(2)));
 // f32 pair -> packed f16 by v_cvt_pkrtz_f16_f32 (round toward zero), NOT by gfx950's new v_cvt_pk_f16_f32 (round to nearest
-// even; what __builtin_convertvector and plain casts of a pair compile to).  With v_cvt_pk_f16_f32 these kernels are only
-// correct while a wave has its SIMD to itself: with two or more waves per SIMD, lanes 16-31 and 48-63 of some tiles come
-// out wrong, differently from run to run (the "occupancy hazard" of DESIGN.md section 4 -- not the LDS-DMA, not the MFMA
-// chains, not the exchange buffers).  Measured with tools/debug/soak.py at two workgroups per CU: -DPP_X_CVT_PK fails on
-// every size, this function and -DPP_X_CVT_SCALAR (the old v_cvt_f16_f32 twice + v_pack_b32_f16, round to nearest) are
-// bit-reproducible.  The split does not care which way hi is rounded: lo = x - hi is exact either way and hi + lo still
-// carries 21 bits of x; pkrtz is one instruction per pair.
+// even; what __builtin_convertvector and plain casts of a pair compile to).  A build with the packed round-to-nearest form
+// everywhere (-DPP_X_CVT_PK) is not reproducible from run to run with two or more waves per SIMD.  Round 5 took that apart
+// (profiles/r05_cvt_pk_hazard.txt): the instruction itself is clean -- in a micro-repro of 100 configurations and at every
+// activation split of these kernels (bit-reproducible, 4.3e-6 rad at T1124) --; the failure is confined to geometry_put's four
+// point pairs written as convertvector TOGETHER (each alone is clean, wait states do not cure it, the barrier protocol holds under
+// injected skew): an interaction inside that one instruction sequence that no reduced form reproduces.  pkrtz stays, everywhere:
+// one rounding rule for every operand.  The split does not care which way hi is rounded: lo = x - hi is exact either way and
+// hi + lo still carries 21 bits of x; pkrtz is one instruction per pair.
 typedef __fp16 fp16x2_t __attribute__((ext_vector_type(2)));
 #if defined(PP_X_CVT_SCALAR)      /* experiment: round-to-nearest through the pre-gfx950 scalar conversion + pack */
 __device__ __forceinline__ h2v cvt2(f32x2v x) {
@@ -67,17 +68,6 @@ __device__ __forceinline__ h2v cvt2(f32x2v x) {
     const fp16x2_t r = __builtin_amdgcn_cvt_pkrtz(x[0], x[1]);
     return __builtin_bit_cast(h2v, r);
 }
-#endif
-// -DPP_LAB -DPP_X_CVT_PK_SITES=mask: v_cvt_pk_f16_f32 at single call sites (bisection of the hazard, tools/debug/cvt_pk_bisect.sh):
-// bit 0 the HIGH part of a split, bit 1 the LOW part, bit 2 the geometry operands' eight point features, bit 3 / 4 the high / low
-// part of their {distance, 0} pair
-#ifdef PP_X_CVT_PK_SITES
-template <int SITE> __device__ __forceinline__ h2v cvt2s(f32x2v x) {
-    if constexpr (((PP_X_CVT_PK_SITES >> SITE) & 1) || (SITE >= 5 && ((PP_X_CVT_PK_SITES >> 2) & 1))) return __builtin_convertvector(x, h2v);
-    else return cvt2(x);
-}
-#else
-template <int SITE> __device__ __forceinline__ h2v cvt2s(f32x2v x) { return cvt2(x); }
 #endif
 // x - (float)hh for a packed pair: one v_fma_mix_f32 per value (the f16 half is an operand of the fp32 FMA; exact, like the
 // v_cvt_f32_f16 + v_sub_f32 pair it replaces -- a quarter of the split's VALU instructions)
@@ -101,7 +91,7 @@ __device__ __forceinline__ void split_tile(const f32x16 &v, HT &o, unsigned &sat
                 x[0] = __builtin_amdgcn_fmed3f(x[0], 0.f, 65504.f);
                 x[1] = __builtin_amdgcn_fmed3f(x[1], 0.f, 65504.f);
             }
-            const h2v hh = cvt2s<0>(x);
+            const h2v hh = cvt2(x);
 #ifndef PP_X_NOSAT     /* A/B aid: build without the sticky-flag bookkeeping */
             if (RELU)      // sticky saturation flag: running maximum of the clamped halves (v_pk_max_u16), see pp_internal.h
 #else
@@ -109,7 +99,7 @@ __device__ __forceinline__ void split_tile(const f32x16 &v, HT &o, unsigned &sat
 #endif
                 sat = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(us2v, sat), __builtin_bit_cast(us2v, hh)));
             const f32x2v d = split_residual(hh, x);
-            const h2v ll = cvt2s<1>(d);
+            const h2v ll = cvt2(d);
             o.hi[s][i] = hh[0]; o.hi[s][i + 1] = hh[1];
             o.lo[s][i] = ll[0]; o.lo[s][i + 1] = ll[1];
         }
@@ -153,7 +143,6 @@ struct EdgeArgs {
     float *dbg;                // diagnostics: [N][4 waves][64 lanes][8] or null
     int n_pairs;               // k_edge_update_mix: workgroups with two residues (the rest have one)
     int mix_mode;
-    int skew;                  // -DPP_X_SKEW (laboratory): 16 * point + wave -- that wave sleeps ~30 k cycles at that point (race hunting)
 };
 enum { P_BMID = 0, P_BOUT = 128, P_FOB = 256, P_G2 = 384, P_BE2 = 512, P_FIB = 640 };
 
@@ -452,13 +441,9 @@ __device__ __forceinline__ void geometry_put(const GeoI &g, const float (&pj)[3]
     for (int i = 0; i < 10; i += 2) {
         const f32x2v x = {v[i], v[i + 1]};
         PP_RANGE(x[0]) PP_RANGE(x[1])
-        // (sites 5 .. 8: the pairs i = 0, 2, 4, 6 one by one, high and low part; site 2 = all four)
-        const h2v hh = i == 0 ? cvt2s<5>(x) : i == 2 ? cvt2s<6>(x) : i == 4 ? cvt2s<7>(x) : i == 6 ? cvt2s<8>(x) : cvt2s<3>(x);
+        const h2v hh = cvt2(x);
         const f32x2v d = split_residual(hh, x);
-        h2v ll = i == 0 ? cvt2s<5>(d) : i == 2 ? cvt2s<6>(d) : i == 4 ? cvt2s<7>(d) : i == 6 ? cvt2s<8>(d) : cvt2s<4>(d);
-#if defined(PP_X_CVT_PK_SITES) && ((PP_X_CVT_PK_SITES >> 9) & 1)      /* bisection aid: two wait states behind every conversion of this block */
-        asm volatile("s_nop 1" : "+v"(ll));
-#endif
+        const h2v ll = cvt2(d);
         if (i < 8) { vh[i] = hh[0]; vh[i + 1] = hh[1]; vl[i] = ll[0]; vl[i + 1] = ll[1]; }
         else { dh = hh; dl = ll; }
     }
@@ -523,13 +508,6 @@ __device__ __forceinline__ void geometry_put(const GeoI &g, const float (&pj)[3]
 #else
 #define MF_BEGIN()
 #define MF_END()
-#endif
-// -DPP_LAB -DPP_X_SKEW: one wave of every workgroup is held back at one point of the chain (PP_SKEW=16 * point + wave in the
-// environment): a barrier protocol that is complete gives the same bits under any skew (tools/debug/skew_hunt.sh)
-#ifdef PP_X_SKEW
-#define SKEW(pt) if (A.skew >= 0 && (A.skew >> 4) == (pt) && (A.skew & 15) == wave) { for (int sk_ = 0; sk_ < 4; sk_++) __builtin_amdgcn_s_sleep(127); }
-#else
-#define SKEW(pt)
 #endif
 #define ROT(p) ((wave + (p)) & 3)        // input tile at position p of a rotated layer (wave-uniform)
 #define BT_FETCH(BUF, t, set)                                                     \
@@ -706,14 +684,12 @@ __device__ __forceinline__ void node_message_body(const EdgeArgs &A, const int r
         if constexpr (ST0) load_tile_q(A.Z + ((size_t)n[r] * K + jj) * 128 + 32 * wave, h, zt[r]);
     }
     if constexpr (!ST0) { PUBLISH_OWN(false, hin, xbuf) }
-    SKEW(8)
 #pragma unroll
     for (int r = 0; r < R; r++) {
         geometry_put(gi0[r], pj[r], wave, lane, gbuf + r * GBUF_FLOATS);
         add_tile_q(pc[r], acc[r]);
         if constexpr (ST0) add_tile_q(zt[r], acc[r]);
     }
-    SKEW(9)
     if constexpr (ST0) __syncthreads();   // geometry operands are in LDS (otherwise the first W_B stage's barrier says so)
     FIRST_LAYER(0, NCH)
     // the edge masks of the final reduction are requested before the last layer (read where they are used, their round trip
@@ -873,12 +849,9 @@ __device__ __forceinline__ void edge_update_body(const EdgeArgs &A, const int re
 #pragma unroll
     for (int it = 0; it < PRM_IT; it++) *reinterpret_cast<f32x4v *>(prm + 4 * min(tid + it * ET, PARAM_LDS / 4 - 1)) = prv[it];
     if (tid < 64) *reinterpret_cast<f32x4v *>(prm + PARAM_LDS + 4 * tid) = prg;
-    SKEW(0)
 #pragma unroll
     for (int r = 0; r < R; r++) geometry_put(gi0[r], pj[r], wave, lane, gbuf + r * GBUF_FLOATS);
-    SKEW(1)
     if constexpr (!ST0) { PUBLISH_OPERAND(out, xbuf, A.ls_in) }
-    SKEW(2)
 #pragma unroll
     for (int r = 0; r < R; r++) {
         add_tile_q(pc[r], acc[r]);
@@ -920,9 +893,7 @@ __device__ __forceinline__ void edge_update_body(const EdgeArgs &A, const int re
         for (int q = 0; q < 16; q++) out[r][q] -= mean;
         ln_affine_tile(out[r], rstd, prm + P_G2 + 32 * wave, prm + P_BE2 + 32 * wave, h);
     }
-    SKEW(3)
     PUBLISH_OPERAND(out, x1buf, A.ls_x1)  // (x1buf last held the geometry operands: read before the barriers above)
-    SKEW(4)
     // `out` keeps x1 (this wave's tile, fp32) as the residual of the second LayerNorm and collects the FFN output
     // on top of it: out = x1 + b + W2 relu(W1 x1 + b1)
 #pragma unroll
@@ -970,16 +941,13 @@ __device__ __forceinline__ void edge_update_body(const EdgeArgs &A, const int re
             load_tile(A.PA2 + (size_t)n[r] * 128 + 32 * wave, h, acc[r]);
         }
         __builtin_amdgcn_sched_barrier(0);
-        SKEW(5)
         PUBLISH_OPERAND(out, xbuf, A.ls_out)
-        SKEW(6)
         __builtin_amdgcn_sched_barrier(0);
         TileQ pc2[R];
 #pragma unroll
         for (int r = 0; r < R; r++) load_tile_q(A.PC2 + (size_t)nbr[r] * 128 + 32 * wave, h, pc2[r]);
 #pragma unroll
         for (int r = 0; r < R; r++) geometry_put(gi_[r], pj2[r], wave, lane, gbuf + r * GBUF_FLOATS);
-        SKEW(7)
         const float bmid = A.b_mid2[32 * wave + j];           // SWAP form: feature on the lane
         TS(13)
         // the next message's first layer always has its W_B stages (the edges are fresh)
@@ -1304,10 +1272,6 @@ static EdgeArgs edge_args(pp_ctx *c, int layer, bool edge) {
     A.N = c->N; A.K = c->K; A.inv_K = 1.0f / (float)c->K;
     A.n_pairs = 0;
     A.mix_mode = 0;
-    {
-        static const char *sk = PP_GETENV("PP_SKEW");
-        A.skew = sk ? atoi(sk) : -1;
-    }
     A.rmask = c->b.residue_mask;
     A.eidx = c->eidx; A.mask_att = c->mask_att; A.frames = c->frames;
     A.pts = edge ? c->ptsE : c->ptsN;

@@ -27,7 +27,7 @@
      defined(PP_X_CVT_SCALAR) || defined(PP_X_CVT_PK) || defined(PP_X_NU_NOMFMA) || defined(PP_X_NU_NOLOAD) ||                   \
      defined(PP_X_NOSAT) || defined(PP_X_NOMFMA) || defined(PP_X_NOACT) || defined(PP_X_E_NOMFMA) || defined(PP_X_CL_NOSCAN) ||  \
      defined(PP_X_CL_NOPAIR) || defined(PP_WDEPTH) || defined(PP_WDEPTH_R1) || defined(PP_NXB_R1) || defined(PP_WGS2) || defined(PP_WGS) ||               \
-     defined(PP_LDS_PAD) || defined(PP_NO_FUSE_NM) || defined(PP_NU_DEPTH) || defined(PP_X_CVT_PK_SITES) || defined(PP_X_SKEW))
+     defined(PP_LDS_PAD) || defined(PP_NO_FUSE_NM) || defined(PP_NU_DEPTH))
 #error "PP_X_* / tuning switches compile laboratory variants (most give wrong results): add -DPP_LAB and build a TAGGED library (python -m packppi_amd.build --tag NAME -DPP_LAB -DPP_X_...)"
 #endif
 #ifdef PP_DIAG

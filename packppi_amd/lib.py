@@ -367,8 +367,9 @@ class Context:
         return traj, last, losses
 
     def saturated(self) -> int:
-        """Sticky f16 saturation flag of this context: 0 = no hidden activation was ever clamped at 65504; bit 0 = in an
-        edge-level kernel, bit 1 = in a node-level kernel.  Waits for the stream."""
+        """Sticky flag word of this context: 0 = clean; bit 0 / bit 1 = a hidden activation was clamped at 65504 in an edge-level /
+        node-level kernel; bit 2 (value 4) = a NaN or infinity entered with the caller's tensors (the reference would return NaN, the
+        kernels' clamps return finite numbers that mean nothing).  Waits for the stream."""
         v = C.c_int(0)
         _check(load().pp_ctx_saturated(self.handle, C.byref(v), _stream(self.plan.device)), "pp_ctx_saturated")
         return int(v.value)

@@ -213,8 +213,9 @@ class TDiffusionModule:
         return self._context(batch).sample(SC_D_init, self.schedule, self.hparams.sample_cfg.mode, sde_noise)
 
     def saturated(self) -> int:
-        """Sticky f16 saturation flag of the context of the last batch (0 = clean; see lib.Context.saturated).  A non-zero
-        value means a hidden activation reached the f16 maximum: results are not fp32-equivalent for this checkpoint."""
+        """Sticky flag word of the context of the last batch (0 = clean; see lib.Context.saturated).  Bits 0 / 1: a hidden
+        activation reached the f16 maximum (results are not fp32-equivalent for this checkpoint); bit 2: a NaN / infinity entered
+        with the batch or the angles (the reference would return NaN)."""
         return self._ctx.saturated() if self._ctx is not None else 0
 
     def compute_rmsd(self, true_coords, pred_coords, atom_mask, residue_mask):

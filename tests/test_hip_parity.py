@@ -1058,6 +1058,39 @@ def test_weight_range_envelope_T1124():
             fh.write("\n".join(lines) + "\n")
 
 
+def test_nonfinite_input_is_flagged(weights):
+    """A NaN that enters with the caller's tensors is not laundered silently: the kernels' clamps (v_med3) return finite angles, the
+    reference would return NaN (layers.py:22-33 has no clamp) -- bit 2 of the sticky word says so (advisor / review, round 4)."""
+    from packppi_amd import synth
+    from packppi_amd.featurize import protein_to_batch
+    from packppi_amd.module import TDiffusionModule
+    b = protein_to_batch(synth.make_complex(64, 5)).to(DEV)
+    m = TDiffusionModule(weights, device=DEV)
+    m.schedule = torch.linspace(1, 0, 5)
+    g = torch.Generator().manual_seed(1)
+    chi = ((torch.rand(1, 64, 4, generator=g) * 2 - 1) * 3.0).to(DEV) * b.SC_D_mask
+    m.sample_from(b, chi)
+    assert m.saturated() == 0
+    bad = chi.clone()
+    bad[0, 17, 1] = float("nan")
+    m.network(b, bad, torch.full((64,), 0.5, device=DEV))
+    assert m.saturated() & 4
+    b2 = protein_to_batch(synth.make_complex(64, 5)).to(DEV)
+    b2["X"][0, 9, 1, 2] = float("inf")                      # a CA coordinate
+    m2 = TDiffusionModule(weights, device=DEV)
+    m2.schedule = m.schedule
+    m2.sample_from(b2, chi)
+    assert m2.saturated() & 4
+    b3 = protein_to_batch(synth.make_complex(64, 5)).to(DEV)
+    b3["residue_mask"][0, 9] = 0.0                          # an angle of a MASKED row is nobody's input
+    b3["X"][0, 9] = 0.0
+    chi3 = chi.clone()
+    chi3[0, 9, 0] = float("nan")
+    m3 = TDiffusionModule(weights, device=DEV)
+    m3.network(b3, chi3, torch.full((64,), 0.5, device=DEV))
+    assert m3.saturated() & 4 == 0
+
+
 def test_checkpoint_outside_the_f16_range(weights):
     """A checkpoint whose hidden activations pass 65504: the default (split-f16) library flags every such evaluation, and the
     exact-fp32 library (libpackppi_hip.f32.so: fp32 MFMA edge kernels, VALU node update; test_fp32_variant_library runs this
