@@ -78,10 +78,10 @@ def _run(args):
         for spec in args.scale or []:                      # name=factor: testing aid
             name, f = spec.split("=")
             sd[name] = sd[name] * float(f)
-        for spec in args.outlier or []:                    # name=value: the first eight entries of a bias set to `value` (testing aid:
-            name, f = spec.split("=")                      # a few huge rows are what the plan's rebalancing does NOT remove)
+        for spec in args.outlier or []:                    # name=factor: the first eight ROWS of a weight scaled (testing aid: a few
+            name, f = spec.split("=")                      # huge rows are what the plan's rebalancing does NOT remove)
             sd[name] = sd[name].clone()
-            sd[name][:8] = float(f)
+            sd[name][:8] *= float(f)
         model = TDiffusionModule(sd, device=dev)
     if args.input:
         from .pdb_io import from_pdb_file
@@ -143,7 +143,7 @@ def main(argv=None):
     p.add_argument("--steps", type=int, default=10, help="sampling steps run after the three network evaluations")
     p.add_argument("--seed", type=int, default=20251003)
     p.add_argument("--scale", action="append", help="NAME=FACTOR: scale one seeded weight (testing aid)")
-    p.add_argument("--outlier", action="append", help="NAME=VALUE: set the first eight entries of a seeded bias (testing aid)")
+    p.add_argument("--outlier", action="append", help="NAME=FACTOR: scale the first eight rows of one seeded weight (testing aid)")
     p.add_argument("--device", type=str, default="cuda:0")
     argv = sys.argv[1:] if argv is None else argv
     args = p.parse_args(argv)

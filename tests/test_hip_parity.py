@@ -1105,21 +1105,22 @@ def test_checkpoint_outside_the_f16_range(weights):
     g = torch.Generator().manual_seed(3)
     chi = (torch.rand(1, 96, 4, generator=g) * 2 - 1) * 3.0 * b.SC_D_mask
     t = torch.full((96,), 0.5)
-    # A few rows of a message MLP's first bias at 1e5: hidden activations of the EDGE kernels beyond 65504 (bit 0) that no exact
-    # rewrite removes (the rest of the layer is of ordinary size); node FFN / decoder weights scaled by 3e5: of the NODE kernels (bit
+    # Eight rows of a message MLP's first layer scaled by 3e5: hidden activations of the EDGE kernels beyond 65504 (bit 0) that no
+    # exact rewrite removes (the rest of the layer is of ordinary size: the median row sets the scale); node FFN / decoder weights scaled by 3e5: of the NODE kernels (bit
     # 1).  A single edge-level layer scaled by 3e5, or a LayerNorm gain of 4e4 in front of the edge FFN / of the next layer's message
     # MLPs, no longer saturates anything: the plan rebalances the ReLU chain (round 4) and scales the LayerNorm operand (round 5,
     # csrc/pp_rebalance.h) -- the default library then computes that checkpoint like the fp32 oracle does, which those cases hold it to.
-    cases = (("mpnn.mpnn_layers.1.edge_message_fn.W_in.bias", 1),
+    cases = (("mpnn.mpnn_layers.1.edge_message_fn.W_in.weight rows", 1),
              ("mpnn.mpnn_layers.2.node_dense.W_in.weight", 2), ("mpnn.mpnn_layers.0.node_dense.W_in.weight", 2),
              ("decoder_score.0.W_in.weight", 2),
              ("mpnn.mpnn_layers.1.norm.2.weight", 0), ("mpnn.mpnn_layers.0.norm.3.weight", 0),
              ("mpnn.mpnn_layers.1.edge_dense.W_in.weight", 0), ("mpnn.mpnn_layers.0.node_message_fn.W_in.weight", 0))
     for name, bit in cases:
         sd = dict(weights)
-        if name.endswith("bias"):
+        if name.endswith(" rows"):
+            name = name[:-5]
             sd[name] = weights[name].clone()
-            sd[name][:8] = 1e5
+            sd[name][:8] *= 3e5
         else:
             sd[name] = weights[name] * (4e4 if "norm" in name else 3e5)      # (a weight itself must stay inside the f16 range: pp_plan_create)
         m = TDiffusionModule(sd, device=DEV)
@@ -1149,7 +1150,7 @@ def test_f16_range_check_build():
     assert rep["total"] == 0 and rep["sticky_flag"] == 0, rep
     # events are reported per kernel family: only the edge kernels have an exact-fp32 replacement (libpackppi_hip.f32.so)
     # (a LayerNorm gain in front of the edge FFN: one edge-level LAYER scaled by 3e5 is rebalanced away when the plan is made)
-    rep = rangecheck.check(["--length", "96", "--steps", "3", "--outlier", "mpnn.mpnn_layers.1.edge_message_fn.W_in.bias=1e5"])
+    rep = rangecheck.check(["--length", "96", "--steps", "3", "--outlier", "mpnn.mpnn_layers.1.edge_message_fn.W_in.weight=3e5"])
     assert rep["network t=0.5"] > 1000 and rep["edge_kernels"] > 1000 and rep["sticky_flag"] & 1, rep
     rep = rangecheck.check(["--length", "96", "--steps", "3", "--scale", "mpnn.mpnn_layers.1.norm.2.weight=4e4"])       # covered since round 5
     assert rep["total"] == 0 and rep["sticky_flag"] == 0 and rep["ln_scaled_features"] == 128 and rep["uncovered_small_operands"] == [], rep
@@ -1170,12 +1171,13 @@ def test_default_library_remembers_a_saturated_activation(weights):
     m.schedule = torch.linspace(1, 0, 31)
     m.sampling(b)
     assert m.saturated() == 0
-    for name, bit in (("mpnn.mpnn_layers.1.edge_message_fn.W_in.bias", 1), ("mpnn.mpnn_layers.0.node_message_fn.W_in.bias", 1),
+    for name, bit in (("mpnn.mpnn_layers.1.edge_message_fn.W_in.weight rows", 1), ("mpnn.mpnn_layers.0.node_message_fn.W_in.weight rows", 1),
                       ("mpnn.mpnn_layers.2.node_dense.W_in.weight", 2), ("decoder_score.0.W_in.weight", 2)):
         sd = dict(weights)
-        if name.endswith("bias"):           # a few huge rows: nothing the plan could rebalance away
+        if name.endswith(" rows"):          # eight huge rows: nothing the plan could rebalance away
+            name = name[:-5]
             sd[name] = weights[name].clone()
-            sd[name][:8] = 1e5
+            sd[name][:8] *= 3e5
         else:
             sd[name] = weights[name] * 3e5
         ms = TDiffusionModule(sd, device=DEV)
