@@ -309,8 +309,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default=None, choices=["t1124", "s1500", "c5"],
-                    help="default: t1124 (BASELINE configs[1]) on one GPU, c5 (configs[4]: the 256 complexes sharded over the ranks) on several")
+    ap.add_argument("--workload", default=None, choices=["t1124", "s1500", "c5", "c5share"],
+                    help="default: t1124 (BASELINE configs[1]) on one GPU, c5 (configs[4]: the 256 complexes sharded over the ranks) on several; "
+                         "c5share = one GPU's share of configs[4] at 8 GPUs as one packed batch (the profiling workload of that regime)")
     ap.add_argument("--proximal", action="store_true", help="add the 50-step proximal optimisation (configs[2] / configs[3])")
     ap.add_argument("--cpu-steps", type=int, default=50, help="diffusion steps of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-grad-steps", type=int, default=4, help="steps of the autograd-on CPU sample (0 = skip)")
@@ -339,6 +340,10 @@ def main():
         from packppi_amd import synth
         from packppi_amd.parallel import shard_complexes
         c5_prot = c5_proteins(shard_complexes(synth.c5_lengths(256), world)[rank], max(1, min(cores, (os.cpu_count() or 1) // world)))
+    elif args.workload == "c5share":
+        from packppi_amd import synth
+        from packppi_amd.parallel import shard_complexes
+        c5_prot = c5_proteins(shard_complexes(synth.c5_lengths(256), 8)[rank % 8], max(1, min(cores, (os.cpu_count() or 1) // world)))
     elif want_secondary and world == 1 and args.workload == "t1124":
         c5_prot = c5_proteins(range(256), cores)          # the share AND the whole job on this GPU
     elif want_secondary:
@@ -433,6 +438,22 @@ def main():
         residues, one_pass, c5_last, complexes = c5_job(world, rank)
         name = ("BASELINE configs[4]: 256 synthetic complexes L~U{270..330} (default_rng(256)) sharded over the GPUs by "
                 "parallel.shard_complexes, packed ragged batches, per-complex metrics + all-gather of the metric rows inside the timed pass")
+    elif args.workload == "c5share":
+        # one GPU's share of configs[4] at 8 GPUs (32 complexes) as ONE packed ragged batch: the profiling workload of the throughput regime
+        from packppi_amd.batch import pack
+        _, share = c5_share(rank % 8, 8, dev, c5_prot)
+        ini = c5_inits(share, 1000 + rank)
+        init_d = torch.cat([ini[i][:, : c.true_residues()] for i, c in share.items()], 1).to(dev)
+        gb = pack(list(share.values()))
+        batch, init = None, None
+        residues = sum(c.true_residues() for c in share.values())
+        name = "BASELINE configs[4], one GPU's share at 8 GPUs: 32 synthetic complexes L~U{270..330} as one packed ragged batch"
+        ctx = Context(model._plan, gb)
+        if args.proximal:
+            raise SystemExit("--proximal with --workload c5share: use the per-complex workloads")
+
+        def one_pass():
+            return Context(model._plan, gb).sample(init_d, model.schedule)
     else:
         batch, init, ref_chi = load_t1124() if args.workload == "t1124" else load_s1500()
         name = {"t1124": "data/T1124_lig.pdb (L=739, 738 true residues), 1 complex per GPU",
@@ -455,7 +476,11 @@ def main():
     total_res = allsum(residues)
 
     # per-complex metric rows: the one real collective of the path (RCCL all-gather of fixed-width rows)
-    if complexes is None:
+    if complexes is None and batch is None:
+        atom_rmsd, row = None, torch.zeros(13, device=dev)
+        rows = [row]
+        ranks_seen, rows_gathered = 1, 0
+    elif complexes is None:
         m = model.analyze_samples(gb, chi)
         row = torch.stack([torch.as_tensor(float(v), device=dev) for v in m.values()]).float()
         atom_rmsd = float(m["atom_rmsd"])
@@ -486,7 +511,7 @@ def main():
     secondary = None
     regimes = {}
     prox_roof = None
-    if want_secondary:
+    if want_secondary and args.workload != "c5share":
         secondary = []
 
         def single_entry(tag, label, b_, init_, ref_, proximal, fixture, regime=None):
@@ -605,7 +630,8 @@ def main():
         t_node = insitu["k_node_message"][0] * 1e-3
         t_nu = insitu["k_node_update"][0] * 1e-3
         n_edges = residues * ctx.K
-        regimes[args.workload] = regime_entry(args.workload, residues, ctx.K, t_edge, insitu["k_edge_update"][1], counters)
+        regimes["c5" if args.workload == "c5share" else args.workload] = regime_entry("c5" if args.workload == "c5share" else args.workload,
+                                                                                     residues, ctx.K, t_edge, insitu["k_edge_update"][1], counters)
         # k_edge_update(l) also computes the node message of layer l + 1 (fused): its algorithmic work is both MLP chains
         # of the reference (layers.py:119-148), 2 FLOP per MAC of the dense layers, per edge.  Executed MFMA work is lower:
         # layer 0's W_B h_E0 products are timestep-invariant and computed once per complex.
@@ -706,7 +732,7 @@ def main():
             out["roofline"] = roof
         if secondary is not None:
             out["secondary"] = secondary
-        if args.cpu_steps > 0 and args.gpus == 1 and complexes is None:
+        if args.cpu_steps > 0 and args.gpus == 1 and complexes is None and batch is not None:
             out["cpu_baseline"] = cpu_baseline(batch, init, weights, args.cpu_steps, args.cpu_grad_steps)
         out["summary"] = make_summary(out)          # LAST key: a flat digest that survives a 2 000-character tail
         print(json.dumps(out), flush=True)

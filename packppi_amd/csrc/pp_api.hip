@@ -492,6 +492,28 @@ extern "C" pp_status pp_plan_create(const float *weights, size_t n_weights, cons
     if ((st = upload(&p->atom14_mask, tables->atom14_mask, 21 * 14)) != PP_OK) return st;
     if ((st = upload(&p->lit_positions, tables->lit_positions, 21 * 14 * 3)) != PP_OK) return st;
     if ((st = upload(&p->between_radius, tables->between_radius, 21 * 14)) != PP_OK) return st;
+    {
+        // How far a side-chain atom can get from its CA whatever the chi angles are: the atom sits at chain(lit) in the backbone
+        // frame (origin CA), the chain composes default frames and rotations about x, a rotation keeps the norm and a frame adds at
+        // most the length of its translation: |atom - CA| <= |lit| + sum of |t_k| over the frames of its chain (features.py:95-194).
+        // Rigorous, about 15 % above the true maximum; the proximal loop's static partner lists are built from it (pp_clash.hip).
+        float ext[21];
+        for (int S = 0; S < 21; S++) {
+            float m = 0.f;
+            for (int a = 4; a < 14; a++) {
+                if (tables->atom14_mask[S * 14 + a] == 0.f) continue;
+                const float *lp = tables->lit_positions + (S * 14 + a) * 3;
+                float b = std::sqrt(lp[0] * lp[0] + lp[1] * lp[1] + lp[2] * lp[2]);
+                const int g = tables->atom14_to_group[S * 14 + a];
+                auto tlen = [&](int k) { const float *f = tables->default_frames + ((size_t)S * 8 + k) * 16; return std::sqrt(f[3] * f[3] + f[7] * f[7] + f[11] * f[11]); };
+                if (g >= 4) for (int k = 4; k <= g; k++) b += tlen(k);
+                else b += tlen(g);
+                m = std::max(m, b);
+            }
+            ext[S] = m * 1.0001f + 1e-3f;
+        }
+        if ((st = upload(&p->side_extent, ext, 21)) != PP_OK) return st;
+    }
     PP_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&p->bounds_lower), 21 * 14 * 14 * sizeof(float)));
     PP_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&p->bounds_upper), 21 * 14 * 14 * sizeof(float)));
     p->clash_params_set = false;
@@ -502,7 +524,7 @@ extern "C" pp_status pp_plan_create(const float *weights, size_t n_weights, cons
 extern "C" void pp_plan_destroy(pp_plan *p) {
     if (!p) return;
     void *ptrs[] = {p->w, p->wT, p->default_frames, p->atom14_to_group, p->atom14_mask, p->lit_positions,
-                    p->between_radius, p->bounds_lower, p->bounds_upper, p->ln_scale};
+                    p->between_radius, p->bounds_lower, p->bounds_upper, p->ln_scale, p->side_extent};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     for (const ArenaSlot &sl : p->arena_pool) {
         (void)hipFree(sl.p);
@@ -680,6 +702,7 @@ static pp_status prepare_impl(pp_plan *plan, const pp_batch *b, const int32_t *s
     }
     ALLOC(xyz, N * 42); ALLOC(rec, N * 64); ALLOC(axes, N * 24); ALLOC(brad, N); ALLOC(per_res, N); ALLOC(dchi, N * 4);
     ALLOC(px, N * 4); ALLOC(pm, N * 4); ALLOC(pv, N * 4); ALLOC(pz, N * 4); ALLOC(pxeff, N * 4); ALLOC(pmask, N);
+    if (c->B == 1) { ALLOC(cand, (size_t)N * 4 * PP_CL_CAP); ALLOC(cand_cnt, N * 4); }      // the proximal loop is defined for one complex (optimize.py:27)
     ALLOC(scal, 64);
     ALLOC(sat, 4);
     ALLOC(seg, N);

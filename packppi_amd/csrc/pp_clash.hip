@@ -272,11 +272,16 @@ k_atom14(int N, const float *__restrict__ X, const int64_t *__restrict__ rtype,
 #endif
 #define CL_MAXC (8192 / CL_WAVES)     // candidate list capacity per wave (entries beyond are handled by re-scanning)
 
+// CAND (the Adam loop of pp_proximal): the partner residues come from the static candidate lists k_clash_cand built once for the
+// whole loop instead of a scan over all L partners of the complex at every step -- the lists hold every residue pair whose hinge can
+// be non-zero for ANY chi (the backbone does not move), in the order and under the wave assignment of the scan, and the exact
+// per-step sphere test still runs on them: the atom pairs that contribute are the same, every contribution is the same number.
+template <bool CAND>
 __global__ void __launch_bounds__(64 * CL_WAVES)
 k_clash(int N, const int2 *__restrict__ seg, const float *__restrict__ xyz, const float4 *__restrict__ rec, const float *__restrict__ exists,
         const float *__restrict__ lower, const float *__restrict__ upper, const int32_t *__restrict__ a2g,
         const float *__restrict__ axes, float tol, float inv_ntot,
-        float *__restrict__ per_res, float *__restrict__ dchi) {
+        float *__restrict__ per_res, float *__restrict__ dchi, const int32_t *__restrict__ cand, const int32_t *__restrict__ cand_cnt) {
     __shared__ int s_list[CL_WAVES][CL_MAXC];
     __shared__ float s_red[CL_WAVES][16][4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -306,29 +311,54 @@ k_clash(int N, const int2 *__restrict__ seg, const float *__restrict__ xyz, cons
 
     float loss_a = 0.f, ga[3] = {0.f, 0.f, 0.f};
     int *list = s_list[wave];
-    // partner residues of the same complex, in windows that fit the candidate list
-    for (int base = 64 * wave; base < L; ) {
+    int n_static = -1;
+    if constexpr (CAND) n_static = cand_cnt[(size_t)i * CL_WAVES + wave];
+    const int32_t *my_cand = CAND ? cand + ((size_t)i * CL_WAVES + wave) * PP_CL_CAP : nullptr;
+    // partner residues of the same complex: from the static candidates (one pass), or in windows that fit the candidate list
+    const bool use_static = CAND && n_static >= 0;
+    bool more = true;
+    for (int base = 64 * wave; use_static ? more : base < L; ) {
         int cnt = 0;
         int jscan = base;
-#ifdef PP_X_CL_NOSCAN      // timing experiment: no candidate scan (and hence no pairs)
-        jscan = L;
-#endif
-        for (; jscan < L && cnt + 64 <= CL_MAXC; jscan += 64 * CL_WAVES) {
-            int jl = jscan + lane;
-            bool keep = false;
-            if (jl < L) {
-                int jg = row0 + jl;
-                if (jg != i) {
+        if (use_static) {
+            // the static candidates of this wave (ascending, at most PP_CL_CAP <= CL_MAXC): the exact sphere test on each, compacted in order
+            for (int c0 = 0; c0 < n_static; c0 += 64) {
+                const int ci = c0 + lane;
+                bool keep = false;
+                int jg = 0;
+                if (ci < n_static) {
+                    jg = my_cand[ci];
                     const float4 cj = rec[(size_t)jg * 16 + 14];
-                    const float4 mj = rec[(size_t)jg * 16 + 15];
                     float dx = cj.x - cai[0], dy = cj.y - cai[1], dz = cj.z - cai[2];
                     float lim = radi + cj.w + reach;
-                    keep = (lim > 0.f) && (dx * dx + dy * dy + dz * dz < lim * lim) && (__float_as_int(mj.y) != ri);
+                    keep = (lim > 0.f) && (dx * dx + dy * dy + dz * dz < lim * lim);
                 }
+                unsigned long long bal = __ballot(keep);
+                if (keep) list[cnt + __popcll(bal & ((1ull << lane) - 1ull))] = jg;
+                cnt += __popcll(bal);
             }
-            unsigned long long bal = __ballot(keep);
-            if (keep) list[cnt + __popcll(bal & ((1ull << lane) - 1ull))] = row0 + jl;
-            cnt += __popcll(bal);
+            more = false;
+        } else {
+#ifdef PP_X_CL_NOSCAN      // timing experiment: no candidate scan (and hence no pairs)
+            jscan = L;
+#endif
+            for (; jscan < L && cnt + 64 <= CL_MAXC; jscan += 64 * CL_WAVES) {
+                int jl = jscan + lane;
+                bool keep = false;
+                if (jl < L) {
+                    int jg = row0 + jl;
+                    if (jg != i) {
+                        const float4 cj = rec[(size_t)jg * 16 + 14];
+                        const float4 mj = rec[(size_t)jg * 16 + 15];
+                        float dx = cj.x - cai[0], dy = cj.y - cai[1], dz = cj.z - cai[2];
+                        float lim = radi + cj.w + reach;
+                        keep = (lim > 0.f) && (dx * dx + dy * dy + dz * dz < lim * lim) && (__float_as_int(mj.y) != ri);
+                    }
+                }
+                unsigned long long bal = __ballot(keep);
+                if (keep) list[cnt + __popcll(bal & ((1ull << lane) - 1ull))] = row0 + jl;
+                cnt += __popcll(bal);
+            }
         }
         base = jscan;
         __builtin_amdgcn_wave_barrier();
@@ -445,6 +475,64 @@ k_clash(int N, const int2 *__restrict__ seg, const float *__restrict__ xyz, cons
 }
 
 // ---------------------------------------------------------------------------------------------
+// static clash-partner candidates of the proximal loop: once per pp_proximal
+// ---------------------------------------------------------------------------------------------
+// The Adam loop moves side chains, never the backbone.  An atom of residue i can only ever overlap an atom of residue j if
+//   |CA_i - CA_j| < e_i + e_j + (3.6 - tol)      e = how far an atom of the residue can be from its CA for ANY chi:
+// the side-chain bound of the residue type (plan->side_extent) or the actual distance of its N / C / O, whichever is larger.  Every
+// other pair has a zero hinge at every step, so k_clash<true> need not look at it: instead of scanning the L partners of the
+// complex at every step (O(L^2) sphere tests per launch: 98 % of them culled at T1124, 99 % at S1500) a wave reads its few dozen
+// candidates.  Same workgroup shape and wave / window assignment as the scan of k_clash: wave w of residue i's workgroup gets the
+// partners of windows 64 w + 256 m, ascending; more than PP_CL_CAP of them and the wave keeps the full scan (count -1).
+__global__ void __launch_bounds__(64 * CL_WAVES)
+k_clash_cand(int N, const int2 *__restrict__ seg, const float *__restrict__ X, const float *__restrict__ amask, const int64_t *__restrict__ rtype,
+             const int64_t *__restrict__ rindex, const float *__restrict__ side_extent, float tol,
+             int32_t *__restrict__ cand, int32_t *__restrict__ cand_cnt) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = blockIdx.x;
+    if (i >= N) return;
+    const int row0 = seg[i].x, L = seg[i].y;
+    auto extent = [&](int n, float (&ca)[3]) {
+        const float *x = X + (size_t)n * 42;
+        ca[0] = x[3]; ca[1] = x[4]; ca[2] = x[5];
+        float e = side_extent[(int)rtype[n]];
+        const float *m = amask + (size_t)n * 14;
+#pragma unroll
+        for (int a = 0; a < 4; a++) {
+            if (a == 1 || m[a] == 0.f) continue;
+            const float dx = x[3 * a] - ca[0], dy = x[3 * a + 1] - ca[1], dz = x[3 * a + 2] - ca[2];
+            e = fmaxf(e, sqrtf(dx * dx + dy * dy + dz * dz) * 1.0001f + 1e-3f);
+        }
+        return e;
+    };
+    float cai[3];
+    const float ei = extent(i, cai);
+    const int ri = (int)rindex[i];
+    const float reach = 3.6f - tol;
+    int32_t *out = cand + ((size_t)i * CL_WAVES + wave) * PP_CL_CAP;
+    int cnt = 0;
+    for (int jscan = 64 * wave; jscan < L; jscan += 64 * CL_WAVES) {
+        const int jl = jscan + lane;
+        bool keep = false;
+        if (jl < L) {
+            const int jg = row0 + jl;
+            if (jg != i && (int)rindex[jg] != ri) {
+                float caj[3];
+                const float ej = extent(jg, caj);
+                const float dx = caj[0] - cai[0], dy = caj[1] - cai[1], dz = caj[2] - cai[2];
+                const float lim = ei + ej + reach;
+                keep = lim > 0.f && dx * dx + dy * dy + dz * dz < lim * lim;
+            }
+        }
+        const unsigned long long bal = __ballot(keep);
+        const int at = cnt + __popcll(bal & ((1ull << lane) - 1ull));
+        if (keep && at < PP_CL_CAP) out[at] = row0 + jl;
+        cnt += __popcll(bal);
+    }
+    if (lane == 0) cand_cnt[(size_t)i * CL_WAVES + wave] = cnt <= PP_CL_CAP ? cnt : -1;
+}
+
+// ---------------------------------------------------------------------------------------------
 // proximal optimiser pieces (B = 1)
 // ---------------------------------------------------------------------------------------------
 // mean of per_res -> scal[0]; mask[n] = per_res[n] > mean; z = chi*mask; x = z; m = v = 0; xeff = chi
@@ -501,12 +589,18 @@ pp_status pp_launch_atom14(pp_ctx *c, const float *chi, float *xyz, hipStream_t 
     return PP_OK;
 }
 
-pp_status pp_launch_clash(pp_ctx *c, const float *xyz, float *per_res, float *dchi, hipStream_t s) {
+pp_status pp_launch_clash(pp_ctx *c, const float *xyz, float *per_res, float *dchi, hipStream_t s, bool use_candidates) {
     const pp_plan *p = c->plan;
-    PP_LAUNCH(c, k_clash, dim3(c->N), dim3(64 * CL_WAVES), 0, s, c->N, c->seg, xyz,
-              reinterpret_cast<const float4 *>(c->rec), c->b.atom_mask,
-              p->bounds_lower, p->bounds_upper, p->atom14_to_group, c->axes, p->clash_tol,
-              1.0f / (float)c->N, per_res, dchi);
+    if (use_candidates && c->cand)
+        PP_LAUNCH(c, k_clash<true>, dim3(c->N), dim3(64 * CL_WAVES), 0, s, c->N, c->seg, xyz,
+                  reinterpret_cast<const float4 *>(c->rec), c->b.atom_mask,
+                  p->bounds_lower, p->bounds_upper, p->atom14_to_group, c->axes, p->clash_tol,
+                  1.0f / (float)c->N, per_res, dchi, c->cand, c->cand_cnt);
+    else
+        PP_LAUNCH(c, k_clash<false>, dim3(c->N), dim3(64 * CL_WAVES), 0, s, c->N, c->seg, xyz,
+                  reinterpret_cast<const float4 *>(c->rec), c->b.atom_mask,
+                  p->bounds_lower, p->bounds_upper, p->atom14_to_group, c->axes, p->clash_tol,
+                  1.0f / (float)c->N, per_res, dchi, nullptr, nullptr);
     PP_HIP_CHECK(hipGetLastError());
     return PP_OK;
 }
@@ -515,9 +609,14 @@ pp_status pp_launch_proximal(pp_ctx *c, const float *chi, float lamda, int nstep
                              float *losses, hipStream_t s) {
     pp_status st;
     const pp_plan *p = c->plan;
+    // static partner candidates of the whole loop (the backbone does not move): k_clash<true> reads them instead of scanning
+    const bool cands = c->cand != nullptr;
+    if (cands)
+        hipLaunchKernelGGL(k_clash_cand, dim3(c->N), dim3(64 * CL_WAVES), 0, s, c->N, c->seg, c->b.X, c->b.atom_mask, c->b.residue_type,
+                           c->b.residue_index, p->side_extent, p->clash_tol, c->cand, c->cand_cnt);
     // clash mask at the incoming angles (optimize.py:5-18)
     if ((st = pp_launch_atom14(c, chi, c->xyz, s)) != PP_OK) return st;
-    if ((st = pp_launch_clash(c, c->xyz, c->per_res, nullptr, s)) != PP_OK) return st;
+    if ((st = pp_launch_clash(c, c->xyz, c->per_res, nullptr, s, cands)) != PP_OK) return st;
     hipLaunchKernelGGL(k_prox_init, dim3(1), dim3(1024), 0, s, c->N, c->per_res, chi, c->pmask, c->pz, c->px, c->pm,
                        c->pv, c->pxeff);
     // Per Adam step two launches: [step t on the block's residues + reconstruction at the new angles] and [clash + gradient
@@ -525,7 +624,7 @@ pp_status pp_launch_proximal(pp_ctx *c, const float *chi, float lamda, int nstep
     const int nblocks = (c->N + 15) / 16;
     float4 *rec = reinterpret_cast<float4 *>(c->rec);
     if ((st = pp_launch_atom14(c, c->pxeff, c->xyz, s)) != PP_OK) return st;
-    if ((st = pp_launch_clash(c, c->xyz, c->per_res, c->dchi, s)) != PP_OK) return st;
+    if ((st = pp_launch_clash(c, c->xyz, c->per_res, c->dchi, s, cands)) != PP_OK) return st;
     for (int t = 0; t < nsteps; t++) {
         const double bc1 = 1.0 - pow(0.9, (double)(t + 1)), bc2 = 1.0 - pow(0.999, (double)(t + 1));
         ProxUpd U;
@@ -547,7 +646,7 @@ pp_status pp_launch_proximal(pp_ctx *c, const float *chi, float lamda, int nstep
             hipLaunchKernelGGL(k_prox_losses, dim3(1), dim3(64), 0, s, U.t + 1, nblocks, U.inv_n, c->prox_part, losses + (t - U.t));
         if (t + 1 < nsteps) {
             c->prof_armed = c->prof_which == 3;      // pp_profile_kernel(3): the clash loss + gradient of the Adam loop
-            st = pp_launch_clash(c, c->xyz, c->per_res, c->dchi, s);
+            st = pp_launch_clash(c, c->xyz, c->per_res, c->dchi, s, cands);
             c->prof_armed = false;
             if (st != PP_OK) return st;
         }

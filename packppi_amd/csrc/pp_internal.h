@@ -40,6 +40,7 @@
 #define PP_MSG_IN 456     // message MLP input width
 #define PP_NPTS 8         // invariant points per node
 #define PP_PROX_CHUNK 64   // proximal steps whose loss terms are parked before one reduction
+#define PP_CL_CAP 96       // static clash-partner candidates kept per (residue, wave) -- k_clash_cand / k_clash<true>
 
 #include "pp_weights.h"      // LayerOff / WeightOff / pp_weight_offsets(): offsets into the concatenated weight buffer
 
@@ -105,6 +106,7 @@ struct pp_plan {
     float *atom14_mask;       // [21][14]
     float *lit_positions;     // [21][14][3]
     float *between_radius;    // [21][14]
+    float *side_extent;       // [21] upper bound of |side-chain atom - CA| over all chi, per residue type (pp_api.hip clash_extents)
     float *bounds_lower, *bounds_upper;   // [21][14][14]
     float clash_tol;
     bool clash_params_set;
@@ -156,6 +158,8 @@ struct pp_ctx {
     float *dchi;              // [N][4]
     float *px, *pm, *pv, *pz, *pxeff;   // proximal: param, Adam moments, anchor, effective chi  [N][4]
     uint8_t *pmask;           // [N]
+    int32_t *cand;            // [N][4][PP_CL_CAP] proximal: static clash-partner candidates of every (residue, wave of its workgroup)
+    int32_t *cand_cnt;        // [N][4] their number, -1 = more than PP_CL_CAP (that wave scans all partners as before)
     float *prox_part;         // [PP_PROX_CHUNK][ceil(N / 16)] per-block loss terms of the proximal steps
     float *scal;              // small scalar scratch
     unsigned *sat;            // sticky word: bit 0 = an edge kernel, bit 1 = a node kernel clamped a hidden activation at 65504
@@ -283,7 +287,7 @@ pp_status pp_launch_node_message(pp_ctx *c, int layer, hipStream_t s);
 bool pp_edge_fused();            // does pp_launch_edge_update also compute the next layer's node message?
 pp_status pp_launch_edge_update(pp_ctx *c, int layer, hipStream_t s);   // + node message of layer + 1
 pp_status pp_launch_atom14(pp_ctx *c, const float *chi, float *xyz, hipStream_t s);
-pp_status pp_launch_clash(pp_ctx *c, const float *xyz, float *per_res, float *dchi, hipStream_t s);
+pp_status pp_launch_clash(pp_ctx *c, const float *xyz, float *per_res, float *dchi, hipStream_t s, bool use_candidates = false);
 pp_status pp_launch_proximal(pp_ctx *c, const float *chi, float lamda, int nsteps, float *traj,
                              float *chi_last, float *losses, hipStream_t s);
 

@@ -10,6 +10,6 @@ cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o run -- python3 $ROOT/bench.py --workload $WL $EXTRA --steps 2 --warmup 1 --cpu-steps 0 --no-secondary > $OUT/bench.json 2> $OUT/err.txt
 cd $ROOT
 f=$(find $OUT -name "*kernel_stats.csv" | head -1)
-cp $f gpurun_out/${GRAFT_ROUND:-r04}_${TAG}_kernel_stats_$SUF.csv
+cp $f gpurun_out/${GRAFT_ROUND:-r05}_${TAG}_kernel_stats_$SUF.csv
 find $OUT -type f ! -name "bench.json" -delete
-head -8 gpurun_out/${GRAFT_ROUND:-r04}_${TAG}_kernel_stats_$SUF.csv | cut -c1-150
+head -8 gpurun_out/${GRAFT_ROUND:-r05}_${TAG}_kernel_stats_$SUF.csv | cut -c1-150

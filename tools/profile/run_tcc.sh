@@ -27,7 +27,7 @@ for f in sorted(glob.glob(sys.argv[1] + "/p*/**/*counter_collection.csv", recurs
             out[k.replace("void ", "")] = {"launches": cnt[(k, "TCC_REQ_sum")], "l2_requests": d.get("TCC_REQ_sum", 0), "l2_hits": d.get("TCC_HIT_sum", 0),
                                            "l2_misses": d.get("TCC_MISS_sum", 0), "l2_hit_rate": hit,
                                            "l2_request_bytes": 128.0 * d.get("TCC_REQ_sum", 0)}
-tag = os.environ.get("PROFILE_TAG", "r04_v2")
+tag = os.environ.get("PROFILE_TAG", "r05_v1")
 json.dump({"command": "rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum -- python3 bench.py --workload %s --steps 1 --warmup 1 --cpu-steps 0 --no-secondary" % sys.argv[2],
            "request_size_bytes": 128, "kernels": out}, open(os.path.join("profiles", "%s_tcc_%s.json" % (tag, sys.argv[2])), "w"), indent=1)
 PY

@@ -12,7 +12,7 @@ import os
 import sys
 from collections import defaultdict
 
-ROUND = os.environ.get("GRAFT_ROUND", "r04")
+ROUND = os.environ.get("GRAFT_ROUND", "r05")
 
 
 def short(name):
