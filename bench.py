@@ -317,7 +317,13 @@ def main():
     ap.add_argument("--cpu-grad-steps", type=int, default=4, help="steps of the autograd-on CPU sample (0 = skip)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the other BASELINE configs (`secondary` list)")
     ap.add_argument("--no-roofline", action="store_true", help="skip the in-situ kernel timing passes (child runs)")
+    ap.add_argument("--build-workers", type=int, default=0, help="processes that build the synthetic complexes (0 = this box's CPU share; the "
+                    "profiling scripts pass 1: no fork under rocprofv3's preloaded library)")
+    ap.add_argument("--diffusion-steps", type=int, default=100, help="network evaluations per pass (the metric is DEFINED at 100; counter passes "
+                    "under rocprofv3 --pmc use a handful: per-launch figures are the same)")
     args = ap.parse_args()
+    global N_DIFFUSION_STEPS
+    N_DIFFUSION_STEPS = args.diffusion_steps
 
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
@@ -335,6 +341,8 @@ def main():
     want_secondary = not args.no_secondary and not args.proximal
     # ---- host-side inputs that take a process pool: BEFORE anything touches the GPU (forked workers) -----------------------
     cores = min(16, os.cpu_count() or 1)
+    if args.build_workers > 0:
+        cores = args.build_workers
     c5_prot = {}
     if args.workload == "c5":
         from packppi_amd import synth

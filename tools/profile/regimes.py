@@ -52,8 +52,8 @@ def main(out):
         e["other_instances"] = others
         regimes[key] = e
     path = os.path.join(ROOT, "profiles", tag + "_regimes.json")
-    json.dump({"command": "rocprofv3 --pmc <SQ set | TCC set> -- python3 bench.py --workload W --steps 1 --warmup 1 --cpu-steps 0 --no-secondary --no-roofline "
-                          "(HIP_FORCE_DEV_KERNARG=1 exported first); tools/profile/run_regimes.sh",
+    json.dump({"command": "rocprofv3 --pmc <SQ set | TCC set> -- python3 bench.py --workload W --steps 1 --warmup 0 --cpu-steps 0 --no-secondary --no-roofline "
+                          "--diffusion-steps 6 (HIP_FORCE_DEV_KERNARG=1 exported first); tools/profile/run_regimes.sh",
                "regimes": regimes}, open(path, "w"), indent=1)
     print(json.dumps({k: {"mfma_busy": round(v["mfma_busy"], 3), "l2_MB": round(v.get("l2_request_bytes", 0) / 1e6, 1)} for k, v in regimes.items()}))
 

@@ -6,6 +6,7 @@ set -e
 export GRAFT_ROUND=${GRAFT_ROUND:-r05}
 export PROFILE_TAG=${PROFILE_TAG:-${GRAFT_ROUND}_v1}
 V=${PROFILE_TAG#${GRAFT_ROUND}_}
+if [ -z "$RESUME_AT_REGIMES" ]; then
 bash tools/profile/run_profiles.sh $V > gpurun_out/set_profiles.log 2>&1
 echo profiles done
 bash tools/profile/run_tcc.sh t1124 > gpurun_out/set_tcc.log 2>&1
@@ -14,6 +15,7 @@ bash tools/profile/run_sq.sh > gpurun_out/${PROFILE_TAG}_sq_counters.txt 2> gpur
 bash tools/profile/run_sq_workload.sh c5share > gpurun_out/${PROFILE_TAG}_sq_c5.txt 2>> gpurun_out/set_sq.err
 bash tools/profile/run_sq_workload.sh s1500 > gpurun_out/${PROFILE_TAG}_sq_s1500.txt 2>> gpurun_out/set_sq.err
 echo sq done
+fi
 bash tools/profile/run_regimes.sh > gpurun_out/set_regimes.log 2>&1       # MFMA-busy + L2 requests per regime -> profiles/<tag>_regimes.json (bench.py reads it)
 echo regimes done
 bash tools/profile/run_stats_workload.sh $V s1500 > gpurun_out/set_stats_s1500.log 2>&1

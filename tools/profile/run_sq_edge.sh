@@ -7,7 +7,7 @@ ROOT=$(pwd); OUT=$ROOT/gpurun_out/sqe_$W; mkdir -p $OUT
 export TMPDIR=/tmp
 export HIP_FORCE_DEV_KERNARG=${HIP_FORCE_DEV_KERNARG:-1}      # before rocprofv3 starts (its preloaded library initialises the HIP runtime ahead of python)
 cd /tmp
-BENCH="python3 $ROOT/bench.py --workload $W --steps 1 --warmup 1 --cpu-steps 0 --no-secondary --no-roofline"
+BENCH="python3 $ROOT/bench.py --workload $W --steps 1 --warmup 1 --cpu-steps 0 --no-secondary --build-workers 1 --no-roofline"
 i=0
 for SET in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAVES" \
            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC" \
@@ -19,7 +19,7 @@ done
 cd $ROOT; find $OUT -type f ! -name "*counter_collection.csv" ! -name "*.err" -delete
 python3 - "$OUT" > gpurun_out/$NAME.txt <<'PY'
 import csv, glob, collections, sys
-print("# rocprofv3 --pmc <set> -- python3 bench.py --workload W --steps 1 --warmup 1 --cpu-steps 0 --no-secondary --no-roofline; mean per launch")
+print("# rocprofv3 --pmc <set> -- python3 bench.py --workload W --steps 1 --warmup 1 --cpu-steps 0 --no-secondary --build-workers 1 --no-roofline; mean per launch")
 for f in sorted(glob.glob(sys.argv[1] + "/p*/**/*counter_collection.csv", recursive=True)):
     agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
     for r in csv.DictReader(open(f)):

@@ -6,7 +6,7 @@ ROOT=$(pwd); OUT=$ROOT/gpurun_out/sqw_$W; mkdir -p $OUT
 export TMPDIR=/tmp
 export HIP_FORCE_DEV_KERNARG=${HIP_FORCE_DEV_KERNARG:-1}      # before rocprofv3 starts: its preloaded library initialises the HIP runtime ahead of python (packppi_amd/__init__.py would set it too late)
 cd /tmp
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_MFMA SQ_WAVES --output-format csv -d $OUT -o run -- python3 $ROOT/bench.py --steps 1 --warmup 1 --cpu-steps 0 --no-secondary --workload $W > $OUT/bench.json 2> $OUT/err.txt
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_MFMA SQ_WAVES --output-format csv -d $OUT -o run -- python3 $ROOT/bench.py --steps 1 --warmup 1 --cpu-steps 0 --no-secondary --build-workers 1 --workload $W > $OUT/bench.json 2> $OUT/err.txt
 cd $ROOT
 python3 - "$OUT" <<'PY'
 import csv, glob, collections, sys
