@@ -610,7 +610,8 @@ pp_status pp_launch_proximal(pp_ctx *c, const float *chi, float lamda, int nstep
     pp_status st;
     const pp_plan *p = c->plan;
     // static partner candidates of the whole loop (the backbone does not move): k_clash<true> reads them instead of scanning
-    const bool cands = c->cand != nullptr;
+    static const char *scan_env = PP_GETENV("PP_CLASH_SCAN");          // diagnostic builds: 1 = the per-step scan of all partners (A/B)
+    const bool cands = c->cand != nullptr && !(scan_env && atoi(scan_env));
     if (cands)
         hipLaunchKernelGGL(k_clash_cand, dim3(c->N), dim3(64 * CL_WAVES), 0, s, c->N, c->seg, c->b.X, c->b.atom_mask, c->b.residue_type,
                            c->b.residue_index, p->side_extent, p->clash_tol, c->cand, c->cand_cnt);
