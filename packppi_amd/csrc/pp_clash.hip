@@ -339,9 +339,6 @@ k_clash(int N, const int2 *__restrict__ seg, const float *__restrict__ xyz, cons
             }
             more = false;
         } else {
-#ifdef PP_X_CL_NOSCAN      // timing experiment: no candidate scan (and hence no pairs)
-            jscan = L;
-#endif
             for (; jscan < L && cnt + 64 <= CL_MAXC; jscan += 64 * CL_WAVES) {
                 int jl = jscan + lane;
                 bool keep = false;
@@ -362,9 +359,6 @@ k_clash(int N, const int2 *__restrict__ seg, const float *__restrict__ xyz, cons
         }
         base = jscan;
         __builtin_amdgcn_wave_barrier();
-#ifdef PP_X_CL_NOPAIR      // timing experiment: candidate scan only
-        cnt = 0;
-#endif
         for (int c = slot; c < cnt; c += 4) {
             const int jg = list[c];
             // all of the partner's records first, unconditionally: inside the branches below the compiler may not hoist them,

@@ -36,11 +36,7 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 #define PARAM_FLOATS 1152               // edge kernel: small per-layer vectors staged once
 
 // Timing-only ablation switch (tools/debug/ablate_edge.py); never defined in a shipped build.
-#ifdef PP_X_NOMFMA
-#define MFMA(a, b, c) ((c) + (a) * (b))
-#else
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
-#endif
 
 struct EdgeArgs {
     int N, K;
@@ -400,11 +396,7 @@ template <int S, bool ST0, bool FUSE>
 __global__ void __launch_bounds__(ET, PP_EU_WGS)
 k_edge_update(EdgeArgs A) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-#ifdef PP_X_PRM_ALIAS          // timing only: params alias the exchange buffer (wrong results) to test an 80 KB footprint
-    float *xbuf = smem + 4 * S * 1024, *prm = xbuf;
-#else
     float *xbuf = smem + 4 * S * 1024, *prm = xbuf + XBUF_FLOATS;
-#endif
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, h = lane >> 5;
@@ -649,11 +641,7 @@ static EdgeArgs edge_args(pp_ctx *c, int layer, bool edge) {
 }
 
 static const size_t NM_SMEM = (4 * PP_NM_SLOTS * 1024 + XBUF_FLOATS) * sizeof(float);
-#ifdef PP_X_PRM_ALIAS
-static const size_t EU_SMEM = (4 * PP_EU_SLOTS * 1024 + XBUF_FLOATS) * sizeof(float);
-#else
 static const size_t EU_SMEM = (4 * PP_EU_SLOTS * 1024 + XBUF_FLOATS + PARAM_FLOATS) * sizeof(float);
-#endif
 static const size_t ST_SMEM = (4 * 2 * 1024) * sizeof(float);
 
 static bool edge_attrs() {

@@ -53,22 +53,10 @@ typedef _Float16 h2v __attribute__((ext_vector_type(2)));
 // one rounding rule for every operand.  The split does not care which way hi is rounded: lo = x - hi is exact either way and
 // hi + lo still carries 21 bits of x; pkrtz is one instruction per pair.
 typedef __fp16 fp16x2_t __attribute__((ext_vector_type(2)));
-#if defined(PP_X_CVT_SCALAR)      /* experiment: round-to-nearest through the pre-gfx950 scalar conversion + pack */
-__device__ __forceinline__ h2v cvt2(f32x2v x) {
-    unsigned a, b, p;
-    asm("v_cvt_f16_f32 %0, %1" : "=v"(a) : "v"(x[0]));
-    asm("v_cvt_f16_f32 %0, %1" : "=v"(b) : "v"(x[1]));
-    asm("v_pack_b32_f16 %0, %1, %2" : "=v"(p) : "v"(a), "v"(b));
-    return __builtin_bit_cast(h2v, p);
-}
-#elif defined(PP_X_CVT_PK)        /* experiment: gfx950's packed round-to-nearest conversion (what a plain cast compiles to) */
-__device__ __forceinline__ h2v cvt2(f32x2v x) { return __builtin_convertvector(x, h2v); }
-#else
 __device__ __forceinline__ h2v cvt2(f32x2v x) {
     const fp16x2_t r = __builtin_amdgcn_cvt_pkrtz(x[0], x[1]);
     return __builtin_bit_cast(h2v, r);
 }
-#endif
 // x - (float)hh for a packed pair: one v_fma_mix_f32 per value (the f16 half is an operand of the fp32 FMA; exact, like the
 // v_cvt_f32_f16 + v_sub_f32 pair it replaces -- a quarter of the split's VALU instructions)
 __device__ __forceinline__ f32x2v split_residual(h2v hh, f32x2v x) {
@@ -182,12 +170,6 @@ enum { P_BMID = 0, P_BOUT = 128, P_FOB = 256, P_G2 = 384, P_BE2 = 512, P_FIB = 6
 #define PP_X_NOWLOAD_ true
 #else
 #define PP_X_NOWLOAD_ false
-#endif
-
-#ifdef PP_X_NOBT         /* timing experiment (results are wrong): only the first tile of a layer's input is read from LDS */
-#define PP_X_NOBT_ true
-#else
-#define PP_X_NOBT_ false
 #endif
 
 #ifdef PP_X_E_NOMFMA     /* timing experiment (results are wrong): the matrix instructions are left out */
@@ -494,21 +476,6 @@ __device__ __forceinline__ void geometry_put(const GeoI &g, const float (&pj)[3]
 // is private to each wave, so the rotation costs nothing: pp_api.hip put_chunk_rot packs wave w's quarter of the chunk at
 // position p from input tile (w + p) & 3.  (Accumulation order per output feature changes with the wave: results differ
 // from round 3 by fp32 rounding, deterministically.)
-// -DPP_LAB -DPP_X_PRIO=n: wave priority experiments (1/2: static per workgroup kind in the mixed launch, 3: raised inside the MFMA
-// blocks, 4: raised outside them)
-#ifndef PP_X_PRIO
-#define PP_X_PRIO 0
-#endif
-#if PP_X_PRIO == 3
-#define MF_BEGIN() __builtin_amdgcn_s_setprio(2);
-#define MF_END() __builtin_amdgcn_s_setprio(0);
-#elif PP_X_PRIO == 4
-#define MF_BEGIN() __builtin_amdgcn_s_setprio(0);
-#define MF_END() __builtin_amdgcn_s_setprio(2);
-#else
-#define MF_BEGIN()
-#define MF_END()
-#endif
 #define ROT(p) ((wave + (p)) & 3)        // input tile at position p of a rotated layer (wave-uniform)
 #define BT_FETCH(BUF, t, set)                                                     \
     _Pragma("unroll") for (int r = 0; r < R; r++) xbuf_get_h((BUF) + r * XBUF_FLOATS, t, lane, bt[set][r]);
@@ -520,23 +487,21 @@ __device__ __forceinline__ void geometry_put(const GeoI &g, const float (&pj)[3]
 // BAR: a workgroup barrier between the two k-steps.
 #define RSTAGE(k, NCH, ACC, BUF, P, SWAP, BAR, FETCH_LATE)                                                  \
     WSTAGE(k, NCH, ACC, {                                                                                   \
-        if constexpr ((P) < 3 && !(FETCH_LATE) && !PP_X_NOBT_) { BT_FETCH(BUF, ROT((P) + 1), ((P) + 1) & 1) }   \
+        if constexpr ((P) < 3 && !(FETCH_LATE)) { BT_FETCH(BUF, ROT((P) + 1), ((P) + 1) & 1) }   \
         (mfma_hs<R, SWAP, 0>(AK, bt[(P) & 1], ACC));                                                        \
         if constexpr (BAR) { ACC_FENCE(ACC) __syncthreads(); }                                              \
-        if constexpr ((P) < 3 && (FETCH_LATE) && !PP_X_NOBT_) { BT_FETCH(BUF, ROT((P) + 1), ((P) + 1) & 1) }    \
+        if constexpr ((P) < 3 && (FETCH_LATE)) { BT_FETCH(BUF, ROT((P) + 1), ((P) + 1) & 1) }    \
         (mfma_hs<R, SWAP, 1>(AK, bt[(P) & 1], ACC));                                                        \
     })
 // a layer whose first B operands (the wave's own tile) are in bt[0] already -- PUBLISH_OWN() put them there and into BUF.
 // BAR_A: barrier A in position 3 (the next publication overwrites BUF and no other barrier lies in between).
 #define RLAYER_OWN(k0, NCH, ACC, BUF, SWAP, BAR_A)                                \
-    MF_BEGIN()                                                                    \
     RSTAGE((k0) + 0, NCH, ACC, BUF, 0, SWAP, true, true)                          \
     RSTAGE((k0) + 1, NCH, ACC, BUF, 1, SWAP, false, false)                        \
     RSTAGE((k0) + 2, NCH, ACC, BUF, 2, SWAP, false, false)                        \
     RSTAGE((k0) + 3, NCH, ACC, BUF, 3, SWAP, BAR_A, false)
 // a layer reading a buffer that was published long ago (x1buf in the FFN blocks 1..3): every tile comes from LDS
 #define RLAYER_BUF(k0, NCH, ACC, BUF, SWAP, BAR_A)                                \
-    MF_BEGIN()                                                                    \
     BT_FETCH(BUF, ROT(0), 0)                                                      \
     RSTAGE((k0) + 0, NCH, ACC, BUF, 0, SWAP, false, false)                        \
     RSTAGE((k0) + 1, NCH, ACC, BUF, 1, SWAP, false, false)                        \
@@ -545,7 +510,6 @@ __device__ __forceinline__ void geometry_put(const GeoI &g, const float (&pj)[3]
 // publish this wave's tile of every residue (split, RELU or not) into BUF and keep it as the B operands of position 0.  No
 // barrier here: B follows inside position 0 of the consuming layer, A was passed inside an earlier stage.
 #define PUBLISH_OWN(RELU, SRC, BUF)                                               \
-    MF_END()                                                                      \
     _Pragma("unroll") for (int r = 0; r < R; r++) {                               \
         split_tile<RELU>(SRC[r], bt[0][r], sat);                                  \
         xbuf_put_h((BUF) + r * XBUF_FLOATS, wave, lane, bt[0][r]);                \
@@ -560,7 +524,6 @@ __device__ __forceinline__ void geometry_put(const GeoI &g, const float (&pj)[3]
     if constexpr (!ST0) {                                                         \
         RLAYER_OWN((K0) + 0, NCH, acc, xbuf, false, false)                        \
     }                                                                             \
-    MF_BEGIN()                                                                    \
     WSTAGE((K0) + C0 + 0, NCH, acc, (mfma_geo<R, 0>(AK, gbuf, lane, acc)))        \
     WSTAGE((K0) + C0 + 1, NCH, acc, (mfma_geo<R, 1>(AK, gbuf, lane, acc)))        \
     if constexpr (!ST0) { __syncthreads(); }                                      \
@@ -706,7 +669,6 @@ __device__ __forceinline__ void node_message_body(const EdgeArgs &A, const int r
 #pragma unroll
         for (int q = 0; q < 16; q++) acc[r][q] = bmid;
     RLAYER_OWN(C0 + 3, NCH, acc, xbuf, true, false)
-    MF_END()
 #pragma unroll
     for (int r = 0; r < R; r++) {
         // rows (registers) are edges e = 8 (r>>2) + 4 h + (r&3); mask and reduce over them
@@ -874,7 +836,6 @@ __device__ __forceinline__ void edge_update_body(const EdgeArgs &A, const int re
     RLAYER_OWN(C0 + 7, NCH, acc, xbuf, false, false)
     TS(4)
     // ---- x1 = LN2(h_E + mask * m): own tile only, statistics merged across the four waves ---------------
-    MF_END()
     f32x16 fib;
     FFN_BIAS_FETCH(0)
 #pragma unroll
@@ -909,7 +870,6 @@ __device__ __forceinline__ void edge_update_body(const EdgeArgs &A, const int re
     FFN_BLOCK(3)
     TS(10)
     // ---- h_E = mask * LN3(x1 + ffn) ---------------------------------------------------------------------
-    MF_END()
 #pragma unroll
     for (int r = 0; r < R; r++) ln_partial(out[r], stat + r * STAT_FLOATS, wave, j, h);
     __syncthreads();
@@ -974,7 +934,6 @@ __device__ __forceinline__ void edge_update_body(const EdgeArgs &A, const int re
         TS(15)
         RLAYER_OWN(NEU + 7, NCH, acc, xbuf, true, false)
         TS(16)
-        MF_END()
 #pragma unroll
         for (int r = 0; r < R; r++) {
             // rows (registers) are edges e = 8 (r>>2) + 4 h + (r&3); mask and reduce over them
@@ -1039,11 +998,6 @@ k_edge_update_mix(EdgeArgs A) {
     } else {
         if (b < A.n_pairs) pair = b; else single = b - A.n_pairs;
     }
-#if PP_X_PRIO == 1
-    if (pair >= 0) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
-#elif PP_X_PRIO == 2
-    if (pair >= 0) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1);
-#endif
     if (pair >= 0) edge_update_body<2, ST0, FUSE, LNS>(A, 2 * pair, smem);
     else edge_update_body<1, ST0, FUSE, LNS>(A, 2 * A.n_pairs + single, smem);
 }

@@ -10,9 +10,15 @@
 #include "../../include/packppi_hip.h"
 
 // ---- product vs laboratory ------------------------------------------------------------------------------------------
-// The kernels double as their own measurement bench: -DPP_X_* switches compile timing variants, most of which give WRONG
-// RESULTS (no weight fetches, no matrix instructions, stop points ...).  None of them may reach a shipped library:
-//   -DPP_LAB   is required by every PP_X_* switch (tools/debug, tools/profile build tagged libraries with it);
+// Five measurement switches are left in the sources, all in pp_edge_f16.hip, all behind -DPP_LAB and a TAGGED library:
+//   -DPP_X_TS [-DPP_X_TS_FINE=k0]  phase / stage clocks of wave 0 into the dbg buffer (tools/debug/phase_*.py, stage_times.py);
+//   -DPP_X_NOWLOAD, -DPP_X_E_NOMFMA  ablations (WRONG RESULTS): no weight fetches / no matrix instructions -- what the launch time
+//                                    is made of (profiles/r02_edge_ablation.txt);
+//   -DPP_X_NOSAT                   no sticky-flag bookkeeping (A/B of its price, tools/debug/ab_sat.sh).
+// The switches of experiments that are settled (node-update stop points and ablations, wave priorities, conversion variants,
+// the clash ablations ...) were removed from the sources in round 5 -- the device code of all four libraries is the same to the
+// instruction (profiles/r05_switch_cleanup.txt); the builds behind the older records are in the history (up to 5cba218).
+//   -DPP_LAB   is required by every PP_X_* switch and by the tuning parameters below;
 //   -DPP_DIAG  (implied by PP_LAB; the libpackppi_hip.dbg.so build) compiles the pp_debug_* exports and the getenv switches
 //              of the launchers (PP_NU_SPLIT, PP_EDGE_MIX, PP_EDGE_R, PP_NM_R, PP_NM_MIX, PP_NODE_F16, PP_DEBUG): same kernels, same
 //              results, forced launch shapes -- the default / .f32 / .chk libraries have neither.
@@ -22,11 +28,8 @@
 #define PP_DIAG
 #endif
 #if !defined(PP_LAB) &&                                                                                                       \
-    (defined(PP_X_NU_STOP) || defined(PP_X_TS) || defined(PP_X_TS_FINE) || defined(PP_X_PRIO) || defined(PP_X_NOWLOAD) ||        \
-     defined(PP_X_NOBT) || defined(PP_X_PRM_ALIAS) || defined(PP_X_PIPE) || defined(PP_X_NU_EMBED_LAUNCH) ||                     \
-     defined(PP_X_CVT_SCALAR) || defined(PP_X_CVT_PK) || defined(PP_X_NU_NOMFMA) || defined(PP_X_NU_NOLOAD) ||                   \
-     defined(PP_X_NOSAT) || defined(PP_X_NOMFMA) || defined(PP_X_NOACT) || defined(PP_X_E_NOMFMA) || defined(PP_X_CL_NOSCAN) ||  \
-     defined(PP_X_CL_NOPAIR) || defined(PP_WDEPTH) || defined(PP_WDEPTH_R1) || defined(PP_NXB_R1) || defined(PP_WGS2) || defined(PP_WGS) ||               \
+    (defined(PP_X_TS) || defined(PP_X_TS_FINE) || defined(PP_X_NOWLOAD) || defined(PP_X_E_NOMFMA) || defined(PP_X_NOSAT) ||      \
+     defined(PP_WDEPTH) || defined(PP_WDEPTH_R1) || defined(PP_NXB_R1) || defined(PP_WGS2) || defined(PP_WGS) ||                 \
      defined(PP_LDS_PAD) || defined(PP_NO_FUSE_NM) || defined(PP_NU_DEPTH))
 #error "PP_X_* / tuning switches compile laboratory variants (most give wrong results): add -DPP_LAB and build a TAGGED library (python -m packppi_amd.build --tag NAME -DPP_LAB -DPP_X_...)"
 #endif

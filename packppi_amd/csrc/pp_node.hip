@@ -383,10 +383,6 @@ __device__ __forceinline__ void gload_N(const nh8 *__restrict__ wq, int slot, AO
 }
 #define MFMA_N(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
 __device__ __forceinline__ void mm3(const AOpN &a, const nh8 &bh, const nh8 &bl, nf4 &cH, nf4 &cL) {
-#ifdef PP_X_NU_NOMFMA        /* timing experiment (wrong results): the weight stream and the barriers without the matrix work */
-    asm volatile("" ::"v"(a.hi), "v"(a.lo), "v"(bh), "v"(bl));
-    return;
-#endif
     cH = MFMA_N(a.hi, bh, cH);
     cL = MFMA_N(a.hi, bl, cL);
     cL = MFMA_N(a.lo, bh, cL);
@@ -474,7 +470,7 @@ __device__ __forceinline__ nf4 ln128(float (*st)[16][2], int wv, int r, int g, c
 #define NSTAGE_IF(k, OWN, ACCV, BODY)                                                                                  \
     {                                                                                                                  \
         __builtin_amdgcn_sched_barrier(0);                                                                             \
-        if constexpr ((k) + NU_ND < NLOAD && !NU_X_NOLOAD) {                                                           \
+        if constexpr ((k) + NU_ND < NLOAD) {                                                           \
             constexpr int nw_ = nu_logical_waves<LAST, CL>((k) + NU_ND);                                               \
             if (nw_ == 8 || wv < nw_)                                                                                  \
                 gload_N(wq, nu_phys_slot<CL>((k) + NU_ND, clq), AR[((k) + NU_ND) % NU_NRING]);                         \
@@ -502,11 +498,6 @@ __device__ __forceinline__ nf4 ln128(float (*st)[16][2], int wv, int r, int g, c
         mm3(AK, fh[(s) & 1], fl[(s) & 1], cH, cL);                                                   \
     })
 
-#ifdef PP_X_NU_NOLOAD        /* timing experiment (wrong results): no weight fetches after the prologue's */
-#define NU_X_NOLOAD true
-#else
-#define NU_X_NOLOAD false
-#endif
 // CL > 1 (middle layers, when CL x tiles workgroups still fit the chip in one round): CL workgroups per 16-residue tile.  A
 // launch lasts as long as ONE CU needs for its workgroup's weight stream, and most CUs idle (47 tiles at T1124); so the tile's
 // common part (W_out, FFN, both LayerNorms: 36 slots) is computed redundantly by CL workgroups on CL CUs, and the 20 slots of
@@ -620,9 +611,6 @@ k_node_update(NUpdArgs A, float *chi, int step, int sde, const float *noise, int
     publish4(sm.a_hi, sm.a_lo, srow * NU_S128 + scol, s4);
     __syncthreads();
 
-#if defined(PP_X_NU_STOP) && PP_X_NU_STOP == 1     /* timing experiment: stop here */
-    return;
-#endif
     nh8 bh[4], bl[4];
     nf4 cH, cL;
     float satm = 0.f;
@@ -636,9 +624,6 @@ k_node_update(NUpdArgs A, float *chi, int step, int sde, const float *noise, int
                          *reinterpret_cast<const nf4 *>(par + NU_P_B0 + fc));
     publish4(sm.b_hi, sm.b_lo, r * NU_S128 + fc, h1);
     __syncthreads();
-#if defined(PP_X_NU_STOP) && PP_X_NU_STOP == 2     /* timing experiment: stop here */
-    return;
-#endif
     // ---- FFN 128 -> 512: hidden tiles 4 w .. 4 w + 3 ----------------------------------------------------------------
     LDB4(sm.b_hi, sm.b_lo)
 #define FFN_IN_TILE(c)                                                                                     \
@@ -649,9 +634,6 @@ k_node_update(NUpdArgs A, float *chi, int step, int sde, const float *noise, int
     FFN_IN_TILE(0) FFN_IN_TILE(1) FFN_IN_TILE(2) FFN_IN_TILE(3)
     if (!(satm < 65504.f)) atomicOr(A.sat, 2u);
     __syncthreads();
-#if defined(PP_X_NU_STOP) && PP_X_NU_STOP == 3     /* timing experiment: stop here */
-    return;
-#endif
     // ---- FFN 512 -> 128, LayerNorm, mask ------------------------------------------------------------------------------
     nh8 fh[2], fl[2];
     ldB(sm.c_hi, sm.c_lo, r * NU_S512 + 8 * g, 0, fh[0], fl[0]);
@@ -664,9 +646,6 @@ k_node_update(NUpdArgs A, float *chi, int step, int sde, const float *noise, int
     if (live && clq == 0 && (MODE != PP_NU_STEP || !embed_next)) *reinterpret_cast<nf4 *>(A.hV_out + (size_t)n * 128 + fc) = h2;
     publish4(sm.a_hi, sm.a_lo, r * NU_S128 + fc, h2);
     __syncthreads();
-#if defined(PP_X_NU_STOP) && PP_X_NU_STOP == 4     /* timing experiment: stop here */
-    return;
-#endif
     LDB4(sm.a_hi, sm.a_lo)
 
     if constexpr (!LAST) {
@@ -718,9 +697,6 @@ k_node_update(NUpdArgs A, float *chi, int step, int sde, const float *noise, int
             publish4(sm.c_hi, sm.c_lo, r * NU_S512 + fc, relu_sat(fold(cH, cL) + *reinterpret_cast<const nf4 *>(par + NU_P_DB0 + fc), satm));
         }
         __syncthreads();
-#if defined(PP_X_NU_STOP) && PP_X_NU_STOP == 5     /* timing experiment: stop here */
-        return;
-#endif
         // the rest of the decoder is one wave's work: 64 -> 32 (two tiles), 32 -> 16, 16 -> 4; activations go through
         // columns 64..127 of the same image (a wave's LDS operations execute in order; the asm is the compiler fence).
         // The other waves only keep their weight stream going (the stages' fetches) and wait at the next barrier.
@@ -785,9 +761,6 @@ k_node_update(NUpdArgs A, float *chi, int step, int sde, const float *noise, int
         if constexpr (MODE != PP_NU_STEP) return;
         if (!embed_next) return;
         __syncthreads();
-#if defined(PP_X_NU_STOP) && PP_X_NU_STOP == 6     /* timing experiment: stop here */
-        return;
-#endif
         // ---- next step's node embedding (encoder.py:218-242) and the layer-0 node-message inputs ---------------------
         // bias + one-hot column + W[:, 21:51] . (30 dense inputs) as one MFMA k-step (slot 46)
         nh8 eh, el;
@@ -801,9 +774,6 @@ k_node_update(NUpdArgs A, float *chi, int step, int sde, const float *noise, int
         if (live) *reinterpret_cast<nf4 *>(A.hV_out + (size_t)n * 128 + fc) = h0;
         publish4(sm.b_hi, sm.b_lo, r * NU_S128 + fc, h0);
         __syncthreads();
-#if defined(PP_X_NU_STOP) && PP_X_NU_STOP == 7     /* timing experiment: stop here */
-        return;
-#endif
         LDB4(sm.b_hi, sm.b_lo)
         cH = zero4; cL = zero4;
         NTILE4(47, cH, cL)
@@ -886,11 +856,7 @@ template <int KL, int SRC0 = 0>
 __device__ __forceinline__ VN wdot(const WSet &w, const VN *act, VN acc) {
 #pragma unroll
     for (int i = 0; i < KL; i++) {
-#ifdef PP_X_NOACT             // timing-only ablation: no activation reads from LDS
-        acc = vfma(w.v[SRC0 + i], acc, acc);
-#else
         acc = vfma(w.v[SRC0 + i], act[i], acc);
-#endif
         // keep the scheduler from running the x/y chains of a whole slice ahead of the z/w chains (it then parks
         // half of every activation read in scratch)
         if ((i & 7) == 7) VN_FOR asm volatile("" : "+v"(acc.g[gi].x), "+v"(acc.g[gi].y), "+v"(acc.g[gi].z), "+v"(acc.g[gi].w));
@@ -987,15 +953,9 @@ k_node_update_valu(NodeArgs A, UpdW W, float *chi, int step, int sde, const floa
     wload<32>(wd, W.ffn_inT, 512, 256 + f + 128, kq, part.g[0].x);
     VN m = meet(sm, flip, part, 128, f, ks);
     m = vadd(m, vscale(ms, out_b));
-#if defined(PP_X_NU_STOP) && PP_X_NU_STOP == 1
-    return;
-#endif
     VN h1 = layernorm(sm, rflip, vadd(hv, m), g0, b0);
     if (ks == 0) sm.h[f] = h1;
     __syncthreads();
-#if defined(PP_X_NU_STOP) && PP_X_NU_STOP == 2
-    return;
-#endif
     // FFN 128 -> 512: thread (f, ks) builds the ks-th K-quarter of hidden units f, f+128, f+256, f+384 in one pass
     // over h1, then every thread owns one hidden unit
     {
@@ -1016,9 +976,6 @@ k_node_update_valu(NodeArgs A, UpdW W, float *chi, int step, int sde, const floa
         sm.a[t] = vrelu(vadd(hd, vn(fib)));
     }
     __syncthreads();
-#if defined(PP_X_NU_STOP) && PP_X_NU_STOP == 3
-    return;
-#endif
     part = wdot<32>(wb, sm.a + ks * 128, vn(0.f));
     part = wdot<32>(wc, sm.a + ks * 128 + 32, part);
     part = wdot<32>(wa, sm.a + ks * 128 + 64, part);
@@ -1052,9 +1009,6 @@ k_node_update_valu(NodeArgs A, UpdW W, float *chi, int step, int sde, const floa
     }
     VN o = meet(sm, flip, part, 128, f, ks);
     o = vadd(o, vn(ffn_out_b));
-#if defined(PP_X_NU_STOP) && PP_X_NU_STOP == 4
-    return;
-#endif
     VN h2 = layernorm(sm, rflip, vadd(h1, o), g1, b1);
     h2 = vmul(h2, rm);
     if (ks == 0) {
@@ -1062,12 +1016,6 @@ k_node_update_valu(NodeArgs A, UpdW W, float *chi, int step, int sde, const floa
         sm.h[f] = h2;
     }
     __syncthreads();
-#if defined(PP_X_NU_STOP) && PP_X_NU_STOP == 5
-    return;
-#endif
-#if defined(PP_X_NU_STOP) && PP_X_NU_STOP == 6
-    if (!mid) return;
-#endif
     if constexpr (mid) {
         // inputs of this layer's edge message and of the next layer's node message in one pass over h2:
         // columns PAe 0..127 | PCe 128..255 | PAn 256..383 | PCn 384..511 | ptsE 512..535 | ptsN 536..559
@@ -1326,10 +1274,6 @@ pp_status pp_launch_node_update(pp_ctx *c, int layer, int last_mode, float *chi,
     A.score = c->score;
     A.sat = c->sat;
     int embed_next = (last_mode == PP_NU_STEP && embed_next_step) ? 1 : 0;    // node embedding for step + 1 afterwards
-#ifdef PP_X_NU_EMBED_LAUNCH      /* experiment: the next step's embedding as its own launch (k_node_embed) */
-    const bool embed_after = embed_next != 0;
-    embed_next = 0;
-#endif
     const dim3 grid((c->N + 15) / 16), block(512);
     const int sde = mode == PP_MODE_SDE ? 1 : 0;
     StepScalars sp = {0.f, 0.f, 0.f, 0.f};
@@ -1385,8 +1329,5 @@ pp_status pp_launch_node_update(pp_ctx *c, int layer, int last_mode, float *chi,
     const nu_kernel_t kern = nu_kernel(last_mode == PP_NU_MID ? 0 : last_mode == PP_NU_STEP ? 1 : 2, multi);
     PP_LAUNCH(c, kern, grid, block, sizeof(SmemU), s, A, chi, step, sde, noise, embed_next, sp, te);
     PP_HIP_CHECK(hipGetLastError());
-#ifdef PP_X_NU_EMBED_LAUNCH
-    if (embed_after) return pp_launch_node_embed(c, chi, *next, s);
-#endif
     return PP_OK;
 }
