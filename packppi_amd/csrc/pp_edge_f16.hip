@@ -692,8 +692,13 @@ __device__ __forceinline__ void node_message_body(const EdgeArgs &A, const int r
     if (pp_sat_hit(sat)) atomicOr(A.sat, 1u);
 }
 
+// three workgroups per CU for both instances: the stand-alone node message is a chain of gathers with 84 MFMAs per wave behind
+// it (52 KB of LDS and <= 168 registers at R = 2), so a third resident workgroup is cover, not contention
+#ifndef PP_NM_WGS2
+#define PP_NM_WGS2 3       // workgroups per CU of the two-residue node message (2 = the edge update's budget: round-4 behaviour)
+#endif
 template <int R, bool ST0>
-__global__ void __launch_bounds__(ET, R == 1 ? PP_WGS : PP_WGS2)
+__global__ void __launch_bounds__(ET, R == 1 ? PP_WGS : PP_NM_WGS2)
 k_node_message(EdgeArgs A) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     node_message_body<R, ST0>(A, blockIdx.x * R, smem);
