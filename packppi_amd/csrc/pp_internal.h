@@ -20,7 +20,7 @@
 // instruction (profiles/r05_switch_cleanup.txt); the builds behind the older records are in the history (up to 5cba218).
 //   -DPP_LAB   is required by every PP_X_* switch and by the tuning parameters below;
 //   -DPP_DIAG  (implied by PP_LAB; the libpackppi_hip.dbg.so build) compiles the pp_debug_* exports and the getenv switches
-//              of the launchers (PP_NU_SPLIT, PP_NU_TEAMS, PP_EDGE_MIX, PP_EDGE_R, PP_NM_R, PP_NM_MIX, PP_NODE_F16, PP_DEBUG): same kernels, same
+//              of the launchers (PP_NU_SPLIT, PP_EDGE_MIX, PP_EDGE_R, PP_NM_R, PP_NM_MIX, PP_NODE_F16, PP_DEBUG): same kernels, same
 //              results, forced launch shapes -- the default / .f32 / .chk libraries have neither.
 // packppi_amd/build.py refuses these flags for the three product libraries and lib.load() refuses a library whose flag
 // stamp is not one of the known sets.

@@ -502,18 +502,10 @@ __device__ __forceinline__ nf4 ln128(float (*st)[16][2], int wv, int r, int g, c
 // launch lasts as long as ONE CU needs for its workgroup's weight stream, and most CUs idle (47 tiles at T1124); so the tile's
 // common part (W_out, FFN, both LayerNorms: 36 slots) is computed redundantly by CL workgroups on CL CUs, and the 20 slots of
 // projections behind it are dealt out among them -- no exchange between workgroups, identical arithmetic per output.
-//
-// TEAMS = 2 (launches with more tiles than the chip holds at two workgroups per CU: packed batches): ONE 1024-thread workgroup per CU
-// whose two eight-wave teams each own a tile -- own LDS block, same code, and every barrier is the whole workgroup's, so the teams
-// stay in lockstep and ask for the same weight lines within a few hundred cycles of each other: one L2 -> L1 fill of the 0.9 MB
-// stream serves both tiles.  (Two independent workgroups on a CU start together as well, but nothing holds them together and each
-// pays for its own fill -- the launch is stream-bound, not latency-bound, so the coupling costs nothing here, unlike in the edge
-// update: DESIGN.md 4.6d'', 4.7b.)  Same arithmetic per residue, same bits.
-template <int MODE, int NU_ND, int CL = 1, int TEAMS = 1>
-__global__ void __launch_bounds__(512 * TEAMS)
+template <int MODE, int NU_ND, int CL = 1>
+__global__ void __launch_bounds__(512)
 k_node_update(NUpdArgs A, float *chi, int step, int sde, const float *noise, int embed_next, StepScalars sp, TimeEmb te_next) {
     static_assert(CL == 1 || MODE == PP_NU_MID, "only the middle layers have a split form");
-    static_assert(TEAMS == 1 || (TEAMS == 2 && CL == 1), "teams and split launches are for opposite ends of the size range");
     constexpr int NU_NRING = NU_ND + 1;
     constexpr bool LAST = MODE != PP_NU_MID;
     constexpr int NSLOT = LAST ? PP_NU_SLOTS_LAST : PP_NU_SLOTS_MID;
@@ -521,10 +513,9 @@ k_node_update(NUpdArgs A, float *chi, int step, int sde, const float *noise, int
     const int clq = CL > 1 ? (int)(blockIdx.x % CL) : 0;          // which of the tile's workgroups this is
     constexpr int NPAR = LAST ? NU_P_LAST_TOTAL : NU_P_MID_TOTAL;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const int team = TEAMS > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 9)) : 0;
-    SmemU &sm = *reinterpret_cast<SmemU *>(smem_raw + (TEAMS > 1 ? team * sizeof(SmemU) : 0));
-    const int tid = TEAMS > 1 ? (int)(threadIdx.x & 511) : (int)threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r = lane & 15, g = lane >> 4, N = A.N, n0 = ((int)(blockIdx.x / CL) * TEAMS + team) * 16;
+    SmemU &sm = *reinterpret_cast<SmemU *>(smem_raw);
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, g = lane >> 4, N = A.N, n0 = (int)(blockIdx.x / CL) * 16;
     const int n = n0 + r, nc = n < N ? n : N - 1;
     const bool live = n < N;
     const int fc = 16 * wv + 4 * g;            // first of this lane's four features in a 128-wide vector
@@ -1214,11 +1205,6 @@ static nu_kernel_t nu_kernel(int mode, bool multi) {
     return mode == 0 ? k_node_update<PP_NU_MID, PP_NU_DEPTH> : mode == 1 ? k_node_update<PP_NU_STEP, PP_NU_DEPTH>
                                                                           : k_node_update<PP_NU_SCORE, PP_NU_DEPTH>;
 }
-// more tiles than 2 x CUs: two tiles per 1024-thread workgroup, one weight fill per CU
-static nu_kernel_t nu_kernel_teams(int mode) {
-    return mode == 0 ? k_node_update<PP_NU_MID, PP_NU_DEPTH_MULTI, 1, 2> : mode == 1 ? k_node_update<PP_NU_STEP, PP_NU_DEPTH_MULTI, 1, 2>
-                                                                                      : k_node_update<PP_NU_SCORE, PP_NU_DEPTH_MULTI, 1, 2>;
-}
 static nu_kernel_t nu_kernel_split(int cl) {
     return cl == 4 ? k_node_update<PP_NU_MID, PP_NU_DEPTH, 4> : k_node_update<PP_NU_MID, PP_NU_DEPTH, 2>;
 }
@@ -1235,9 +1221,6 @@ static pp_status node_attrs() {
         for (int cl = 2; cl <= 4; cl += 2)
             PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(nu_kernel_split(cl)),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SmemU)));
-        for (int mode = 0; mode < 3; mode++)
-            PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(nu_kernel_teams(mode)),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * sizeof(SmemU))));
 #ifndef PP_EDGE_F16
         PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_node_update_valu<PP_NU_MID>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Smem)));
         PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_node_update_valu<PP_NU_STEP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Smem)));
@@ -1333,15 +1316,6 @@ pp_status pp_launch_node_update(pp_ctx *c, int layer, int last_mode, float *chi,
     static const char *split_env = PP_GETENV("PP_NU_SPLIT");
     static const int split_max = split_env ? atoi(split_env) : 4;     // measurement aid: 1 = never
     const int tiles = (int)grid.x;
-    // more tiles than the chip holds at two workgroups per CU: two tiles per 1024-thread workgroup (teams in lockstep share the fill)
-    static const char *teams_env = PP_GETENV("PP_NU_TEAMS");
-    static const int teams_mode = teams_env ? atoi(teams_env) : -1;      // measurement / test aid: 0 = never, 1 = always
-    if (teams_mode == 1 || (teams_mode < 0 && tiles > 2 * g_nu_cus)) {
-        const int km = last_mode == PP_NU_MID ? 0 : last_mode == PP_NU_STEP ? 1 : 2;
-        PP_LAUNCH(c, nu_kernel_teams(km), dim3((tiles + 1) / 2), dim3(1024), 2 * sizeof(SmemU), s, A, chi, step, sde, noise, embed_next, sp, te);
-        PP_HIP_CHECK(hipGetLastError());
-        return PP_OK;
-    }
     const int cl = last_mode != PP_NU_MID ? 1 : (split_max >= 4 && 4 * tiles <= g_nu_cus) ? 4 : (split_max >= 2 && 2 * tiles <= g_nu_cus) ? 2 : 1;
     if (cl > 1) {
         // the tile's workgroups all read the old h_V and one of them writes the new one: into the other buffer, so that a
@@ -1352,8 +1326,7 @@ pp_status pp_launch_node_update(pp_ctx *c, int layer, int last_mode, float *chi,
         PP_HIP_CHECK(hipGetLastError());
         return PP_OK;
     }
-    const int kmode = last_mode == PP_NU_MID ? 0 : last_mode == PP_NU_STEP ? 1 : 2;
-    const nu_kernel_t kern = nu_kernel(kmode, multi);
+    const nu_kernel_t kern = nu_kernel(last_mode == PP_NU_MID ? 0 : last_mode == PP_NU_STEP ? 1 : 2, multi);
     PP_LAUNCH(c, kern, grid, block, sizeof(SmemU), s, A, chi, step, sde, noise, embed_next, sp, te);
     PP_HIP_CHECK(hipGetLastError());
     return PP_OK;

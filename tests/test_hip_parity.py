@@ -922,45 +922,6 @@ def test_node_update_split_launch_is_bit_identical():
     assert len(outs[0]) == 4 and outs[0] == outs[1], outs
 
 
-def test_node_update_team_launch_is_bit_identical():
-    """A launch with more tiles than the chip holds at two workgroups per CU runs the node update as 1024-thread workgroups whose
-    two eight-wave teams own a 16-residue tile each (pp_node.hip, TEAMS = 2: the teams pass the same barriers, so one fill of the
-    weight stream serves both).  Every residue keeps its arithmetic: forced onto small, odd (a team without a tile), multi-chain and
-    packed shapes it must give the same bits as the plain launches (PP_NU_TEAMS = 1 / 0, read by libpackppi_hip.dbg.so only)."""
-    import subprocess
-    import sys
-    from packppi_amd.build import diag_variant_path
-    if not os.path.exists(diag_variant_path()):
-        pytest.skip("libpackppi_hip.dbg.so not built (__graft_entry__.build() builds it)")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = ("import hashlib, sys, torch; sys.path.insert(0, %r)\n"
-            "from packppi_amd import synth\n"
-            "from packppi_amd.batch import pack\n"
-            "from packppi_amd.featurize import protein_to_batch\n"
-            "from packppi_amd.module import TDiffusionModule\n"
-            "from packppi_amd.weights import make_random_state_dict\n"
-            "m = TDiffusionModule(make_random_state_dict(20251003), device='cuda:0')\n"
-            "m.schedule = torch.linspace(1, 0, 11)\n"
-            "def run(tag, b, L):\n"
-            "    g = torch.Generator().manual_seed(L)\n"
-            "    init = ((torch.rand(1, L, 4, generator=g) * 2 - 1) * 3.0).to('cuda:0') * b['SC_D_mask']\n"
-            "    out = m.sample_from(b, init)\n"
-            "    s, h = m.network(b, out, torch.full((L,), 0.3))\n"
-            "    print(tag, hashlib.sha256(out.cpu().numpy().tobytes() + h.cpu().numpy().tobytes() + s.cpu().numpy().tobytes()).hexdigest())\n"
-            "for L in (40, 90, 300, 1100, 4500):\n"       # 3 / 6 / 19 / 69 tiles; 282 tiles: more than the chip has CUs
-            "    run('L%%d' %% L, protein_to_batch(synth.make_complex(L, 40 + L)).to('cuda:0'), L)\n"
-            "cs = [protein_to_batch(synth.make_complex(L, 7 + L)).to('cuda:0') for L in (61, 333, 47, 150)]\n"
-            "pb = pack(cs)\n"
-            "run('packed', pb, int(pb['max_size']))\n") % root
-    outs = []
-    for teams in ("0", "1"):
-        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PP_NU_TEAMS=teams, PACKPPI_LIB=diag_variant_path()),
-                           capture_output=True, text=True, timeout=900)
-        assert r.returncode == 0, r.stderr[-2000:]
-        outs.append([ln for ln in r.stdout.splitlines() if ln.startswith(("L", "packed"))])
-    assert len(outs[0]) == 6 and outs[0] == outs[1], outs
-
-
 def test_fp32_variant_library():
     """The end-to-end parity cases once more on the exact-fp32 edge kernels (one child test run with PACKPPI_LIB)."""
     import subprocess
