@@ -46,7 +46,7 @@ F16_MFMA_PEAK_TFLOPS = 2500.0       # MI355X_MICROARCH.md, "Peak BF16/FP16 MFMA 
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md, "HBM3E peak BW 8.0 TB/s spec"
 L2_PEAK_TBS = 34.5                  # MI355X_MICROARCH.md, "L2 (per XCD)": 4 MiB per XCD, ~34.5 TB/s aggregate
 CU_VMEM_PEAK_GBS = 64 * 2.4         # one CU's vector-memory path: 64 B/clk at 2.4 GHz
-PROFILE_TAG = "r05_v1"             # the committed rocprofv3 summaries of THIS command (profiles/<tag>_*.{csv,json})
+PROFILE_TAG = "r05_v2"             # the committed rocprofv3 summaries of THIS command (profiles/<tag>_*.{csv,json})
 
 
 def _load_fixture(name, init_key):
