@@ -204,8 +204,8 @@ pp_status pp_proximal(pp_ctx *ctx, const float *chi, float lamda, int num_steps,
 pp_status pp_time_kernel(pp_ctx *ctx, int which, int iters, float *avg_ms, void *stream);
 
 /* Measurement aid, no reference counterpart: in-situ duration of a hot kernel.  After
- * pp_profile_kernel(ctx, which) (0 node message, 1 edge update, 2 node update; 3 clash loss + gradient and
- * 4 Adam step + reconstruction of the Adam loop inside pp_proximal) every launch of that
+ * pp_profile_kernel(ctx, which) (0 node message, 1 edge update, 2 node update; 3 the one launch per Adam step
+ * inside pp_proximal: clash loss + gradient, the step, the reconstruction at the new angles) every launch of that
  * kernel made by pp_score / pp_sample / pp_proximal carries a start / stop HIP event pair on the launch stream
  * (hipExtLaunchKernelGGL: the dispatch's own begin and end, the interval rocprofv3's kernel trace reports);
  * pp_profile_read waits for the last one, returns the summed intervals (ms) and the number of

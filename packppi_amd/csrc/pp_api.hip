@@ -700,13 +700,13 @@ static pp_status prepare_impl(pp_plan *plan, const pp_batch *b, const int32_t *s
     ALLOC(ptsE, N * 48); ALLOC(PAe, N * 128); ALLOC(PCe, N * 128);
     ALLOC(score, N * 4); ALLOC(chi_tmp, N * 4);
     }
-    ALLOC(xyz, N * 42); ALLOC(rec, N * 64); ALLOC(axes, N * 24); ALLOC(brad, N); ALLOC(per_res, N); ALLOC(dchi, N * 4);
+    ALLOC(xyz, N * 42); ALLOC(rec, N * 64); ALLOC(axes, N * 24); ALLOC(rec2, N * 64); ALLOC(axes2, N * 24); ALLOC(brad, N); ALLOC(per_res, N); ALLOC(dchi, N * 4);
     ALLOC(px, N * 4); ALLOC(pm, N * 4); ALLOC(pv, N * 4); ALLOC(pz, N * 4); ALLOC(pxeff, N * 4); ALLOC(pmask, N);
     if (c->B == 1) { ALLOC(cand, (size_t)N * 4 * PP_CL_CAP); ALLOC(cand_cnt, N * 4); }      // the proximal loop is defined for one complex (optimize.py:27)
     ALLOC(scal, 64);
     ALLOC(sat, 4);
     ALLOC(seg, N);
-    ALLOC(prox_part, (size_t)PP_PROX_CHUNK * ((N + 15) / 16));
+    ALLOC(prox_part, (size_t)PP_PROX_CHUNK * N);
     c->max_steps = 1 << 20;
 #undef ALLOC
     c->last_stream = static_cast<hipStream_t>(stream);
@@ -1026,8 +1026,8 @@ extern "C" pp_status pp_debug_score_prefix(pp_ctx *c, const float *chi, float t,
 // dispatch's own begin and end timestamps);
 // pp_profile_read synchronises, sums the pair intervals, reports (total ms, launches) and switches profiling off.
 extern "C" pp_status pp_profile_kernel(pp_ctx *c, int which) {
-    if (!c || which < 0 || which > 4)
-        FAIL(PP_ERR_INVALID, "pp_profile_kernel: which must be 0 (node message), 1 (edge update), 2 (node update), 3 (clash, inside pp_proximal) or 4 (Adam step + atom14, inside pp_proximal)");
+    if (!c || which < 0 || which > 3)
+        FAIL(PP_ERR_INVALID, "pp_profile_kernel: which must be 0 (node message), 1 (edge update), 2 (node update) or 3 (the Adam-step launch of pp_proximal: clash + gradient + step + reconstruction)");
     c->prof_which = which;
     c->prof_n = 0;
     return PP_OK;

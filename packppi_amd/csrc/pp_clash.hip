@@ -70,37 +70,41 @@ __device__ __forceinline__ float sel8(const float (&v)[8], int g) {
 // every lane up to its group), lane 14 walks the whole chain and emits the four chi axes, and the per-residue
 // reductions (bounding spheres, side-chain atom count) are 16-lane butterflies.  (One thread per residue took 26 us
 // at T1124 -- a 3000-instruction dependent chain on 12 waves; this layout takes ~5.)
-// One Adam step of the proximal optimiser on the block's own residues, fused in front of the reconstruction that needs its
-// result (UPD instances of k_atom14): loss_t is reduced per block into `loss_part` and summed in block order afterwards
-// (k_prox_losses), so the loss curve does not depend on arrival order.
+// One Adam step of the proximal optimiser (UPD argument of k_clash<CAND, true>): since round 5 it runs in the TAIL of the clash
+// kernel, on the residue whose gradient that workgroup has just reduced, and goes straight on to the reconstruction at the new
+// angles (one launch per Adam step instead of two).  loss_t is parked per residue in `loss_part` and summed in the fixed order of
+// k_prox_losses, so the loss curve does not depend on arrival order.
 struct ProxUpd {
     int t, nblocks;
     float lamda, step_size, bc2s, inv_n;
-    const float *per_res, *dchi, *chi0, *z;
+    const float *chi0, *z;
     const uint8_t *mask;
     float *x, *m, *v, *xeff, *traj, *last, *loss_part;
 };
 
-template <bool UPD>
-__global__ void __launch_bounds__(256)
-k_atom14(int N, const float *__restrict__ X, const int64_t *__restrict__ rtype,
-         const float *__restrict__ BB_D, const float *__restrict__ chi,
-         const float *__restrict__ default_frames, const int32_t *__restrict__ a2g,
-         const float *__restrict__ amask14, const float *__restrict__ lit,
-         const float *__restrict__ atom_exists, const float *__restrict__ between_radius,
-         const int64_t *__restrict__ rindex,
-         float *__restrict__ xyz, float *__restrict__ axes, float *__restrict__ brad,
-         float4 *__restrict__ rec, ProxUpd U) {
-    const int a = threadIdx.x & 15;
-    const int nraw = blockIdx.x * 16 + (threadIdx.x >> 4);
-    const bool live = nraw < N;
-    const int n = live ? nraw : N - 1;           // out-of-range groups mirror the last residue and store nothing
-    const int S = (int)rtype[n];
+// What the reconstruction of residue n needs on lane a (0..15) and does not depend on the angles: requested in one batch, so that
+// every memory round trip of the chain starts before the first dependent instruction.
+struct A14In {
+    int S, g, g0;
+    float ca[3];
+    Rig G;
+    float lp[3], am, ex_t, br_t;
+    DF f0, f5, f6, f7;
+    float xa_t[3];
+    float bbd_t;
+};
+__device__ __forceinline__ A14In a14_load(int n, int a, int S, const float *__restrict__ X,
+                                          const float *__restrict__ BB_D, const float *__restrict__ default_frames,
+                                          const int32_t *__restrict__ a2g, const float *__restrict__ amask14,
+                                          const float *__restrict__ lit, const float *__restrict__ atom_exists,
+                                          const float *__restrict__ between_radius) {
+    A14In I;
+    I.S = S;
     const float *x = X + (size_t)n * 42;
     // backbone frame (same construction as k_frames)
-    float av[3], bv[3], ca[3];
+    float av[3], bv[3];
 #pragma unroll
-    for (int k = 0; k < 3; k++) { ca[k] = x[3 + k]; av[k] = x[6 + k] - ca[k]; bv[k] = x[k] - ca[k]; }
+    for (int k = 0; k < 3; k++) { I.ca[k] = x[3 + k]; av[k] = x[6 + k] - I.ca[k]; bv[k] = x[k] - I.ca[k]; }
     float na = sqrtf(av[0] * av[0] + av[1] * av[1] + av[2] * av[2] + 1e-8f);
 #pragma unroll
     for (int k = 0; k < 3; k++) av[k] /= na;
@@ -111,77 +115,36 @@ k_atom14(int N, const float *__restrict__ X, const int64_t *__restrict__ rtype,
 #pragma unroll
     for (int k = 0; k < 3; k++) bv[k] /= nb;
     float cv[3] = {av[1] * bv[2] - av[2] * bv[1], av[2] * bv[0] - av[0] * bv[2], av[0] * bv[1] - av[1] * bv[0]};
-    Rig G;
 #pragma unroll
-    for (int r = 0; r < 3; r++) { G.R.m[3 * r] = av[r]; G.R.m[3 * r + 1] = bv[r]; G.R.m[3 * r + 2] = cv[r]; G.t[r] = ca[r]; }
+    for (int r = 0; r < 3; r++) { I.G.R.m[3 * r] = av[r]; I.G.R.m[3 * r + 1] = bv[r]; I.G.R.m[3 * r + 2] = cv[r]; I.G.t[r] = I.ca[r]; }
 
     const float *df = default_frames + (size_t)S * 8 * 16;
-    const int g = a < 14 ? a2g[S * 14 + a] : (a == 14 ? 7 : 0);     // lane 14 walks the full chi chain
+    I.g = a < 14 ? a2g[S * 14 + a] : (a == 14 ? 7 : 0);     // lane 14 walks the full chi chain
     // per-atom table entries: fetched here, unconditionally (lanes 14, 15 mirror atom 13), not inside the branches that use them
     const int ac = a < 14 ? a : 13;
     const float *lp_ = lit + ((size_t)S * 14 + ac) * 3;
-    const float lp[3] = {lp_[0], lp_[1], lp_[2]};
-    const float am = amask14[S * 14 + ac];
-    const float ex_t = atom_exists ? atom_exists[(size_t)n * 14 + ac] : 1.f;
-    const float br_t = between_radius[S * 14 + ac];
-    // the default frames of the lane's own chain: group min(g, 4) and the chi2..chi4 groups 5..7 (every memory round trip of
-    // this kernel starts here, before the Adam step; fetched where they are used they were four dependent waits)
-    const int g0 = g < 4 ? g : 4;
-    const DF f0 = load_df(df, g0), f5 = load_df(df, 5), f6 = load_df(df, 6), f7 = load_df(df, 7);
-    const float xa_t[3] = {x[3 * (a < 4 ? a : 3)], x[3 * (a < 4 ? a : 3) + 1], x[3 * (a < 4 ? a : 3) + 2]};
-    const float bbd_t = BB_D[(size_t)n * 3 + (a < 3 ? a : 2)];
-    float chi_t = 0.f;
-    if constexpr (!UPD) chi_t = chi[(size_t)n * 4 + (a >= 3 && a < 7 ? a - 3 : 0)];
-    // (everything above is independent of the angles: its loads are in flight while the Adam step below runs)
-    __shared__ float s_chi[16][4];            // UPD: the block's new angles (reconstruction reads them here, not from memory)
-    if constexpr (UPD) {
-        // loss_t = mean_n [sum_k (xeff - z)^2 + lamda per_res] at the incoming iterate; then torch.optim.Adam defaults
-        // (lr 1e-2, betas (0.9, 0.999), eps 1e-8, bias-corrected; step_size = lr / (1 - beta1^t) and bc2s = sqrt(1 - beta2^t)
-        // come from the host in double); outputs as optimize.py:66-71.  Lane k < 4 of a residue's 16 lanes owns chi_k.
-        __shared__ float s_q[16];
-        const int k = threadIdx.x & 15, grp = threadIdx.x >> 4, nn = blockIdx.x * 16 + grp;
-        float q = 0.f;
-        const float pr_t = U.per_res[nn < N ? nn : N - 1];
-        if (nn < N && k < 4) {
-            const size_t e = (size_t)nn * 4 + k;
-            // every operand first (read whether masked or not): one memory round trip for the whole update
-            const float xe = U.xeff[e], ze = U.z[e], xo = U.x[e], dch = U.dchi[e], mo = U.m[e], vo = U.v[e], c0v = U.chi0[e];
-            const bool mk = U.mask[nn] != 0;
-            const float d = xe - ze;
-            q = fabsf(d) * fabsf(d);
-            const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
-            float g = 0.f;
-            if (mk) g = 2.f * (xo - ze) * U.inv_n + U.lamda * dch;
-            const float mm = mo + (g - mo) * (1.f - b1);             // exp_avg.lerp_(grad, 1 - beta1)
-            const float vv = vo * b2 + (1.f - b2) * (g * g);
-            const float denom = sqrtf(vv) / U.bc2s + eps;
-            const float xn = xo - U.step_size * (mm / denom);
-            U.m[e] = mm; U.v[e] = vv; U.x[e] = xn;
-            const float outv = mk ? xn : c0v;
-            U.xeff[e] = outv;
-            s_chi[grp][k] = outv;
-            if (U.traj) U.traj[(size_t)U.t * N * 4 + e] = outv;
-            if (U.last) U.last[e] = outv;
-        }
-        q += __shfl_xor(q, 1, 16);
-        q += __shfl_xor(q, 2, 16);
-        if (k == 0) s_q[grp] = nn < N ? q + U.lamda * pr_t : 0.f;
-        __syncthreads();                      // the block's new angles (read below through `chi`) and its loss terms
-        if (threadIdx.x == 0) {
-            float tt = 0.f;
-            for (int i = 0; i < 16; i++) tt += s_q[i];
-            U.loss_part[(size_t)U.t * U.nblocks + blockIdx.x] = tt;
-        }
-    }
-    // the 7 angles as normalised (sin, cos): lane k < 7 evaluates angle k (phi-like 0..2, chi 3..6); group g uses angle g-1
+    I.lp[0] = lp_[0]; I.lp[1] = lp_[1]; I.lp[2] = lp_[2];
+    I.am = amask14[S * 14 + ac];
+    I.ex_t = atom_exists ? atom_exists[(size_t)n * 14 + ac] : 1.f;
+    I.br_t = between_radius[S * 14 + ac];
+    // the default frames of the lane's own chain: group min(g, 4) and the chi2..chi4 groups 5..7 (fetched where they are used they
+    // were four dependent waits)
+    I.g0 = I.g < 4 ? I.g : 4;
+    I.f0 = load_df(df, I.g0); I.f5 = load_df(df, 5); I.f6 = load_df(df, 6); I.f7 = load_df(df, 7);
+    I.xa_t[0] = x[3 * (a < 4 ? a : 3)]; I.xa_t[1] = x[3 * (a < 4 ? a : 3) + 1]; I.xa_t[2] = x[3 * (a < 4 ? a : 3) + 2];
+    I.bbd_t = BB_D[(size_t)n * 3 + (a < 3 ? a : 2)];
+    return I;
+}
+// The chain itself: `ang` = the angle lane a < 7 of the residue's 16 lanes evaluates (phi-like 0..2 from BB_D, chi 3..6).  The 16
+// lanes of a residue must be 16 consecutive lanes of one wave (the 16-wide shuffles).
+__device__ __forceinline__ void a14_finish(const A14In &I, int n, int a, bool live, float ang, const int64_t *__restrict__ rindex,
+                                           float *__restrict__ xyz, float *__restrict__ axes, float *__restrict__ brad,
+                                           float4 *__restrict__ rec) {
+    const int g = I.g, g0 = I.g0, S = I.S;
+    const Rig &G = I.G;
+    // the 7 angles as normalised (sin, cos): lane k < 7 evaluates angle k; group g uses angle g-1
     float my_s = 0.f, my_c = 1.f;
     if (a < 7) {
-        // (UPD: the angles this block has just written.  A group beyond N mirrors residue N - 1, which belongs to this same
-        // block -- N - 1 = 16 blockIdx.x + its group -- so its angles are in s_chi too)
-        float ang;
-        if (a < 3) ang = bbd_t;
-        else if (UPD) ang = s_chi[n - blockIdx.x * 16][a - 3];
-        else ang = chi_t;
         const float s0 = sinf(ang), c0 = cosf(ang);
         const float den = sqrtf(fmaxf(s0 * s0 + c0 * c0, 1e-12f));
         my_s = s0 / den; my_c = c0 / den;
@@ -189,9 +152,9 @@ k_atom14(int N, const float *__restrict__ X, const int64_t *__restrict__ rtype,
     float sn[8], cs[8];
     sn[0] = 0.f; cs[0] = 1.f;
 #pragma unroll
-    for (int g = 1; g < 8; g++) { sn[g] = __shfl(my_s, g - 1, 16); cs[g] = __shfl(my_c, g - 1, 16); }
+    for (int gq = 1; gq < 8; gq++) { sn[gq] = __shfl(my_s, gq - 1, 16); cs[gq] = __shfl(my_c, gq - 1, 16); }
 
-    Rig chain = torsion_frame(f0, sel8(sn, g0), sel8(cs, g0));
+    Rig chain = torsion_frame(I.f0, sel8(sn, g0), sel8(cs, g0));
     const bool axis_lane = a == 14 && axes != nullptr && live;
     float ax[4][6];                       // lane 14: the four chi axes in global coordinates (stored below, one branch)
     {
@@ -200,7 +163,7 @@ k_atom14(int N, const float *__restrict__ X, const int64_t *__restrict__ rtype,
     }
 #pragma unroll
     for (int gg = 5; gg < 8; gg++) {
-        const Rig nx = compose(chain, torsion_frame(gg == 5 ? f5 : gg == 6 ? f6 : f7, sn[gg], cs[gg]));
+        const Rig nx = compose(chain, torsion_frame(gg == 5 ? I.f5 : gg == 6 ? I.f6 : I.f7, sn[gg], cs[gg]));
         const bool take = gg <= g;        // selects, not a branch: the chain stays one basic block
 #pragma unroll
         for (int q = 0; q < 9; q++) chain.R.m[q] = take ? nx.R.m[q] : chain.R.m[q];
@@ -221,15 +184,15 @@ k_atom14(int N, const float *__restrict__ X, const int64_t *__restrict__ rtype,
     if (a < 14) {
         if (a < 4) {
 #pragma unroll
-            for (int k = 0; k < 3; k++) p[k] = xa_t[k];
+            for (int k = 0; k < 3; k++) p[k] = I.xa_t[k];
         } else {
             float rp[3];
-            rot3(F.R, lp, rp);
+            rot3(F.R, I.lp, rp);
 #pragma unroll
-            for (int k = 0; k < 3; k++) p[k] = (rp[k] + F.t[k]) * am;
+            for (int k = 0; k < 3; k++) p[k] = (rp[k] + F.t[k]) * I.am;
         }
-        ex = ex_t;
-        reff = ex * br_t;
+        ex = I.ex_t;
+        reff = ex * I.br_t;
         if (live) {
 #pragma unroll
             for (int k = 0; k < 3; k++) xyz[((size_t)n * 14 + a) * 3 + k] = p[k];
@@ -237,6 +200,7 @@ k_atom14(int N, const float *__restrict__ X, const int64_t *__restrict__ rtype,
         }
     }
     // per-residue reductions over the 16 lanes
+    const float *ca = I.ca;
     const bool has = a < 14 && ex != 0.f;
     float dca = 0.f;
     if (has) { float dx = p[0] - ca[0], dy = p[1] - ca[1], dz = p[2] - ca[2]; dca = dx * dx + dy * dy + dz * dz; }
@@ -264,6 +228,24 @@ k_atom14(int N, const float *__restrict__ X, const int64_t *__restrict__ rtype,
     }
 }
 
+__global__ void __launch_bounds__(256)
+k_atom14(int N, const float *__restrict__ X, const int64_t *__restrict__ rtype,
+         const float *__restrict__ BB_D, const float *__restrict__ chi,
+         const float *__restrict__ default_frames, const int32_t *__restrict__ a2g,
+         const float *__restrict__ amask14, const float *__restrict__ lit,
+         const float *__restrict__ atom_exists, const float *__restrict__ between_radius,
+         const int64_t *__restrict__ rindex,
+         float *__restrict__ xyz, float *__restrict__ axes, float *__restrict__ brad,
+         float4 *__restrict__ rec) {
+    const int a = threadIdx.x & 15;
+    const int nraw = blockIdx.x * 16 + (threadIdx.x >> 4);
+    const bool live = nraw < N;
+    const int n = live ? nraw : N - 1;           // out-of-range groups mirror the last residue and store nothing
+    const A14In I = a14_load(n, a, (int)rtype[n], X, BB_D, default_frames, a2g, amask14, lit, atom_exists, between_radius);
+    const float chi_t = chi[(size_t)n * 4 + (a >= 3 && a < 7 ? a - 3 : 0)];
+    a14_finish(I, n, a, live, a < 3 ? I.bbd_t : chi_t, rindex, xyz, axes, brad, rec);
+}
+
 // ---------------------------------------------------------------------------------------------
 // clash: one wave per residue.  lane = 16 * slot + a,  a = own atom (0..13), slot = 0..3 partner stripe
 // ---------------------------------------------------------------------------------------------
@@ -276,12 +258,29 @@ k_atom14(int N, const float *__restrict__ X, const int64_t *__restrict__ rtype,
 // whole loop instead of a scan over all L partners of the complex at every step -- the lists hold every residue pair whose hinge can
 // be non-zero for ANY chi (the backbone does not move), in the order and under the wave assignment of the scan, and the exact
 // per-step sphere test still runs on them: the atom pairs that contribute are the same, every contribution is the same number.
-template <bool CAND>
+//
+// FUSE (the Adam loop of pp_proximal, round 5): wave 0 goes on, for ITS residue, to Adam step U.t with the gradient it has just reduced
+// (the operands of optimize.py:47-71 as the separate k_atom14<true> launch of rounds 2-4 read them: per_res and dchi now come from
+// registers) and to the reconstruction at the new angles, which it writes into the OTHER record / axes buffer (F.rec_out, F.axes_out:
+// the other workgroups of this launch still read this step's) -- one launch per Adam step instead of two.  The four partner stripes of
+// wave 0 run the tail redundantly (same addresses, same values; stripe 0 stores): no divergence inside the 16-lane shuffles.
+struct ClashFuse {
+    const float *X, *BB_D, *default_frames, *amask14, *lit, *atom_exists, *between_radius;
+    const int64_t *rindex;
+    float *xyz, *axes_out, *brad;
+    float4 *rec_out;
+    ProxUpd U;
+};
+// (The tail's reconstruction chain wants ~130 registers; with the 33 KB candidate lists the compiler holds the kernel to the 128 of four
+// waves per SIMD and spills twenty dwords in the tail.  Buying them with amdgpu_waves_per_eu(1, 3) -- 129 registers, no scratch -- made
+// the launch 2.2x SLOWER, 36 instead of 16 us at T1124: profiles/r05_prox_fused_step.txt.  The spill stays.)
+template <bool CAND, bool FUSE>
 __global__ void __launch_bounds__(64 * CL_WAVES)
 k_clash(int N, const int2 *__restrict__ seg, const float *__restrict__ xyz, const float4 *__restrict__ rec, const float *__restrict__ exists,
         const float *__restrict__ lower, const float *__restrict__ upper, const int32_t *__restrict__ a2g,
         const float *__restrict__ axes, float tol, float inv_ntot,
-        float *__restrict__ per_res, float *__restrict__ dchi, const int32_t *__restrict__ cand, const int32_t *__restrict__ cand_cnt) {
+        float *__restrict__ per_res, float *__restrict__ dchi, const int32_t *__restrict__ cand, const int32_t *__restrict__ cand_cnt,
+        ClashFuse F) {
     __shared__ int s_list[CL_WAVES][CL_MAXC];
     __shared__ float s_red[CL_WAVES][16][4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -445,9 +444,10 @@ k_clash(int N, const int2 *__restrict__ seg, const float *__restrict__ xyz, cons
     }
     float lres = (own && a >= 4) ? loss_a : 0.f;
     for (int o = 8; o > 0; o >>= 1) lres += __shfl_xor(lres, o);
-    if (lane == 0) per_res[i] = lres / (nsc + 1e-10f);
-    if (dchi) {
-        float dk[4] = {0.f, 0.f, 0.f, 0.f};
+    const float pres = lres / (nsc + 1e-10f);
+    if (lane == 0) per_res[i] = pres;
+    float dk[4] = {0.f, 0.f, 0.f, 0.f};
+    if (dchi || FUSE) {
         if (own && a >= 5) {
             const int g = a2g[S * 14 + a];
 #pragma unroll
@@ -464,7 +464,46 @@ k_clash(int N, const int2 *__restrict__ seg, const float *__restrict__ xyz, cons
         for (int k = 0; k < 4; k++) {
             for (int o = 8; o > 0; o >>= 1) dk[k] += __shfl_xor(dk[k], o);
         }
-        if (lane < 4) dchi[(size_t)i * 4 + lane] = lane == 0 ? dk[0] : (lane == 1 ? dk[1] : (lane == 2 ? dk[2] : dk[3]));
+        if (dchi && lane < 4) dchi[(size_t)i * 4 + lane] = lane == 0 ? dk[0] : (lane == 1 ? dk[1] : (lane == 2 ? dk[2] : dk[3]));
+    }
+    if constexpr (FUSE) {
+        const ProxUpd &U = F.U;
+        const bool st = slot == 0;                  // the stripe that stores
+        // everything the tail reads, in one batch: the reconstruction's inputs and the Adam operands of chi_k, k = a < 4
+        const A14In I = a14_load(i, a, S, F.X, F.BB_D, F.default_frames, a2g, F.amask14, F.lit, F.atom_exists, F.between_radius);
+        const int k = a < 4 ? a : 0;
+        const size_t e = (size_t)i * 4 + k;
+        const float xe = U.xeff[e], ze = U.z[e], xo = U.x[e], mo = U.m[e], vo = U.v[e], c0v = U.chi0[e];
+        const bool mk = U.mask[i] != 0;
+        // loss_t = mean_n [sum_k (xeff - z)^2 + lamda per_res] at the incoming iterate; then torch.optim.Adam defaults (lr 1e-2,
+        // betas (0.9, 0.999), eps 1e-8, bias-corrected; step_size = lr / (1 - beta1^t) and bc2s = sqrt(1 - beta2^t) come from the
+        // host in double); outputs as optimize.py:66-71
+        const float dch = k == 0 ? dk[0] : (k == 1 ? dk[1] : (k == 2 ? dk[2] : dk[3]));
+        float q = 0.f, outv = 0.f;
+        if (a < 4) {
+            const float d = xe - ze;
+            q = fabsf(d) * fabsf(d);
+            const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
+            float g = 0.f;
+            if (mk) g = 2.f * (xo - ze) * U.inv_n + U.lamda * dch;
+            const float mm = mo + (g - mo) * (1.f - b1);             // exp_avg.lerp_(grad, 1 - beta1)
+            const float vv = vo * b2 + (1.f - b2) * (g * g);
+            const float denom = sqrtf(vv) / U.bc2s + eps;
+            const float xn = xo - U.step_size * (mm / denom);
+            outv = mk ? xn : c0v;
+            if (st) {
+                U.m[e] = mm; U.v[e] = vv; U.x[e] = xn;
+                U.xeff[e] = outv;
+                if (U.traj) U.traj[(size_t)U.t * N * 4 + e] = outv;
+                if (U.last) U.last[e] = outv;
+            }
+        }
+        q += __shfl_xor(q, 1, 16);
+        q += __shfl_xor(q, 2, 16);
+        if (lane == 0) U.loss_part[(size_t)U.t * N + i] = q + U.lamda * pres;
+        // the reconstruction at the new angles: lane a in 3..6 evaluates chi_(a-3), which lane a - 3 has just stepped
+        const float chi_new = __shfl(outv, (a - 3) & 15, 16);
+        a14_finish(I, i, a, st, a < 3 ? I.bbd_t : chi_new, F.rindex, F.xyz, F.axes_out, F.brad, F.rec_out);
     }
 }
 
@@ -563,12 +602,17 @@ k_prox_init(int N, const float *__restrict__ per_res, const float *__restrict__ 
     }
 }
 
-// losses[t0 + t] = (1 / N) sum over blocks, in block order, of the partial sums the UPD kernels left
-__global__ void k_prox_losses(int nt, int nblocks, float inv_n, const float *__restrict__ part, float *__restrict__ losses) {
+// losses[t0 + t] = (1 / N) sum of the per-residue terms the fused clash kernel left, in a fixed order: groups of 16 residues first,
+// then the groups in order (the order of rounds 2-4, when a 16-residue block of k_atom14<true> summed its own terms: same bits)
+__global__ void k_prox_losses(int nt, int N, float inv_n, const float *__restrict__ part, float *__restrict__ losses) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nt) return;
     float s = 0.f;
-    for (int b = 0; b < nblocks; b++) s += part[(size_t)t * nblocks + b];
+    for (int b = 0; b < N; b += 16) {
+        float tt = 0.f;
+        for (int i = b; i < b + 16 && i < N; i++) tt += part[(size_t)t * N + i];
+        s += tt;
+    }
     losses[t] = s * inv_n;
 }
 
@@ -576,9 +620,9 @@ pp_status pp_launch_atom14(pp_ctx *c, const float *chi, float *xyz, hipStream_t 
     const pp_plan *p = c->plan;
     // the packed records feed k_clash; they need the residue numbering, which geometry-only batches may not carry
     float4 *rec = c->b.residue_index ? reinterpret_cast<float4 *>(c->rec) : nullptr;
-    hipLaunchKernelGGL(k_atom14<false>, dim3((c->N + 15) / 16), dim3(256), 0, s, c->N, c->b.X, c->b.residue_type, c->b.BB_D, chi,
+    hipLaunchKernelGGL(k_atom14, dim3((c->N + 15) / 16), dim3(256), 0, s, c->N, c->b.X, c->b.residue_type, c->b.BB_D, chi,
                        p->default_frames, p->atom14_to_group, p->atom14_mask, p->lit_positions, c->b.atom_mask,
-                       p->between_radius, c->b.residue_index, xyz, c->axes, c->brad, rec, ProxUpd{});
+                       p->between_radius, c->b.residue_index, xyz, c->axes, c->brad, rec);
     PP_HIP_CHECK(hipGetLastError());
     return PP_OK;
 }
@@ -586,15 +630,15 @@ pp_status pp_launch_atom14(pp_ctx *c, const float *chi, float *xyz, hipStream_t 
 pp_status pp_launch_clash(pp_ctx *c, const float *xyz, float *per_res, float *dchi, hipStream_t s, bool use_candidates) {
     const pp_plan *p = c->plan;
     if (use_candidates && c->cand)
-        PP_LAUNCH(c, k_clash<true>, dim3(c->N), dim3(64 * CL_WAVES), 0, s, c->N, c->seg, xyz,
+        PP_LAUNCH(c, (k_clash<true, false>), dim3(c->N), dim3(64 * CL_WAVES), 0, s, c->N, c->seg, xyz,
                   reinterpret_cast<const float4 *>(c->rec), c->b.atom_mask,
                   p->bounds_lower, p->bounds_upper, p->atom14_to_group, c->axes, p->clash_tol,
-                  1.0f / (float)c->N, per_res, dchi, c->cand, c->cand_cnt);
+                  1.0f / (float)c->N, per_res, dchi, c->cand, c->cand_cnt, ClashFuse{});
     else
-        PP_LAUNCH(c, k_clash<false>, dim3(c->N), dim3(64 * CL_WAVES), 0, s, c->N, c->seg, xyz,
+        PP_LAUNCH(c, (k_clash<false, false>), dim3(c->N), dim3(64 * CL_WAVES), 0, s, c->N, c->seg, xyz,
                   reinterpret_cast<const float4 *>(c->rec), c->b.atom_mask,
                   p->bounds_lower, p->bounds_upper, p->atom14_to_group, c->axes, p->clash_tol,
-                  1.0f / (float)c->N, per_res, dchi, nullptr, nullptr);
+                  1.0f / (float)c->N, per_res, dchi, nullptr, nullptr, ClashFuse{});
     PP_HIP_CHECK(hipGetLastError());
     return PP_OK;
 }
@@ -614,37 +658,40 @@ pp_status pp_launch_proximal(pp_ctx *c, const float *chi, float lamda, int nstep
     if ((st = pp_launch_clash(c, c->xyz, c->per_res, nullptr, s, cands)) != PP_OK) return st;
     hipLaunchKernelGGL(k_prox_init, dim3(1), dim3(1024), 0, s, c->N, c->per_res, chi, c->pmask, c->pz, c->px, c->pm,
                        c->pv, c->pxeff);
-    // Per Adam step two launches: [step t on the block's residues + reconstruction at the new angles] and [clash + gradient
-    // there].  Loss terms are parked per block and reduced in block order, PP_PROX_CHUNK steps at a time.
-    const int nblocks = (c->N + 15) / 16;
-    float4 *rec = reinterpret_cast<float4 *>(c->rec);
-    if ((st = pp_launch_atom14(c, c->pxeff, c->xyz, s)) != PP_OK) return st;
-    if ((st = pp_launch_clash(c, c->xyz, c->per_res, c->dchi, s, cands)) != PP_OK) return st;
+    // ONE launch per Adam step: [clash + gradient at the current angles -> step t on the workgroup's own residue -> its
+    // reconstruction at the new angles, into the other record / axes buffer].  Loss terms are parked per residue and reduced in a
+    // fixed order, PP_PROX_CHUNK steps at a time.
+    if ((st = pp_launch_atom14(c, c->pxeff, c->xyz, s)) != PP_OK) return st;        // records and axes at the start angles -> c->rec, c->axes
+    float *rec_in = c->rec, *rec_out = c->rec2, *axes_in = c->axes, *axes_out = c->axes2;
     for (int t = 0; t < nsteps; t++) {
         const double bc1 = 1.0 - pow(0.9, (double)(t + 1)), bc2 = 1.0 - pow(0.999, (double)(t + 1));
-        ProxUpd U;
-        U.t = t; U.nblocks = nblocks;
+        ClashFuse F;
+        F.X = c->b.X; F.BB_D = c->b.BB_D; F.default_frames = p->default_frames; F.amask14 = p->atom14_mask; F.lit = p->lit_positions;
+        F.atom_exists = c->b.atom_mask; F.between_radius = p->between_radius; F.rindex = c->b.residue_index;
+        F.xyz = c->xyz; F.axes_out = axes_out; F.brad = c->brad; F.rec_out = reinterpret_cast<float4 *>(rec_out);
+        ProxUpd &U = F.U;
+        U.nblocks = 0;
         U.lamda = lamda; U.step_size = (float)(1e-2 / bc1); U.bc2s = (float)sqrt(bc2); U.inv_n = 1.0f / (float)c->N;
-        U.per_res = c->per_res; U.dchi = c->dchi; U.chi0 = chi; U.z = c->pz; U.mask = c->pmask;
-        U.x = c->px; U.m = c->pm; U.v = c->pv; U.xeff = c->pxeff; U.traj = traj; U.last = chi_last;
+        U.chi0 = chi; U.z = c->pz; U.mask = c->pmask;
+        U.x = c->px; U.m = c->pm; U.v = c->pv; U.xeff = c->pxeff; U.last = chi_last;
         U.loss_part = c->prox_part;
         U.t = t % PP_PROX_CHUNK;
-        float *traj_t = traj ? traj + (size_t)(t - U.t) * c->N * 4 : nullptr;     // U.t indexes within the chunk
-        U.traj = traj_t;
-        c->prof_armed = c->prof_which == 4;          // pp_profile_kernel(4): the fused Adam step + reconstruction
-        PP_LAUNCH(c, k_atom14<true>, dim3(nblocks), dim3(256), 0, s, c->N, c->b.X, c->b.residue_type, c->b.BB_D, c->pxeff,
-                  p->default_frames, p->atom14_to_group, p->atom14_mask, p->lit_positions, c->b.atom_mask,
-                  p->between_radius, c->b.residue_index, c->xyz, c->axes, c->brad, rec, U);
+        U.traj = traj ? traj + (size_t)(t - U.t) * c->N * 4 : nullptr;     // U.t indexes within the chunk
+        c->prof_armed = c->prof_which == 3;          // pp_profile_kernel(3): the fused clash + Adam step + reconstruction
+        if (cands)
+            PP_LAUNCH(c, (k_clash<true, true>), dim3(c->N), dim3(64 * CL_WAVES), 0, s, c->N, c->seg, c->xyz,
+                      reinterpret_cast<const float4 *>(rec_in), c->b.atom_mask, p->bounds_lower, p->bounds_upper, p->atom14_to_group,
+                      axes_in, p->clash_tol, 1.0f / (float)c->N, c->per_res, c->dchi, c->cand, c->cand_cnt, F);
+        else
+            PP_LAUNCH(c, (k_clash<false, true>), dim3(c->N), dim3(64 * CL_WAVES), 0, s, c->N, c->seg, c->xyz,
+                      reinterpret_cast<const float4 *>(rec_in), c->b.atom_mask, p->bounds_lower, p->bounds_upper, p->atom14_to_group,
+                      axes_in, p->clash_tol, 1.0f / (float)c->N, c->per_res, c->dchi, nullptr, nullptr, F);
         c->prof_armed = false;
+        std::swap(rec_in, rec_out);
+        std::swap(axes_in, axes_out);
         const bool chunk_end = U.t == PP_PROX_CHUNK - 1 || t == nsteps - 1;
         if (chunk_end)
-            hipLaunchKernelGGL(k_prox_losses, dim3(1), dim3(64), 0, s, U.t + 1, nblocks, U.inv_n, c->prox_part, losses + (t - U.t));
-        if (t + 1 < nsteps) {
-            c->prof_armed = c->prof_which == 3;      // pp_profile_kernel(3): the clash loss + gradient of the Adam loop
-            st = pp_launch_clash(c, c->xyz, c->per_res, c->dchi, s, cands);
-            c->prof_armed = false;
-            if (st != PP_OK) return st;
-        }
+            hipLaunchKernelGGL(k_prox_losses, dim3(1), dim3(64), 0, s, U.t + 1, c->N, U.inv_n, c->prox_part, losses + (t - U.t));
     }
     PP_HIP_CHECK(hipGetLastError());
     return PP_OK;

@@ -157,6 +157,7 @@ struct pp_ctx {
     float *xyz;               // [N][14][3]
     float *rec;               // [N][16][4] packed per-residue records for k_clash (positions + radii, CA + reach, ids)
     float *axes;              // [N][4][6]  chi-frame x-axis (3) | origin (3)
+    float *rec2, *axes2;      // the other buffers of the proximal loop: step t reads rec / axes of step t and writes those of step t + 1
     float *brad;              // [N] bounding radius around CA
     float *per_res;           // [N]
     float *dchi;              // [N][4]

@@ -460,8 +460,7 @@ def test_bench_summary_is_small_and_last():
     spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
-    prox = {"k_clash": {"kernel_us": 14.61234, "frac": 0.0123456, "culled_fraction_of_residue_pairs": 0.98765},
-            "k_atom14<true>": {"kernel_us": 10.21234, "frac": 0.0081234}}
+    prox = {"k_clash": {"kernel_us": 16.21234, "frac": 0.0123456, "culled_fraction_of_residue_pairs": 0.98765, "hbm_frac": 0.0051234}}
     out = {"value": 60967.123456, "ms_per_step": 12.105123, "scaling": "weak", "n_gpus": 1,
            "config": {"workload": "data/T1124_lig.pdb"}, "parity": {"max_abs_dchi_vs_reference_rad": 4.812345e-6},
            "secondary": [{"config": c, "value": 53812.123, "ms_per_step": 13.7123, "max_abs_dchi_vs_reference_rad": 4.8e-6,
