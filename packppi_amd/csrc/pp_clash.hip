@@ -603,17 +603,29 @@ k_prox_init(int N, const float *__restrict__ per_res, const float *__restrict__ 
 }
 
 // losses[t0 + t] = (1 / N) sum of the per-residue terms the fused clash kernel left, in a fixed order: groups of 16 residues first,
-// then the groups in order (the order of rounds 2-4, when a 16-residue block of k_atom14<true> summed its own terms: same bits)
-__global__ void k_prox_losses(int nt, int N, float inv_n, const float *__restrict__ part, float *__restrict__ losses) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nt) return;
+// then the groups in order (the order of rounds 2-4, when a 16-residue block of k_atom14<true> summed its own terms).  One workgroup per
+// step: a lane adds up one group (16 sequential adds), the group sums meet in LDS and lane 0 adds them in order -- the chain of N dependent
+// loads a single lane per step would walk is 185 us at T1124.
+__global__ void __launch_bounds__(256)
+k_prox_losses(int N, float inv_n, const float *__restrict__ part, float *__restrict__ losses) {
+    __shared__ float s_tt[256];
+    const int t = blockIdx.x;
+    const int ngroups = (N + 15) / 16;
     float s = 0.f;
-    for (int b = 0; b < N; b += 16) {
+    for (int g0 = 0; g0 < ngroups; g0 += 256) {          // 256 groups (4096 residues) at a time, in order
+        const int g = g0 + threadIdx.x;
         float tt = 0.f;
-        for (int i = b; i < b + 16 && i < N; i++) tt += part[(size_t)t * N + i];
-        s += tt;
+        if (g < ngroups)
+            for (int i = 16 * g; i < 16 * g + 16 && i < N; i++) tt += part[(size_t)t * N + i];
+        s_tt[threadIdx.x] = tt;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int n = ngroups - g0 < 256 ? ngroups - g0 : 256;
+            for (int q = 0; q < n; q++) s += s_tt[q];
+        }
+        __syncthreads();
     }
-    losses[t] = s * inv_n;
+    if (threadIdx.x == 0) losses[t] = s * inv_n;
 }
 
 pp_status pp_launch_atom14(pp_ctx *c, const float *chi, float *xyz, hipStream_t s) {
@@ -691,7 +703,7 @@ pp_status pp_launch_proximal(pp_ctx *c, const float *chi, float lamda, int nstep
         std::swap(axes_in, axes_out);
         const bool chunk_end = U.t == PP_PROX_CHUNK - 1 || t == nsteps - 1;
         if (chunk_end)
-            hipLaunchKernelGGL(k_prox_losses, dim3(1), dim3(64), 0, s, U.t + 1, c->N, U.inv_n, c->prox_part, losses + (t - U.t));
+            hipLaunchKernelGGL(k_prox_losses, dim3(U.t + 1), dim3(256), 0, s, c->N, U.inv_n, c->prox_part, losses + (t - U.t));
     }
     PP_HIP_CHECK(hipGetLastError());
     return PP_OK;
