@@ -100,23 +100,15 @@ def pack(complexes: Iterable[Batch]) -> Batch:
     complexes = list(complexes)
     rows = {k: [] for k in TENSOR_KEYS}
     offs = [0]
-    masks = []
+    ends = []
     for c in complexes:
         lead = c["residue_type"].dim() == 2
         if lead and c["residue_type"].shape[0] != 1:
             raise ValueError("pack() takes single complexes (use split() on a padded batch first)")
-        masks.append(c["residue_mask"][0] if lead else c["residue_mask"])
-    # index of the last true residue + 1 of every complex (0 for an empty one), computed where the masks live: one concatenation,
-    # one segmented maximum and ONE read-back for the whole batch (a per-complex reduction was a hundred small launches for 32 complexes)
-    lens = [int(m.numel()) for m in masks]
-    if sum(lens) == 0:
-        raise ValueError("empty complex")
-    dev = masks[0].device
-    seg = torch.repeat_interleave(torch.arange(len(lens)), torch.tensor(lens)).to(dev, non_blocking=True)
-    pos1 = torch.cat([torch.arange(1, n + 1) for n in lens]).to(dev, non_blocking=True)
-    last = torch.zeros(len(lens), dtype=torch.int64, device=dev)
-    last.scatter_reduce_(0, seg, torch.where(torch.cat(masks) > 0, pos1, torch.zeros_like(pos1)), "amax")
-    ends = [int(x) for x in last.tolist()]
+        keep = (c["residue_mask"][0] if lead else c["residue_mask"]) > 0
+        # index of the last true residue + 1 (0 for an empty complex), computed where the mask lives
+        ends.append((keep * torch.arange(1, keep.numel() + 1, device=keep.device)).max())
+    ends = [int(x) for x in torch.stack(ends).tolist()]            # ONE read-back for the whole batch
     for c, n in zip(complexes, ends):
         if n == 0:
             raise ValueError("empty complex")
@@ -131,19 +123,6 @@ def pack(complexes: Iterable[Batch]) -> Batch:
     out["seg_offsets"] = torch.tensor(offs, dtype=torch.int32).to(out["X"].device, non_blocking=True)
     out["seg_offsets_host"] = offs
     return out
-
-
-def true_counts(complexes: Iterable[Batch]) -> List[int]:
-    """Number of true residues of every complex (B = 1 batches or per-complex data): one concatenation, one segmented sum and ONE
-    read-back, where the masks live."""
-    masks = [c["residue_mask"].reshape(-1) for c in complexes]
-    if not masks:
-        return []
-    lens = [int(m.numel()) for m in masks]
-    dev = masks[0].device
-    seg = torch.repeat_interleave(torch.arange(len(lens)), torch.tensor(lens)).to(dev, non_blocking=True)
-    cnt = torch.zeros(len(lens), dtype=torch.int64, device=dev).index_add_(0, seg, (torch.cat(masks) > 0).to(torch.int64))
-    return [int(x) for x in cnt.tolist()]
 
 
 def unpack(packed: Batch, t: torch.Tensor) -> List[torch.Tensor]:

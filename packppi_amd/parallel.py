@@ -108,7 +108,7 @@ def sample_sharded(model, complexes, use_proximal=False, group=None, init_chi=No
     reference defines for one complex at a time (optimize.py:27), and the metrics then run per complex.
     ``init_chi`` (optional, {complex id: [1, L, 4]}) injects the initial noised angles instead of drawing them.
     Returns (chi per local complex id, ids_all, rows_all)."""
-    from .batch import pack, unpack, true_counts as _true_counts
+    from .batch import pack, unpack
     from .functional import proximal_optimizer
     if rank is None:
         rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -119,7 +119,7 @@ def sample_sharded(model, complexes, use_proximal=False, group=None, init_chi=No
     mine = shard_complexes(lengths, world)[rank]
     cfg = model.hparams.sample_cfg
     groups, cur, rows_in = [], [], 0
-    true_counts = _true_counts([complexes[i] for i in mine])       # one read-back
+    true_counts = (torch.stack([(complexes[i]["residue_mask"] > 0).sum() for i in mine]).tolist() if mine else [])   # one read-back
     for i, n_true in zip(mine, true_counts):
         n = int(complexes[i]["max_size"])
         # K = min(32, L) is a property of the batch (encoder.py:115): a complex that is shorter than 32 rows once its trailing
