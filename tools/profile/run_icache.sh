@@ -17,7 +17,7 @@ for SET in "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_D
   rocprofv3 --pmc $SET --output-format csv -d $OUT/p$i -o run -- $BENCH > $OUT/p$i.json 2> $OUT/p$i.err || echo "pass $i failed: $(tail -2 $OUT/p$i.err)"
   echo "pass $i done"
 done
-cd $ROOT; find $OUT -type f ! -name "*counter_collection.csv" ! -name "*.err" -delete; du -sh $OUT
+cd $ROOT; find $OUT -type f ! -name "*counter_collection.csv" ! -name "*.err" -delete; du -sh $OUT | cut -f1
 python3 - <<'PY'
 import csv, glob, collections
 for f in sorted(glob.glob("gpurun_out/icache/p*/**/*counter_collection.csv", recursive=True)):

@@ -16,5 +16,5 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o run -- $BENCH > 
 echo "fetch pass done"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -o run -- $BENCH > $OUT/write.json 2> $OUT/write.err
 echo "write pass done"
-cd $ROOT; find $OUT -type f ! -name "*.csv" ! -name "*.json" ! -name "*.err" -delete; du -sh $OUT
+cd $ROOT; find $OUT -type f ! -name "*.csv" ! -name "*.json" ! -name "*.err" -delete; du -sh $OUT | cut -f1
 tail -2 $OUT/stats.err; python3 tools/profile/summarize.py $OUT $TAG
