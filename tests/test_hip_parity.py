@@ -261,6 +261,29 @@ def test_proximal(tag):
     assert abs(float(m["atom_rmsd"]) - float(z["metric32.atom_rmsd"])) < 1e-3, (tag, float(m["atom_rmsd"]))
 
 
+def test_proximal_loss_reduction_at_odd_and_large_sizes():
+    """The loss of a proximal step is reduced from per-residue terms in a fixed order (k_prox_losses: groups of 16 residues, 256 groups
+    at a time).  First loss value of the loop against the same quantity assembled with torch from compute_residue_clash -- optimize.py:47-52
+    at the incoming iterate: mean_n [sum_k (chi - z)^2 + lamda per_res], z = chi where the residue is above the mean clash -- on a size that
+    is no multiple of 16 and on one beyond 4096 residues (the second 256-group window)."""
+    from packppi_amd import synth
+    from packppi_amd.featurize import protein_to_batch
+    from packppi_amd.functional import compute_residue_clash, proximal_optimizer
+    for L in (203, 4200):
+        gb = protein_to_batch(synth.make_complex(L, 900 + L)).to(DEV)
+        gen = torch.Generator().manual_seed(L)
+        chi = ((torch.rand(1, L, 4, generator=gen) * 2 - 1) * 3.0).to(DEV) * gb.SC_D_mask
+        chis, losses = proximal_optimizer(gb, chi, 12.0, 0.5, 1.0, 3)
+        chis2, losses2 = proximal_optimizer(gb, chi, 12.0, 0.5, 1.0, 3)
+        assert losses == losses2 and all(torch.equal(a, b) for a, b in zip(chis, chis2))
+        pr = compute_residue_clash(gb, chi, 12.0, 0.5).double()                       # [1, L]
+        keep = (pr > pr.float().mean().double()).unsqueeze(-1)                       # the residues the optimiser moves
+        z = chi.double() * keep
+        want = float((((chi.double() - z) ** 2).sum(-1) + 1.0 * pr).mean())
+        assert abs(losses[0] - want) <= 2e-6 * max(1.0, abs(want)), (L, losses[0], want)
+        assert np.isfinite(losses).all() and losses[-1] <= losses[0] + 1e-6
+
+
 def test_proximal_is_bit_reproducible():
     """The clash loss and its gradient are gathered per residue and reduced in a fixed order (no atomics): two runs of the
     50-step optimisation agree bit for bit, losses included."""
