@@ -673,7 +673,8 @@ pp_status pp_launch_proximal(pp_ctx *c, const float *chi, float lamda, int nstep
     // ONE launch per Adam step: [clash + gradient at the current angles -> step t on the workgroup's own residue -> its
     // reconstruction at the new angles, into the other record / axes buffer].  Loss terms are parked per residue and reduced in a
     // fixed order, PP_PROX_CHUNK steps at a time.
-    if ((st = pp_launch_atom14(c, c->pxeff, c->xyz, s)) != PP_OK) return st;        // records and axes at the start angles -> c->rec, c->axes
+    // (records and axes at the start angles are in c->rec / c->axes already: the atom14 launch above ran at `chi`, which is what
+    // k_prox_init has just copied into xeff, and the clash launch between them writes neither)
     float *rec_in = c->rec, *rec_out = c->rec2, *axes_in = c->axes, *axes_out = c->axes2;
     for (int t = 0; t < nsteps; t++) {
         const double bc1 = 1.0 - pow(0.9, (double)(t + 1)), bc2 = 1.0 - pow(0.999, (double)(t + 1));
